@@ -1,0 +1,293 @@
+"""NumPy restatement of the reference `thrifty detect` per-block algorithm.
+
+TEST INFRASTRUCTURE ONLY.  This module is the parity oracle for the HIP path in
+``thrifty_amd``; it is imported by tests/, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` and by nothing else.  The shipped product
+never routes through it.
+
+Parity status: PINNED.  ``tests/test_oracle_golden.py`` checks every function
+below against fixtures produced by importing the reference itself
+(``tests/golden/make_golden.py``; NumPy 2.2.6 / SciPy 1.15.3, np.fft branch of
+signal_utils.py:10-32) and against the known-answer tables of the reference's
+own unit tests (tests/test_carrier_detect.py, test_carrier_sync.py,
+test_soa_estimator.py, test_block_data.py, test_util.py).
+
+Each function cites the reference file:line it follows (paths relative to the
+reference checkout).  Third-party arithmetic: ``np.fft`` (pocketfft) and
+``scipy.optimize.curve_fit`` (MINPACK lmdif) exactly as the reference calls
+them (signal_utils.py:23-32, carrier_sync.py:189); the reference does not pin
+their versions (requirements.txt:2-3).
+
+dtype notes (NumPy >= 2 semantics, which the fixtures were generated under):
+FFT #1 and the carrier statistics stay complex64/float32; the frequency shift,
+FFT #2, the IFFT and all correlation statistics are complex128/float64
+(carrier_sync.py:235-237 promotes).
+"""
+from __future__ import annotations
+
+import math
+from collections import namedtuple
+
+import numpy as np
+from scipy.optimize import curve_fit
+
+CarrierStage = namedtuple("CarrierStage", "detected bin offset energy noise threshold")
+CorrStage = namedtuple("CorrStage", "detected sample offset energy noise threshold")
+BlockResult = namedtuple("BlockResult", "detected soa carrier corr")
+
+
+# --------------------------------------------------------------------------
+# a1: u8 IQ pairs -> complex64            (block_data.py:38-52, rawconv.c:10-26)
+# --------------------------------------------------------------------------
+def iq_u8_to_c64(raw):
+    raw = np.asarray(raw, dtype=np.uint8)
+    z = raw.astype(np.float32).view(np.complex64)
+    z -= 127.4 + 127.4j
+    z /= 128
+    return z
+
+
+def c64_to_iq_u8(z):
+    """Inverse quantiser (block_data.py:55-67): *128 + 127.4, truncate."""
+    f = np.asarray(z).astype(np.complex64).view(np.float32) * 128 + 127.4
+    return f.astype(np.uint8)
+
+
+# --------------------------------------------------------------------------
+# a5: carrier window + threshold detector          (carrier_detect.py:17-154)
+# --------------------------------------------------------------------------
+def window_to_indices(start, stop, n):
+    """Closed bin interval -> FFT index interval (carrier_detect.py:17-58).
+
+    ``stop`` may come back >= n, meaning the window wraps."""
+    if abs(start) >= n or abs(stop) >= n:
+        raise ValueError("Frequency window out of range: {} - {}".format(start, stop))
+    if start < 0 <= stop:
+        start, stop = n + start, n + stop
+    if start < 0:
+        start += n
+    if stop < 0:
+        stop += n
+    if stop < start:
+        start, stop = stop, start
+    return start, stop
+
+
+def carrier_peak(mag, window):
+    """First-max inside the (wrapping, inclusive) window (carrier_detect.py:118-154
+    with peak_filter=None).  Keeps the reference's ``> len`` quirk."""
+    n = len(mag)
+    lo, hi = window_to_indices(*(window if window is not None else (0, -1)), n)
+    sel = np.take(mag, range(lo, hi + 1), mode="wrap")
+    rel = int(np.argmax(sel))
+    peak_mag = sel[rel]
+    idx = rel + lo
+    if idx > n:
+        idx -= n
+    return idx, peak_mag
+
+
+def carrier_noise(mag, peak_mag):
+    """sqrt((sum mag^2 - 2 peak^2)/(N-1))  (carrier_detect.py:99-107)."""
+    total = np.sum(mag ** 2)
+    with np.errstate(invalid="ignore"):
+        return np.sqrt((total - 2 * peak_mag ** 2) / (len(mag) - 1))
+
+
+def threshold_value(mag, coeffs, noise_rms):
+    """sqrt(c + s*noise^2 + d*std(mag)^2)  (carrier_detect.py:110-115,
+    soa_estimator.py:127-134)."""
+    c, s, d = coeffs
+    std = np.std(mag) if d else 0
+    with np.errstate(invalid="ignore"):
+        return np.sqrt(c + s * noise_rms ** 2 + d * std ** 2)
+
+
+def carrier_detect(mag, coeffs, window):
+    """(detected, bin, peak_mag, noise_rms, threshold)  (carrier_detect.py:61-96)."""
+    idx, peak = carrier_peak(mag, window)
+    noise = carrier_noise(mag, peak)
+    thr = threshold_value(mag, coeffs, noise)
+    return bool(peak > thr), idx, peak, noise, thr
+
+
+# --------------------------------------------------------------------------
+# a6: Dirichlet-kernel sub-bin fit                  (carrier_sync.py:121-196)
+# --------------------------------------------------------------------------
+def dirichlet(x, n, w):
+    """sin(pi W x/N) / (W sin(pi x/N)), 1 at x=0  (carrier_sync.py:121-132)."""
+    x = np.array(x, dtype=np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        d = np.sin(np.pi * w * x / n) / np.sin(np.pi * x / n) / w
+        d[np.isnan(d)] = 1
+    return d
+
+
+def dirichlet_fit(mag, peak_idx, n, w, width=6):
+    """Least-squares (A, offset) of A*|D(x-offset)| over peak_idx + [-3..3],
+    SciPy curve_fit from p0 = (mag[peak], 0)  (carrier_sync.py:179-194).
+    Indexing is NumPy's: negative indices wrap, >= N raises IndexError."""
+    xs = np.arange(-(width // 2), width // 2 + 1)
+    ys = mag[peak_idx + xs]
+
+    def model(x, amp, off):
+        return amp * np.abs(dirichlet(np.array(x, dtype=np.float64) - off, n, w))
+
+    popt, _ = curve_fit(model, xs, ys, p0=(mag[peak_idx], 0))
+    return popt[0], popt[1]
+
+
+# --------------------------------------------------------------------------
+# a7: fractional frequency shift + FFT #2           (carrier_sync.py:222-238)
+# --------------------------------------------------------------------------
+def shift_and_fft(x, shift):
+    n = len(x)
+    ramp = np.arange(n) * 1.0 / n - 0.5
+    rot = np.exp(2j * np.pi * shift * ramp)
+    return np.fft.fft(x * rot)
+
+
+# --------------------------------------------------------------------------
+# a9-a14: matched filter + SoA estimator               (soa_estimator.py)
+# --------------------------------------------------------------------------
+def unique_window(block_len, history_len, template_len):
+    """Half-open range of lags unique to a block (soa_estimator.py:20-39)."""
+    assert history_len >= template_len - 1
+    corr_len = block_len - template_len + 1
+    pad = history_len - template_len + 1
+    left = pad // 2
+    return left, corr_len - (pad - left)
+
+
+class TemplateBank(object):
+    """Per-template constants (soa_estimator.py:63-76)."""
+
+    def __init__(self, template, block_len, history_len):
+        template = np.asarray(template)
+        self.template = template
+        self.energy = np.sum(np.abs(template) ** 2)
+        self.template_len = len(template)
+        self.corr_len = block_len - self.template_len + 1
+        padded = np.concatenate([template, np.zeros(self.corr_len - 1)])
+        self.spectrum = np.fft.fft(padded)
+        # cached like signal_utils.py:130-136: a *named* conjugate keeps NumPy from
+        # eliding a temporary into an in-place multiply (different rounding path)
+        self.spectrum_conj = np.conj(self.spectrum)
+        self.window = unique_window(block_len, history_len, self.template_len)
+
+
+def despread(xhat, bank):
+    """ifft(X * conj(T))[:corr_len]  (soa_estimator.py:97-102)."""
+    prod = xhat * bank.spectrum_conj
+    return np.fft.ifft(prod)[: bank.corr_len]
+
+
+def corr_peak(corr_mag, window):
+    lo, hi = window
+    idx = int(np.argmax(corr_mag[lo:hi])) + lo
+    return idx, corr_mag[idx]
+
+
+def corr_noise(xhat, bank, peak_mag):
+    """sqrt((mean|X|^2 * sum t^2 - peak^2)/N)  (soa_estimator.py:108-120,
+    signal_utils.py:118-128)."""
+    energy = np.sqrt(np.mean(np.abs(xhat) ** 2)) ** 2
+    with np.errstate(invalid="ignore"):
+        return np.sqrt((energy * bank.energy - peak_mag ** 2) / len(xhat))
+
+
+def log_parabola(corr_mag, idx):
+    """Gaussian 3-point interpolation (soa_estimator.py:159-170)."""
+    if idx == 0 or idx == len(corr_mag) - 1:
+        return 0
+    a, b, c = np.log(corr_mag[idx - 1]), np.log(corr_mag[idx]), np.log(corr_mag[idx + 1])
+    return 0.5 * (c - a) / (2 * b - a - c)
+
+
+def clip_offset(v, lim=0.6):
+    return -lim if v < -lim else lim if v > lim else v
+
+
+def soa_estimate(xhat, bank, coeffs):
+    """(CorrStage, corr)  (soa_estimator.py:78-92)."""
+    corr = despread(xhat, bank)
+    mag = np.abs(corr)
+    idx, peak = corr_peak(mag, bank.window)
+    noise = corr_noise(xhat, bank, peak)
+    thr = threshold_value(mag, coeffs, noise)
+    det = bool(peak > thr)
+    off = clip_offset(log_parabola(mag, idx) if det else 0)
+    return CorrStage(det, idx, off, peak, noise, thr), corr
+
+
+# --------------------------------------------------------------------------
+# a8 + a15: one block end to end        (carrier_sync.py:52-76, detect.py:60-78)
+# --------------------------------------------------------------------------
+class OracleDetector(object):
+    """Functional twin of reference ``Detector`` for ONE template or several.
+
+    ``detect_block`` returns one BlockResult per template (the reference has a
+    single template; with several the carrier stage is shared, which is what
+    running the reference once per template yields)."""
+
+    def __init__(self, block_len, history_len, templates, carrier_thresh,
+                 carrier_window, corr_thresh, carrier_len=None):
+        if isinstance(templates, np.ndarray) and templates.ndim == 1:
+            templates = [templates]
+        self.block_len = block_len
+        self.history_len = history_len
+        self.new_len = block_len - history_len
+        self.banks = [TemplateBank(t, block_len, history_len) for t in templates]
+        self.carrier_len = carrier_len if carrier_len is not None else len(templates[0])
+        self.carrier_thresh = carrier_thresh
+        self.carrier_window = carrier_window
+        self.corr_thresh = corr_thresh
+
+    def carrier_stage(self, x):
+        spec = np.fft.fft(x)
+        mag = np.abs(spec)
+        det, idx, peak, noise, thr = carrier_detect(mag, self.carrier_thresh,
+                                                    self.carrier_window)
+        off = 0
+        xhat = None
+        if det:
+            _, off = dirichlet_fit(mag, idx, self.block_len, self.carrier_len)
+            xhat = shift_and_fft(x, -(idx + off))
+        return CarrierStage(det, idx, off, peak, noise, thr), xhat, mag
+
+    def detect_block(self, block_idx, x, want_data=False):
+        assert len(x) == self.block_len
+        car, xhat, _ = self.carrier_stage(x)
+        out, data = [], []
+        for bank in self.banks:
+            if xhat is None:
+                out.append(BlockResult(False, None, car, None))
+                data.append((None, None))
+                continue
+            cs, corr = soa_estimate(xhat, bank, self.corr_thresh)
+            soa = self.new_len * block_idx + cs.sample + cs.offset
+            out.append(BlockResult(cs.detected, soa, car, cs))
+            data.append((xhat, corr))
+        return (out, data) if want_data else out
+
+    def detect_u8(self, block_idx, raw, want_data=False):
+        return self.detect_block(block_idx, iq_u8_to_c64(raw), want_data)
+
+
+# --------------------------------------------------------------------------
+# a16: .toad line                                      (toads_data.py:47-61)
+# --------------------------------------------------------------------------
+def toad_line(rxid, timestamp, block_idx, res):
+    car, cs = res.carrier, res.corr
+    s = ("{t:.6f} {b} {s:.8f} {ps} {po} {pe} {pn} {cb} {co} {ce} {cn}".format(
+        t=timestamp, b=block_idx, s=res.soa, ps=cs.sample, po=cs.offset,
+        pe=cs.energy, pn=cs.noise, cb=car.bin, co=car.offset, ce=car.energy,
+        cn=car.noise))
+    if rxid is not None:
+        s = str(rxid) + " " + s
+    return s
+
+
+def fft_bin(idx, n):
+    """FFT index -> signed bin (util.py:11-22)."""
+    return idx if (idx < 0 or idx <= (2 * n - 1) / 4) else idx - n
