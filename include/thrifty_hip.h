@@ -1,0 +1,166 @@
+/*
+ * thrifty_hip.h -- C ABI of the MI355X (gfx950) matched-filter detection engine.
+ *
+ * This is the drop-in boundary for the `thrifty detect` hot path.  Each entry
+ * point names the reference interface it stands in for (paths relative to the
+ * swkrueger/Thrifty checkout).  Conventions follow the reference's native twin
+ * (fastcard/fastcard.h:46-53, fastdet/corr_detector.h:24-38): an opaque handle
+ * created from a caller-owned settings struct, `int` status returns
+ * (0 = ok, <0 = error; the message is available from thr_last_error()), the
+ * library owns all FFT/work buffers, a handle is single-threaded / not
+ * re-entrant, and distinct handles are fully independent (one per device and
+ * stream), so a host may drive 8 GPUs from 8 processes or threads.
+ *
+ * No exceptions cross this boundary and no torch / C++ types appear in it.
+ */
+#ifndef THRIFTY_HIP_H
+#define THRIFTY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define THR_ABI_VERSION 1
+
+/* status codes */
+#define THR_OK 0
+#define THR_ERR_ARG (-1)      /* bad argument / unsupported configuration      */
+#define THR_ERR_DEVICE (-2)   /* HIP runtime error (no GPU, OOM, launch failure) */
+#define THR_ERR_STATE (-3)    /* call sequence error                            */
+
+/* thr_record.flags */
+#define THR_FLAG_CARRIER 1u      /* carrier_detect verdict (carrier_detect.py:95)  */
+#define THR_FLAG_CORR 2u         /* correlation peak verdict (soa_estimator.py:85) */
+#define THR_FLAG_INDEX_ERROR 4u  /* reference raises IndexError here: carrier bin
+                                    + 3 >= block_len (carrier_sync.py:187)         */
+
+/* input sample formats for thr_detect*() */
+#define THR_IN_U8 0   /* interleaved unsigned 8-bit I,Q (RTL-SDR; block_data.py:38-52) */
+#define THR_IN_C64 1  /* interleaved float32 re,im (a `Signal` already converted)     */
+
+/*
+ * Detector configuration.  Mirrors `DetectorSettings` (thrifty/detect.py:24-31)
+ * plus what `Detector.__init__` derives from it (detect.py:40-58); the native
+ * twin's equivalent is fargs_t + CorrDetector's ctor (corr_detector.h:26-30).
+ */
+typedef struct thr_settings {
+    int32_t block_len;        /* samples per block, power of two                   */
+    int32_t history_len;      /* samples repeated from the previous block          */
+    int32_t n_templates;      /* >= 1 (the reference has exactly 1)                */
+    int32_t template_len;     /* samples per template (all templates equal length) */
+    const double* templates;  /* [n_templates][template_len], real, time domain    */
+    int32_t carrier_len;      /* Dirichlet-kernel width; 0 = template_len          */
+    int32_t carrier_window[2];/* closed bin interval, negative = wrap
+                                 (carrier_detect.py:17-58); {0,-1} = all bins       */
+    double carrier_thresh[3]; /* (constant, snr, stddev) carrier_detect.py:110-115 */
+    double corr_thresh[3];    /* (constant, snr, stddev) soa_estimator.py:127-134  */
+    int32_t device_id;        /* HIP device ordinal                                */
+    int32_t max_batch;        /* largest number of blocks per thr_detect*() call   */
+} thr_settings;
+
+/*
+ * One detection record per (block, template): the payload of
+ * `DetectionResult` / `CarrierSyncInfo` / `CorrDetectionInfo`
+ * (thrifty/toads_data.py:8-45) and of fastdet's CorrDetection
+ * (corr_detector.h:14-22).  64 bytes, written densely as out[block][template].
+ */
+typedef struct thr_record {
+    int64_t block_idx;      /* caller's block index (passed through)              */
+    uint32_t flags;         /* THR_FLAG_*                                          */
+    int32_t template_id;    /* 0 .. n_templates-1                                  */
+    int32_t carrier_bin;    /* CarrierSyncInfo.bin                                 */
+    int32_t corr_sample;    /* CorrDetectionInfo.sample (-1 if no carrier)         */
+    double carrier_offset;  /* CarrierSyncInfo.offset (0 if no carrier)            */
+    double corr_offset;     /* CorrDetectionInfo.offset, clipped to +-0.6          */
+    float carrier_energy;   /* CarrierSyncInfo.energy (peak magnitude)             */
+    float carrier_noise;    /* CarrierSyncInfo.noise  (rms)                        */
+    float corr_energy;      /* CorrDetectionInfo.energy (peak magnitude)           */
+    float corr_noise;       /* CorrDetectionInfo.noise  (rms)                      */
+    uint64_t reserved;
+} thr_record;
+
+typedef struct thr_handle thr_handle;
+
+/* Library / ABI identification. */
+int thr_abi_version(void);
+const char* thr_last_error(void);
+
+/*
+ * Replaces `Detector.__init__` (detect.py:40-58: DefaultSynchronizer +
+ * SoaEstimator construction incl. template zero-pad + FFT,
+ * soa_estimator.py:63-76) and fastcard_new()/CorrDetector::CorrDetector
+ * (fastcard.c:13-117, corr_detector.cpp:31-86).  `settings` and the template
+ * array need only live for the duration of the call.
+ */
+int thr_create(const thr_settings* settings, thr_handle** out);
+/* Replaces fastcard_free() (fastcard.c:119-146). */
+void thr_destroy(thr_handle* h);
+
+/*
+ * Replaces the body of the hot loop: `Detector.detect` (detect.py:60-78) ==
+ * Synchronizer.sync (carrier_sync.py:52-76) + SoaEstimator.soa_estimate
+ * (soa_estimator.py:78-92), and fastcard_process() + CorrDetector::detect()
+ * (fastcard.c:177-189, corr_detector.cpp:177-197), for `n_blocks` blocks at once.
+ *
+ * Host-buffer form: `samples` is n_blocks * block_len samples in `format`
+ * (u8: 2 bytes/sample; c64: 8 bytes/sample) in host memory; `block_idx` (may be
+ * NULL -> 0,1,2,...) is copied into the records; `out` receives
+ * n_blocks * n_templates records, ordered [block][template].  Synchronous.
+ */
+int thr_detect(thr_handle* h, const void* samples, int format, const int64_t* block_idx,
+               size_t n_blocks, thr_record* out);
+
+/*
+ * Device-resident form (what bench.py times): `d_samples`, `d_block_idx`
+ * (may be NULL) and `d_out` are device pointers on the handle's device.  The
+ * work is enqueued on the handle's stream and NOT synchronised; call
+ * thr_sync() (or synchronise the stream you passed to thr_set_stream()).
+ */
+int thr_detect_device(thr_handle* h, const void* d_samples, int format,
+                      const int64_t* d_block_idx, size_t n_blocks, thr_record* d_out);
+int thr_sync(thr_handle* h);
+/* Use an externally owned hipStream_t (e.g. torch's current stream); NULL restores the handle's own. */
+int thr_set_stream(thr_handle* h, void* hip_stream);
+
+/*
+ * K7: keep only records whose THR_FLAG_CORR is set, preserving order -- what
+ * detector_cli's `if detected: print(result.serialize())` does (detect.py:217-219).
+ * Device pointers; `*n_kept` is written on the host after an internal sync.
+ */
+int thr_compact_device(thr_handle* h, const thr_record* d_in, size_t n_records,
+                       thr_record* d_out, size_t* n_kept);
+
+/*
+ * Per-kernel timing with HIP events on the handle's stream (bench.py's
+ * roofline leg).  After enabling, every thr_detect*() call brackets each
+ * kernel with events; thr_profile_read() syncs and returns accumulated
+ * milliseconds and launch counts per kernel slot and resets the accumulators.
+ * Slots: 0 = carrier (FFT#1 + peak), 1 = fit, 2 = correlate (FFT#2..SoA).
+ */
+#define THR_N_KERNEL_SLOTS 3
+int thr_profile_enable(thr_handle* h, int on);
+int thr_profile_read(thr_handle* h, double ms[THR_N_KERNEL_SLOTS],
+                     int64_t launches[THR_N_KERNEL_SLOTS]);
+const char* thr_kernel_name(int slot);
+
+/*
+ * Test hooks (tests/ only).  Host pointers, synchronous.
+ * thr_debug_fft: forward FFT of n_blocks blocks -> complex64 spectra in natural
+ *   order (parity of K1+K2 against np.fft.fft, signal_utils.py:21-25).
+ * thr_debug_stage: per-block intermediates of Detector.detect(yield_data=True)
+ *   (detect.py:75-78): the frequency-shifted spectrum and the correlation
+ *   (first corr_len lags) for template `template_id`; either output may be NULL.
+ */
+int thr_debug_fft(thr_handle* h, const void* samples, int format, size_t n_blocks,
+                  float* spectra_out /* [n_blocks][block_len][2] */);
+int thr_debug_stage(thr_handle* h, const void* samples, int format, size_t n_blocks,
+                    int template_id, float* shifted_fft_out /* [n][block_len][2] */,
+                    float* corr_out /* [n][block_len][2] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* THRIFTY_HIP_H */

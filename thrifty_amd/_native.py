@@ -1,0 +1,226 @@
+"""ctypes binding of libthriftyhip.so (include/thrifty_hip.h).
+
+There is deliberately no fallback: if the shared library is missing or no
+MI355X is visible, constructing an :class:`Engine` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libthriftyhip.so")
+
+THR_IN_U8 = 0
+THR_IN_C64 = 1
+FLAG_CARRIER = 1
+FLAG_CORR = 2
+FLAG_INDEX_ERROR = 4
+N_KERNEL_SLOTS = 3
+
+EXPORTS = [
+    "thr_abi_version", "thr_last_error", "thr_create", "thr_destroy", "thr_detect",
+    "thr_detect_device", "thr_sync", "thr_set_stream", "thr_compact_device",
+    "thr_profile_enable", "thr_profile_read", "thr_kernel_name", "thr_debug_fft",
+    "thr_debug_stage",
+]
+
+
+class ThrSettings(C.Structure):
+    _fields_ = [
+        ("block_len", C.c_int32), ("history_len", C.c_int32),
+        ("n_templates", C.c_int32), ("template_len", C.c_int32),
+        ("templates", C.POINTER(C.c_double)),
+        ("carrier_len", C.c_int32), ("carrier_window", C.c_int32 * 2),
+        ("carrier_thresh", C.c_double * 3), ("corr_thresh", C.c_double * 3),
+        ("device_id", C.c_int32), ("max_batch", C.c_int32),
+    ]
+
+
+# numpy mirror of thr_record (64 bytes)
+RECORD_DTYPE = np.dtype([
+    ("block_idx", "<i8"), ("flags", "<u4"), ("template_id", "<i4"),
+    ("carrier_bin", "<i4"), ("corr_sample", "<i4"),
+    ("carrier_offset", "<f8"), ("corr_offset", "<f8"),
+    ("carrier_energy", "<f4"), ("carrier_noise", "<f4"),
+    ("corr_energy", "<f4"), ("corr_noise", "<f4"), ("reserved", "<u8"),
+])
+assert RECORD_DTYPE.itemsize == 64
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def _share_hip_runtime_with_torch():
+    """A process can hold only ONE HIP runtime.  PyTorch-ROCm wheels bundle their
+    own libamdhip64 (SONAME libamdhip64.so.7, same as /opt/rocm's); if both copies
+    get loaded, whichever initialises second sees "No HIP GPUs".  bench.py and the
+    multi-GPU gather need torch in the same process, so when a torch wheel with a
+    bundled runtime is installed we load *that* copy first (RTLD_GLOBAL); our
+    DT_NEEDED libamdhip64.so.7 then resolves to it by SONAME.  Without torch the
+    system ROCm runtime is used.  THRIFTY_HIP_RUNTIME=system skips this."""
+    if os.environ.get("THRIFTY_HIP_RUNTIME", "") == "system":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
+def load_library():
+    """dlopen the engine; raises NativeError (never falls back) if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(
+            "%s not found: build it with `python -m thrifty_amd.build` (needs hipcc). "
+            "thrifty_amd has no CPU fallback." % LIB_PATH)
+    _share_hip_runtime_with_torch()
+    lib = C.CDLL(LIB_PATH)
+    vp, i64p = C.c_void_p, C.POINTER(C.c_int64)
+    lib.thr_abi_version.restype = C.c_int
+    lib.thr_last_error.restype = C.c_char_p
+    lib.thr_kernel_name.restype = C.c_char_p
+    lib.thr_kernel_name.argtypes = [C.c_int]
+    lib.thr_create.argtypes = [C.POINTER(ThrSettings), C.POINTER(vp)]
+    lib.thr_destroy.argtypes = [vp]
+    lib.thr_destroy.restype = None
+    lib.thr_detect.argtypes = [vp, vp, C.c_int, vp, C.c_size_t, vp]
+    lib.thr_detect_device.argtypes = [vp, vp, C.c_int, vp, C.c_size_t, vp]
+    lib.thr_sync.argtypes = [vp]
+    lib.thr_set_stream.argtypes = [vp, vp]
+    lib.thr_compact_device.argtypes = [vp, vp, C.c_size_t, vp, C.POINTER(C.c_size_t)]
+    lib.thr_profile_enable.argtypes = [vp, C.c_int]
+    lib.thr_profile_read.argtypes = [vp, C.POINTER(C.c_double), i64p]
+    lib.thr_debug_fft.argtypes = [vp, vp, C.c_int, C.c_size_t, vp]
+    lib.thr_debug_stage.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_int, vp, vp]
+    _lib = lib
+    return lib
+
+
+def _check(lib, rc):
+    if rc != 0:
+        raise NativeError("libthriftyhip: %s (code %d)" % (lib.thr_last_error().decode(), rc))
+
+
+class Engine(object):
+    """One detector handle == one (device, stream).  Not thread-safe per handle."""
+
+    def __init__(self, block_len, history_len, templates, carrier_thresh, carrier_window,
+                 corr_thresh, carrier_len=0, device_id=0, max_batch=256):
+        lib = load_library()
+        tpl = np.ascontiguousarray(np.atleast_2d(np.asarray(templates, dtype=np.float64)))
+        if tpl.ndim != 2:
+            raise ValueError("templates must be 1-D or [n_templates, template_len]")
+        st = ThrSettings()
+        st.block_len, st.history_len = int(block_len), int(history_len)
+        st.n_templates, st.template_len = tpl.shape
+        st.templates = tpl.ctypes.data_as(C.POINTER(C.c_double))
+        st.carrier_len = int(carrier_len)
+        window = (0, -1) if carrier_window is None else carrier_window
+        st.carrier_window[0], st.carrier_window[1] = int(window[0]), int(window[1])
+        for i in range(3):
+            st.carrier_thresh[i] = float(carrier_thresh[i])
+            st.corr_thresh[i] = float(corr_thresh[i])
+        st.device_id, st.max_batch = int(device_id), int(max_batch)
+        handle = C.c_void_p()
+        _check(lib, lib.thr_create(C.byref(st), C.byref(handle)))
+        self._lib, self._h = lib, handle
+        self.block_len, self.n_templates = int(block_len), int(tpl.shape[0])
+        self.max_batch = int(max_batch)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.thr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host-buffer path -------------------------------------------------
+    def _as_input(self, blocks):
+        a = np.asarray(blocks)
+        if a.dtype == np.uint8:
+            a = np.ascontiguousarray(a).reshape(-1, 2 * self.block_len)
+            return a, THR_IN_U8
+        a = np.ascontiguousarray(a.astype(np.complex64, copy=False)).reshape(-1, self.block_len)
+        return a, THR_IN_C64
+
+    def detect(self, blocks, block_idx=None):
+        """blocks: u8 [B, 2N] or complex64 [B, N] -> structured records [B, n_templates]."""
+        a, fmt = self._as_input(blocks)
+        nb = a.shape[0]
+        out = np.zeros((nb, self.n_templates), dtype=RECORD_DTYPE)
+        idx_p = None
+        if block_idx is not None:
+            idx = np.ascontiguousarray(np.asarray(block_idx, dtype=np.int64))
+            assert idx.shape == (nb,)
+            idx_p = idx.ctypes.data
+        _check(self._lib, self._lib.thr_detect(self._h, a.ctypes.data, fmt, idx_p, nb,
+                                               out.ctypes.data))
+        return out
+
+    # ---- device-resident path (pointers are plain integers) ---------------
+    def detect_device(self, d_samples, fmt, n_blocks, d_out, d_block_idx=None):
+        _check(self._lib, self._lib.thr_detect_device(self._h, d_samples, fmt, d_block_idx,
+                                                      n_blocks, d_out))
+
+    def compact_device(self, d_in, n_records, d_out):
+        kept = C.c_size_t(0)
+        _check(self._lib, self._lib.thr_compact_device(self._h, d_in, n_records, d_out,
+                                                       C.byref(kept)))
+        return kept.value
+
+    def sync(self):
+        _check(self._lib, self._lib.thr_sync(self._h))
+
+    def set_stream(self, stream_ptr):
+        _check(self._lib, self._lib.thr_set_stream(self._h, stream_ptr))
+
+    def profile_enable(self, on=True):
+        _check(self._lib, self._lib.thr_profile_enable(self._h, int(bool(on))))
+
+    def profile_read(self):
+        ms = (C.c_double * N_KERNEL_SLOTS)()
+        cnt = (C.c_int64 * N_KERNEL_SLOTS)()
+        _check(self._lib, self._lib.thr_profile_read(self._h, ms, cnt))
+        return {self._lib.thr_kernel_name(i).decode(): (ms[i], cnt[i])
+                for i in range(N_KERNEL_SLOTS)}
+
+    # ---- test hooks ------------------------------------------------------
+    def debug_fft(self, blocks):
+        a, fmt = self._as_input(blocks)
+        out = np.zeros((a.shape[0], self.block_len), dtype=np.complex64)
+        _check(self._lib, self._lib.thr_debug_fft(self._h, a.ctypes.data, fmt, a.shape[0],
+                                                  out.ctypes.data))
+        return out
+
+    def debug_stage(self, blocks, template_id=0):
+        a, fmt = self._as_input(blocks)
+        xhat = np.zeros((a.shape[0], self.block_len), dtype=np.complex64)
+        corr = np.zeros((a.shape[0], self.block_len), dtype=np.complex64)
+        _check(self._lib, self._lib.thr_debug_stage(self._h, a.ctypes.data, fmt, a.shape[0],
+                                                    template_id, xhat.ctypes.data,
+                                                    corr.ctypes.data))
+        return xhat, corr

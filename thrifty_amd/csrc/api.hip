@@ -1,0 +1,547 @@
+// C ABI of the detection engine (see include/thrifty_hip.h).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <complex>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "detect_common.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                  \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess)                                                          \
+            return fail(THR_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr,                \
+                        hipGetErrorString(_e), __FILE__, __LINE__);                    \
+    } while (0)
+
+// Plain iterative radix-2 FFT in double, host side, setup only (template
+// spectrum; the reference does this once in float64 too, soa_estimator.py:68-72).
+void host_fft(std::vector<std::complex<double>>& a) {
+    const size_t n = a.size();
+    for (size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(a[i], a[j]);
+    }
+    const double pi = 3.14159265358979323846;
+    for (size_t len = 2; len <= n; len <<= 1) {
+        // exact-ish twiddles: evaluate each directly (no recurrence drift)
+        std::vector<std::complex<double>> w(len / 2);
+        for (size_t k = 0; k < len / 2; ++k)
+            w[k] = std::complex<double>(std::cos(2 * pi * double(k) / double(len)),
+                                        -std::sin(2 * pi * double(k) / double(len)));
+        for (size_t i = 0; i < n; i += len)
+            for (size_t k = 0; k < len / 2; ++k) {
+                const std::complex<double> u = a[i + k], v = a[i + k + len / 2] * w[k];
+                a[i + k] = u + v;
+                a[i + k + len / 2] = u - v;
+            }
+    }
+}
+
+float2 unit_root(long long num, long long den) {  // exp(-2 pi i num/den), exact reduction
+    const double pi = 3.14159265358979323846;
+    num %= den;
+    if (num < 0) num += den;
+    const double a = 2 * pi * double(num) / double(den);
+    return float2{float(std::cos(a)), float(-std::sin(a))};
+}
+
+struct EventPair {
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct thr_handle {
+    thr_settings cfg{};
+    thr::DevCfg dev{};
+    int device = 0;
+    int n_cu = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    // constants
+    float2* d_tables = nullptr;
+    float2* d_twn = nullptr;
+    float4* d_tspec = nullptr;
+    // per-batch work buffers
+    thr::CarStats* d_stats = nullptr;
+    thr::ShiftParams* d_shifts = nullptr;
+    int* d_work_list = nullptr;
+    int* d_work_count = nullptr;
+    float4* d_xhat_scratch = nullptr;
+    int* d_ncompact = nullptr;
+    // host-path staging (lazy)
+    void* d_in = nullptr;
+    size_t d_in_bytes = 0;
+    long long* d_idx = nullptr;
+    thr_record* d_rec = nullptr;
+    // profiling
+    bool prof = false;
+    std::vector<EventPair> pending[THR_N_KERNEL_SLOTS];
+    double ms[THR_N_KERNEL_SLOTS] = {0, 0, 0};
+    int64_t launches[THR_N_KERNEL_SLOTS] = {0, 0, 0};
+};
+
+namespace {
+
+struct ProfScope {
+    thr_handle* h;
+    int slot;
+    EventPair ev{};
+    bool on;
+    ProfScope(thr_handle* h_, int slot_) : h(h_), slot(slot_), on(h_->prof) {
+        if (on) {
+            hipEventCreate(&ev.a);
+            hipEventCreate(&ev.b);
+            hipEventRecord(ev.a, h->stream);
+        }
+    }
+    ~ProfScope() {
+        if (on) {
+            hipEventRecord(ev.b, h->stream);
+            h->pending[slot].push_back(ev);
+        }
+    }
+};
+
+int window_indices(int start, int stop, int n, int* lo, int* count) {
+    // carrier_detect.py:17-58
+    if (std::abs(start) >= n || std::abs(stop) >= n)
+        return fail(THR_ERR_ARG, "Frequency window out of range: %d - %d", start, stop);
+    if (start < 0 && stop >= 0) {
+        start += n;
+        stop += n;
+    }
+    if (start < 0) start += n;
+    if (stop < 0) stop += n;
+    if (stop < start) std::swap(start, stop);
+    *lo = start;
+    *count = std::min(stop - start + 1, n);
+    return THR_OK;
+}
+
+int build_constants(thr_handle* h) {
+    const int n = h->cfg.block_len;
+    // --- LDS twiddle tables (forward sign): C[32][32], A[16][32], Bt[16][32]
+    std::vector<float2> tab(2048);
+    for (int a = 0; a < 32; ++a)
+        for (int b = 0; b < 32; ++b) tab[a * 32 + b] = unit_root((long long)a * b, 1024);
+    for (int k1 = 0; k1 < 16; ++k1)
+        for (int n2 = 0; n2 < 32; ++n2) tab[1024 + k1 * 32 + n2] = unit_root((long long)k1 * n2, 512);
+    for (int k1 = 0; k1 < 16; ++k1)
+        for (int mp = 0; mp < 32; ++mp) tab[1536 + k1 * 32 + mp] = unit_root((long long)k1 * mp, n);
+    HIP_TRY(hipMalloc(&h->d_tables, tab.size() * sizeof(float2)));
+    HIP_TRY(hipMemcpy(h->d_tables, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice));
+    // --- full-length root table for the shift phasor
+    std::vector<float2> tw(n);
+    for (int j = 0; j < n; ++j) tw[j] = unit_root(j, n);
+    HIP_TRY(hipMalloc(&h->d_twn, tw.size() * sizeof(float2)));
+    HIP_TRY(hipMemcpy(h->d_twn, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
+    // --- template spectra: conj(FFT(zero-padded template)) / N, in the
+    //     digit-reversed, lane-coalesced order k_correlate consumes
+    const int w = h->cfg.template_len, nt = h->cfg.n_templates;
+    std::vector<float2> spec(size_t(nt) * n);
+    for (int t = 0; t < nt; ++t) {
+        std::vector<std::complex<double>> buf(n, 0.0);
+        double energy = 0;
+        for (int i = 0; i < w; ++i) {
+            const double v = h->cfg.templates[size_t(t) * w + i];
+            buf[i] = v;
+            energy += v * v;
+        }
+        h->dev.tmpl_energy[t] = float(energy);
+        host_fft(buf);
+        float2* out = spec.data() + size_t(t) * n;
+        for (int tid = 0; tid < 512; ++tid)
+            for (int k3 = 0; k3 < 32; ++k3) {
+                const int k = (tid >> 5) + 16 * (tid & 31) + 512 * k3;
+                const std::complex<double> c = std::conj(buf[k]) / double(n);
+                out[((k3 >> 1) * 512 + tid) * 2 + (k3 & 1)] = float2{float(c.real()), float(c.imag())};
+            }
+    }
+    HIP_TRY(hipMalloc(&h->d_tspec, spec.size() * sizeof(float2)));
+    HIP_TRY(hipMemcpy(h->d_tspec, spec.data(), spec.size() * sizeof(float2), hipMemcpyHostToDevice));
+    return THR_OK;
+}
+
+int ensure_staging(thr_handle* h, int format) {
+    const size_t need = size_t(h->cfg.max_batch) * h->cfg.block_len * (format == THR_IN_U8 ? 2 : 8);
+    if (h->d_in_bytes < need) {
+        if (h->d_in) hipFree(h->d_in);
+        h->d_in = nullptr;
+        h->d_in_bytes = 0;
+        HIP_TRY(hipMalloc(&h->d_in, need));
+        h->d_in_bytes = need;
+    }
+    if (!h->d_idx) HIP_TRY(hipMalloc(&h->d_idx, size_t(h->cfg.max_batch) * sizeof(long long)));
+    if (!h->d_rec)
+        HIP_TRY(hipMalloc(&h->d_rec,
+                          size_t(h->cfg.max_batch) * h->cfg.n_templates * sizeof(thr_record)));
+    return THR_OK;
+}
+
+int run_batch(thr_handle* h, const void* d_samples, int format, const long long* d_block_idx,
+              int n_blocks, thr_record* d_out, float2* dump_fft, float2* dump_xhat,
+              float2* dump_corr, int dump_template, bool carrier_only) {
+    const int grid = std::min(n_blocks, h->n_cu);
+    HIP_TRY(hipMemsetAsync(h->d_work_count, 0, sizeof(int), h->stream));
+    {
+        ProfScope p(h, 0);
+        HIP_TRY(thr::launch_carrier_16k(format, d_samples, n_blocks, h->dev, h->d_tables, h->d_stats,
+                                        dump_fft, grid, h->stream));
+    }
+    if (carrier_only) return THR_OK;
+    {
+        ProfScope p(h, 1);
+        HIP_TRY(thr::launch_fit(n_blocks, h->dev, h->d_stats, d_block_idx, h->d_shifts,
+                                h->d_work_list, h->d_work_count, d_out, h->stream));
+    }
+    {
+        ProfScope p(h, 2);
+        HIP_TRY(thr::launch_correlate_16k(format, d_samples, h->dev, h->d_tables, h->d_twn,
+                                          h->d_tspec, h->d_shifts, h->d_work_list, h->d_work_count,
+                                          d_out, h->d_xhat_scratch, dump_xhat, dump_corr,
+                                          dump_template, grid, h->stream));
+    }
+    return THR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int thr_abi_version(void) { return THR_ABI_VERSION; }
+
+const char* thr_last_error(void) { return g_last_error.c_str(); }
+
+const char* thr_kernel_name(int slot) {
+    static const char* names[THR_N_KERNEL_SLOTS] = {"k_carrier", "k_fit", "k_correlate"};
+    return (slot >= 0 && slot < THR_N_KERNEL_SLOTS) ? names[slot] : "";
+}
+
+int thr_create(const thr_settings* s, thr_handle** out) {
+    if (!s || !out) return fail(THR_ERR_ARG, "thr_create: null argument");
+    *out = nullptr;
+    const int n = s->block_len;
+    if (n <= 0 || (n & (n - 1))) return fail(THR_ERR_ARG, "block_len %d is not a power of two", n);
+    if (n != 16384)
+        return fail(THR_ERR_ARG,
+                    "block_len %d not supported by this build (LDS-resident path: 16384 only)", n);
+    if (s->n_templates < 1 || s->n_templates > thr::kMaxTemplates)
+        return fail(THR_ERR_ARG, "n_templates %d out of range [1, %d]", s->n_templates,
+                    thr::kMaxTemplates);
+    if (!s->templates || s->template_len < 1 || s->template_len > n)
+        return fail(THR_ERR_ARG, "bad template (len %d)", s->template_len);
+    if (s->history_len < s->template_len - 1 || s->history_len >= n)
+        return fail(THR_ERR_ARG, "history_len %d must satisfy template_len-1 <= history_len < block_len",
+                    s->history_len);  // soa_estimator.py:32 asserts the lower bound
+    if (s->max_batch < 1) return fail(THR_ERR_ARG, "max_batch must be >= 1");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(THR_ERR_DEVICE, "no HIP device available (this engine has no CPU fallback)");
+    if (s->device_id < 0 || s->device_id >= ndev)
+        return fail(THR_ERR_ARG, "device_id %d out of range (%d devices)", s->device_id, ndev);
+
+    thr_handle* h = new thr_handle();
+    h->cfg = *s;
+    h->cfg.templates = nullptr;  // not retained beyond this call (re-pointed below)
+    h->device = s->device_id;
+    int rc = THR_OK;
+    do {
+        if (hipSetDevice(h->device) != hipSuccess) {
+            rc = fail(THR_ERR_DEVICE, "hipSetDevice(%d) failed", h->device);
+            break;
+        }
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, h->device) != hipSuccess) {
+            rc = fail(THR_ERR_DEVICE, "hipGetDeviceProperties failed");
+            break;
+        }
+        h->n_cu = prop.multiProcessorCount;
+        if (size_t(prop.maxSharedMemoryPerMultiProcessor) < thr::lds_bytes_16k()) {
+            rc = fail(THR_ERR_DEVICE, "device has %zu B LDS per CU, need %zu",
+                      size_t(prop.maxSharedMemoryPerMultiProcessor), thr::lds_bytes_16k());
+            break;
+        }
+        thr::DevCfg& d = h->dev;
+        d.block_len = n;
+        d.history_len = s->history_len;
+        d.n_templates = s->n_templates;
+        d.carrier_len = s->carrier_len > 0 ? s->carrier_len : s->template_len;
+        if ((rc = window_indices(s->carrier_window[0], s->carrier_window[1], n, &d.win_lo,
+                                 &d.win_count)) != THR_OK)
+            break;
+        // soa_estimator.py:20-39
+        const int corr_len = n - s->template_len + 1;
+        const int pad = s->history_len - s->template_len + 1;
+        d.corr_lo = pad / 2;
+        d.corr_hi = corr_len - (pad - pad / 2);
+        d.corr_len = corr_len;
+        if (d.corr_hi <= d.corr_lo) {
+            rc = fail(THR_ERR_ARG, "empty correlation window [%d, %d)", d.corr_lo, d.corr_hi);
+            break;
+        }
+        for (int i = 0; i < 3; ++i) {
+            d.car_thr[i] = float(s->carrier_thresh[i]);
+            d.cor_thr[i] = float(s->corr_thresh[i]);
+        }
+        d.car_want_std = s->carrier_thresh[2] != 0.0;
+        d.cor_want_std = s->corr_thresh[2] != 0.0;
+
+        h->cfg.templates = s->templates;
+        rc = build_constants(h);
+        h->cfg.templates = nullptr;
+        if (rc != THR_OK) break;
+
+#define CREATE_TRY(expr)                                                              \
+    if ((expr) != hipSuccess) {                                                       \
+        rc = fail(THR_ERR_DEVICE, "%s failed (%s)", #expr, hipGetErrorString(hipGetLastError())); \
+        break;                                                                        \
+    }
+        CREATE_TRY(thr::prepare_16k());
+        CREATE_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+        h->stream = h->own_stream;
+        const size_t mb = size_t(s->max_batch);
+        CREATE_TRY(hipMalloc(&h->d_stats, mb * sizeof(thr::CarStats)));
+        CREATE_TRY(hipMalloc(&h->d_shifts, mb * sizeof(thr::ShiftParams)));
+        CREATE_TRY(hipMalloc(&h->d_work_list, mb * sizeof(int)));
+        CREATE_TRY(hipMalloc(&h->d_work_count, sizeof(int)));
+        CREATE_TRY(hipMalloc(&h->d_ncompact, sizeof(int)));
+        if (s->n_templates > 1)
+            CREATE_TRY(hipMalloc(&h->d_xhat_scratch, size_t(h->n_cu) * n * sizeof(float2)));
+#undef CREATE_TRY
+    } while (0);
+    if (rc != THR_OK) {
+        thr_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return THR_OK;
+}
+
+void thr_destroy(thr_handle* h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    if (h->own_stream) hipStreamSynchronize(h->own_stream);
+    for (auto& v : h->pending)
+        for (auto& e : v) {
+            hipEventDestroy(e.a);
+            hipEventDestroy(e.b);
+        }
+    void* bufs[] = {h->d_tables, h->d_twn, h->d_tspec, h->d_stats, h->d_shifts, h->d_work_list,
+                    h->d_work_count, h->d_xhat_scratch, h->d_ncompact, h->d_in, h->d_idx, h->d_rec};
+    for (void* b : bufs)
+        if (b) hipFree(b);
+    if (h->own_stream) hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+int thr_set_stream(thr_handle* h, void* hip_stream) {
+    if (!h) return fail(THR_ERR_ARG, "null handle");
+    h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+    return THR_OK;
+}
+
+int thr_sync(thr_handle* h) {
+    if (!h) return fail(THR_ERR_ARG, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return THR_OK;
+}
+
+int thr_detect_device(thr_handle* h, const void* d_samples, int format,
+                      const int64_t* d_block_idx, size_t n_blocks, thr_record* d_out) {
+    if (!h || !d_samples || !d_out) return fail(THR_ERR_ARG, "thr_detect_device: null argument");
+    if (format != THR_IN_U8 && format != THR_IN_C64) return fail(THR_ERR_ARG, "bad format %d", format);
+    if (n_blocks == 0) return THR_OK;
+    if (n_blocks > size_t(h->cfg.max_batch))
+        return fail(THR_ERR_ARG, "n_blocks %zu exceeds max_batch %d", n_blocks, h->cfg.max_batch);
+    HIP_TRY(hipSetDevice(h->device));
+    return run_batch(h, d_samples, format, reinterpret_cast<const long long*>(d_block_idx),
+                     int(n_blocks), d_out, nullptr, nullptr, nullptr, 0, false);
+}
+
+int thr_detect(thr_handle* h, const void* samples, int format, const int64_t* block_idx,
+               size_t n_blocks, thr_record* out) {
+    if (!h || !samples || !out) return fail(THR_ERR_ARG, "thr_detect: null argument");
+    if (format != THR_IN_U8 && format != THR_IN_C64) return fail(THR_ERR_ARG, "bad format %d", format);
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = ensure_staging(h, format);
+    if (rc != THR_OK) return rc;
+    const size_t blk_bytes = size_t(h->cfg.block_len) * (format == THR_IN_U8 ? 2 : 8);
+    const size_t nt = size_t(h->cfg.n_templates);
+    for (size_t done = 0; done < n_blocks;) {
+        const size_t nb = std::min(n_blocks - done, size_t(h->cfg.max_batch));
+        HIP_TRY(hipMemcpyAsync(h->d_in, static_cast<const unsigned char*>(samples) + done * blk_bytes,
+                               nb * blk_bytes, hipMemcpyHostToDevice, h->stream));
+        if (block_idx) {
+            HIP_TRY(hipMemcpyAsync(h->d_idx, block_idx + done, nb * sizeof(long long),
+                                   hipMemcpyHostToDevice, h->stream));
+        } else {
+            std::vector<long long> idx(nb);
+            for (size_t i = 0; i < nb; ++i) idx[i] = (long long)(done + i);
+            HIP_TRY(hipMemcpyAsync(h->d_idx, idx.data(), nb * sizeof(long long), hipMemcpyHostToDevice,
+                                   h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));  // idx goes out of scope
+        }
+        rc = run_batch(h, h->d_in, format, h->d_idx, int(nb), h->d_rec, nullptr, nullptr, nullptr, 0,
+                       false);
+        if (rc != THR_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(out + done * nt, h->d_rec, nb * nt * sizeof(thr_record),
+                               hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        done += nb;
+    }
+    return THR_OK;
+}
+
+int thr_compact_device(thr_handle* h, const thr_record* d_in, size_t n_records, thr_record* d_out,
+                       size_t* n_kept) {
+    if (!h || !d_in || !d_out || !n_kept) return fail(THR_ERR_ARG, "thr_compact_device: null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    if (n_records > size_t(1) << 30) return fail(THR_ERR_ARG, "too many records");
+    HIP_TRY(thr::launch_compact(d_in, int(n_records), d_out, h->d_ncompact, h->stream));
+    int n = 0;
+    HIP_TRY(hipMemcpyAsync(&n, h->d_ncompact, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    *n_kept = size_t(n);
+    return THR_OK;
+}
+
+int thr_profile_enable(thr_handle* h, int on) {
+    if (!h) return fail(THR_ERR_ARG, "null handle");
+    h->prof = on != 0;
+    return THR_OK;
+}
+
+int thr_profile_read(thr_handle* h, double ms[THR_N_KERNEL_SLOTS],
+                     int64_t launches[THR_N_KERNEL_SLOTS]) {
+    if (!h || !ms || !launches) return fail(THR_ERR_ARG, "thr_profile_read: null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int s = 0; s < THR_N_KERNEL_SLOTS; ++s) {
+        for (auto& e : h->pending[s]) {
+            float t = 0;
+            if (hipEventElapsedTime(&t, e.a, e.b) == hipSuccess) {
+                h->ms[s] += t;
+                h->launches[s] += 1;
+            }
+            hipEventDestroy(e.a);
+            hipEventDestroy(e.b);
+        }
+        h->pending[s].clear();
+        ms[s] = h->ms[s];
+        launches[s] = h->launches[s];
+        h->ms[s] = 0;
+        h->launches[s] = 0;
+    }
+    return THR_OK;
+}
+
+int thr_debug_fft(thr_handle* h, const void* samples, int format, size_t n_blocks,
+                  float* spectra_out) {
+    if (!h || !samples || !spectra_out) return fail(THR_ERR_ARG, "thr_debug_fft: null argument");
+    if (format != THR_IN_U8 && format != THR_IN_C64) return fail(THR_ERR_ARG, "bad format %d", format);
+    if (n_blocks > size_t(h->cfg.max_batch)) return fail(THR_ERR_ARG, "n_blocks exceeds max_batch");
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = ensure_staging(h, format);
+    if (rc != THR_OK) return rc;
+    const size_t n = size_t(h->cfg.block_len);
+    const size_t blk_bytes = n * (format == THR_IN_U8 ? 2 : 8);
+    float2* d_dump = nullptr;
+    HIP_TRY(hipMalloc(&d_dump, n_blocks * n * sizeof(float2)));
+    rc = THR_OK;
+    do {
+        if (hipMemcpyAsync(h->d_in, samples, n_blocks * blk_bytes, hipMemcpyHostToDevice, h->stream) !=
+            hipSuccess) {
+            rc = fail(THR_ERR_DEVICE, "H2D copy failed");
+            break;
+        }
+        rc = run_batch(h, h->d_in, format, nullptr, int(n_blocks), h->d_rec, d_dump, nullptr, nullptr,
+                       0, true);
+        if (rc != THR_OK) break;
+        if (hipMemcpyAsync(spectra_out, d_dump, n_blocks * n * sizeof(float2), hipMemcpyDeviceToHost,
+                           h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) {
+            rc = fail(THR_ERR_DEVICE, "D2H copy failed: %s", hipGetErrorString(hipGetLastError()));
+            break;
+        }
+    } while (0);
+    hipFree(d_dump);
+    return rc;
+}
+
+int thr_debug_stage(thr_handle* h, const void* samples, int format, size_t n_blocks,
+                    int template_id, float* shifted_fft_out, float* corr_out) {
+    if (!h || !samples) return fail(THR_ERR_ARG, "thr_debug_stage: null argument");
+    if (format != THR_IN_U8 && format != THR_IN_C64) return fail(THR_ERR_ARG, "bad format %d", format);
+    if (n_blocks > size_t(h->cfg.max_batch)) return fail(THR_ERR_ARG, "n_blocks exceeds max_batch");
+    if (template_id < 0 || template_id >= h->cfg.n_templates) return fail(THR_ERR_ARG, "bad template_id");
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = ensure_staging(h, format);
+    if (rc != THR_OK) return rc;
+    const size_t n = size_t(h->cfg.block_len);
+    const size_t blk_bytes = n * (format == THR_IN_U8 ? 2 : 8);
+    const size_t dump_bytes = n_blocks * n * sizeof(float2);
+    float2 *d_x = nullptr, *d_c = nullptr;
+    HIP_TRY(hipMalloc(&d_x, dump_bytes));
+    if (hipMalloc(&d_c, dump_bytes) != hipSuccess) {
+        hipFree(d_x);
+        return fail(THR_ERR_DEVICE, "hipMalloc failed");
+    }
+    rc = THR_OK;
+    do {
+        if (hipMemsetAsync(d_x, 0, dump_bytes, h->stream) != hipSuccess ||
+            hipMemsetAsync(d_c, 0, dump_bytes, h->stream) != hipSuccess ||
+            hipMemcpyAsync(h->d_in, samples, n_blocks * blk_bytes, hipMemcpyHostToDevice, h->stream) !=
+                hipSuccess) {
+            rc = fail(THR_ERR_DEVICE, "staging failed");
+            break;
+        }
+        rc = run_batch(h, h->d_in, format, nullptr, int(n_blocks), h->d_rec, nullptr, d_x, d_c,
+                       template_id, false);
+        if (rc != THR_OK) break;
+        if (shifted_fft_out &&
+            hipMemcpyAsync(shifted_fft_out, d_x, dump_bytes, hipMemcpyDeviceToHost, h->stream) != hipSuccess) {
+            rc = fail(THR_ERR_DEVICE, "D2H copy failed");
+            break;
+        }
+        if (corr_out &&
+            hipMemcpyAsync(corr_out, d_c, dump_bytes, hipMemcpyDeviceToHost, h->stream) != hipSuccess) {
+            rc = fail(THR_ERR_DEVICE, "D2H copy failed");
+            break;
+        }
+        if (hipStreamSynchronize(h->stream) != hipSuccess) {
+            rc = fail(THR_ERR_DEVICE, "sync failed: %s", hipGetErrorString(hipGetLastError()));
+            break;
+        }
+    } while (0);
+    hipFree(d_x);
+    hipFree(d_c);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,818 @@
+// LDS-resident fused detection kernels for block_len = 16384 on gfx950.
+//
+// One 512-thread workgroup owns one IQ block at a time; the block's 16384
+// complex samples live in LDS (136 KiB padded) between the three register
+// passes of a 16 x 32 x 32 decimation-in-frequency FFT.  The spectrum leaves
+// the last pass in digit-reversed order *in registers*, which is exactly the
+// order the mirrored decimation-in-time inverse consumes, so the template
+// product and the first inverse pass need no LDS round trip and no reordering.
+//
+//   k_carrier   : u8/c64 -> FFT#1 -> |X|^2 sum, windowed first-max, 7-bin
+//                 neighbourhood                (signal_utils.py:21-25,
+//                 carrier_detect.py:99-154)
+//   k_fit       : noise/threshold verdict + Dirichlet LSQ fit + shift phasors
+//                 (carrier_detect.py:61-115, carrier_sync.py:150-196)
+//   k_correlate : shift -> FFT#2 -> x conj(T) -> IFFT -> |.|^2 windowed
+//                 argmax -> noise/threshold -> log-parabola -> record
+//                 (carrier_sync.py:222-238, soa_estimator.py:78-170)
+#include <hip/hip_runtime.h>
+
+#include "detect_common.hpp"
+#include "fft_regs.hpp"
+
+namespace thr {
+
+namespace k16 {
+constexpr int N = 16384;
+constexpr int R1 = 16, R2 = 32, R3 = 32;
+constexpr int S1 = R2 * R3;       // 1024
+constexpr int CHUNK = 34;         // 32 complex + 2 pad (16 B) -> conflict-free strided b128
+constexpr int ROW = R2 * CHUNK;   // 1088
+constexpr int NT = 512;           // threads per workgroup
+constexpr int DATA = R1 * ROW;    // 17408 complex
+// LDS carve (complex units)
+constexpr int OFF_C = DATA;             // C[32][32]  = W_1024^(a*b)
+constexpr int OFF_A = OFF_C + 1024;     // A[16][32]  = W_512^(n2*k1)   [k1][n2]
+constexpr int OFF_B = OFF_A + 512;      // Bt[16][32] = W_N^(m'*k1)     [k1][m']
+constexpr int OFF_S = OFF_B + 512;      // 128 complex (1 KiB) reduction scratch
+constexpr int LDS_CPX = OFF_S + 128;
+constexpr size_t LDS_BYTES = size_t(LDS_CPX) * sizeof(cpx);  // 156,672 B
+}  // namespace k16
+
+using namespace k16;
+
+// Thread id the optimiser cannot see through: stops LICM from hoisting every
+// per-thread LDS address / window predicate out of the persistent block loop
+// (that cost ~220 SGPR + ~70 VGPR spills).
+__device__ __forceinline__ int opaque_tid() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
+// ---------------------------------------------------------------- reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_max(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned lo = __shfl_xor((unsigned)v, o, 64);
+        unsigned hi = __shfl_xor((unsigned)(v >> 32), o, 64);
+        unsigned long long w = ((unsigned long long)hi << 32) | lo;
+        v = w > v ? w : v;
+    }
+    return v;
+}
+
+// scratch must hold >= 8 doubles; all 512 threads call; result valid in all threads
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[wv] = v;
+    __syncthreads();
+    double t = 0;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) t += scratch[i];
+    return t;
+}
+__device__ __forceinline__ unsigned long long block_max(unsigned long long v,
+                                                         unsigned long long* scratch) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[wv] = v;
+    __syncthreads();
+    unsigned long long t = 0;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) t = scratch[i] > t ? scratch[i] : t;
+    return t;
+}
+
+// ---------------------------------------------------------------- LDS tables
+__device__ __forceinline__ void load_tables(cpx* lds, const cpx* __restrict__ tables) {
+    // 2048 complex = 16 KiB: 512 threads x 2 x float4
+    const float4* src = reinterpret_cast<const float4*>(tables);
+    float4* dst = reinterpret_cast<float4*>(lds + OFF_C);
+    dst[threadIdx.x] = src[threadIdx.x];
+    dst[threadIdx.x + NT] = src[threadIdx.x + NT];
+}
+
+// ---------------------------------------------------------------- sample load
+// Two adjacent samples m = 2t, 2t+1 of sub-sequence n1 (n = n1*1024 + m).
+template <int FMT>
+__device__ __forceinline__ void load_pair(const void* __restrict__ blk, int n1, int t, cpx& a,
+                                          cpx& b) {
+    if constexpr (FMT == THR_IN_U8) {
+        const uchar4 q = reinterpret_cast<const uchar4*>(blk)[n1 * (S1 / 2) + t];
+        constexpr float sc = 1.0f / 128.0f, of = -127.4f / 128.0f;  // == (v - 127.4f) / 128 exactly
+        a = cpx{fmaf((float)q.x, sc, of), fmaf((float)q.y, sc, of)};
+        b = cpx{fmaf((float)q.z, sc, of), fmaf((float)q.w, sc, of)};
+    } else {
+        const float4 q = reinterpret_cast<const float4*>(blk)[n1 * (S1 / 2) + t];
+        a = cpx{q.x, q.y};
+        b = cpx{q.z, q.w};
+    }
+}
+
+// ------------------------------------------------------------ forward passes
+// Pass 1 (radix 16 over n1, two adjacent m per thread) -> LDS.
+// If PH: pre-rotate x[n1] by rpow[n1] and fold the per-m phasor p0/p1 into the twiddle.
+template <int FMT, bool PH>
+__device__ __forceinline__ void fwd_pass1(cpx* lds, const void* __restrict__ blk,
+                                          const cpx* __restrict__ rpow, cpx p0, cpx p1) {
+    const int t = opaque_tid();
+    cpx v0[R1], v1[R1];
+#pragma unroll
+    for (int n1 = 0; n1 < R1; ++n1) {
+        load_pair<FMT>(blk, n1, t, v0[n1], v1[n1]);
+        if constexpr (PH) {
+            const cpx r = rpow[n1];
+            v0[n1] = cmul(v0[n1], r);
+            v1[n1] = cmul(v1[n1], r);
+        }
+    }
+    dft_dif<R1, -1>(v0);
+    dft_dif<R1, -1>(v1);
+    const int n2 = t >> 4, mp = 2 * (t & 15);
+    const cpx* tA = lds + OFF_A;
+    const cpx* tB = lds + OFF_B;
+    float4* out = reinterpret_cast<float4*>(lds + n2 * CHUNK + mp);
+    static_for<R1>([&](auto K) {
+        constexpr int k1 = decltype(K)::value;
+        constexpr int src = brev(k1, R1);
+        cpx y0 = v0[src], y1 = v1[src];
+        if constexpr (k1 == 0) {
+            if constexpr (PH) {
+                y0 = cmul(y0, p0);
+                y1 = cmul(y1, p1);
+            }
+        } else {
+            const cpx a = tA[k1 * 32 + n2];
+            const float4 bb = *reinterpret_cast<const float4*>(tB + k1 * 32 + mp);
+            cpx w0 = cmul(a, cpx{bb.x, bb.y});
+            cpx w1 = cmul(a, cpx{bb.z, bb.w});
+            if constexpr (PH) {
+                w0 = cmul(w0, p0);
+                w1 = cmul(w1, p1);
+            }
+            y0 = cmul(y0, w0);
+            y1 = cmul(y1, w1);
+        }
+        out[k1 * (ROW / 2)] = float4{y0.x, y0.y, y1.x, y1.y};
+    });
+}
+
+// Pass 2 (radix 32 over n2, in place) -- thread (k1 = t>>5, m' = t&31).
+__device__ __forceinline__ void fwd_pass2(cpx* lds) {
+    const int t = opaque_tid();
+    const int k1 = t >> 5, mp = t & 31;
+    cpx* base = lds + k1 * ROW + mp;
+    const cpx* tC = lds + OFF_C + mp;
+    cpx v[R2];
+#pragma unroll
+    for (int n2 = 0; n2 < R2; ++n2) v[n2] = base[n2 * CHUNK];
+    dft_dif<R2, -1>(v);
+    static_for<R2>([&](auto K) {
+        constexpr int k2 = decltype(K)::value;
+        cpx y = v[brev(k2, R2)];
+        if constexpr (k2 != 0) y = cmul(y, tC[k2 * 32]);
+        base[k2 * CHUNK] = y;
+    });
+}
+
+// Pass 3 (radix 32 over m', registers only) -- thread (k1 = t>>5, k2 = t&31).
+// On return bin k = k1 + 16*k2 + 512*k3 is in v[brev(k3, 32)].
+__device__ __forceinline__ void fwd_pass3(const cpx* lds, cpx* v) {
+    const int t = opaque_tid();
+    const float4* src = reinterpret_cast<const float4*>(lds + (t >> 5) * ROW + (t & 31) * CHUNK);
+#pragma unroll
+    for (int j = 0; j < R3 / 2; ++j) {
+        const float4 q = src[j];
+        v[2 * j] = cpx{q.x, q.y};
+        v[2 * j + 1] = cpx{q.z, q.w};
+    }
+    dft_dif<R3, -1>(v);
+}
+
+// ------------------------------------------------------------ inverse passes
+// Pass A (radix 32 over k3, registers) then twiddle conj(W_1024^(n3*k2)) -> LDS.
+// Input: z[brev(k3)] = Z[k1,k2,k3] (same placement fwd_pass3 produces).
+__device__ __forceinline__ void inv_passA(cpx* lds, cpx* z) {
+    const int t = opaque_tid();
+    const int k2 = t & 31;
+    // z is indexed by brev(k3); a DIF butterfly wants natural order input. Re-label:
+    cpx v[R3];
+    static_for<R3>([&](auto K) {
+        constexpr int k3 = decltype(K)::value;
+        v[k3] = z[brev(k3, R3)];
+    });
+    dft_dif<R3, +1>(v);
+    const cpx* tC = lds + OFF_C + k2;
+    float4* dst = reinterpret_cast<float4*>(lds + (t >> 5) * ROW + k2 * CHUNK);
+    static_for<R3 / 2>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        cpx y0 = v[brev(2 * j, R3)], y1 = v[brev(2 * j + 1, R3)];
+        if constexpr (j != 0) y0 = cmulc(y0, tC[(2 * j) * 32]);
+        y1 = cmulc(y1, tC[(2 * j + 1) * 32]);
+        dst[j] = float4{y0.x, y0.y, y1.x, y1.y};
+    });
+}
+
+// Pass B (radix 32 over k2, in place) -- thread (k1 = t>>5, n3 = t&31);
+// twiddle conj(W_N^(k1*(32*n2 + n3))) = conj(A[k1][n2] * Bt[k1][n3]).
+__device__ __forceinline__ void inv_passB(cpx* lds) {
+    const int t = opaque_tid();
+    const int k1 = t >> 5, n3 = t & 31;
+    cpx* base = lds + k1 * ROW + n3;
+    cpx v[R2];
+#pragma unroll
+    for (int k2 = 0; k2 < R2; ++k2) v[k2] = base[k2 * CHUNK];
+    dft_dif<R2, +1>(v);
+    const cpx b = lds[OFF_B + k1 * 32 + n3];
+    const cpx* tA = lds + OFF_A + k1 * 32;
+    static_for<R2>([&](auto K) {
+        constexpr int n2 = decltype(K)::value;
+        cpx y = v[brev(n2, R2)];
+        cpx w = b;
+        if constexpr (n2 != 0) w = cmul(tA[n2], b);
+        base[n2 * CHUNK] = cmulc(y, w);
+    });
+}
+
+// Pass C (radix 16 over k1, two adjacent m per thread), registers out:
+// c0[brev(n1)] = corr[n1*1024 + 2t], c1[...] = corr[n1*1024 + 2t + 1].
+__device__ __forceinline__ void inv_passC(const cpx* lds, cpx* c0, cpx* c1) {
+    const int t = opaque_tid();
+    const int n2 = t >> 4, mp = 2 * (t & 15);
+    const float4* src = reinterpret_cast<const float4*>(lds + n2 * CHUNK + mp);
+#pragma unroll
+    for (int k1 = 0; k1 < R1; ++k1) {
+        const float4 q = src[k1 * (ROW / 2)];
+        c0[k1] = cpx{q.x, q.y};
+        c1[k1] = cpx{q.z, q.w};
+    }
+    dft_dif<R1, +1>(c0);
+    dft_dif<R1, +1>(c1);
+}
+
+// =========================================================================
+// K_A: carrier stage
+// =========================================================================
+template <int FMT, bool WANT_STD, bool DUMP>
+__global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples, int n_blocks,
+                                                DevCfg cfg, const cpx* __restrict__ tables,
+                                                CarStats* __restrict__ stats,
+                                                cpx* __restrict__ dump_fft) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cpx* lds = reinterpret_cast<cpx*>(smem_raw);
+    double* sc_d = reinterpret_cast<double*>(lds + OFF_S);
+    unsigned long long* sc_u = reinterpret_cast<unsigned long long*>(lds + OFF_S + 16);
+    float* sc_nb = reinterpret_cast<float*>(lds + OFF_S + 32);
+
+    load_tables(lds, tables);
+    const size_t blk_bytes = size_t(N) * (FMT == THR_IN_U8 ? 2 : 8);
+
+    for (int b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+        const void* blk = static_cast<const unsigned char*>(samples) + size_t(b) * blk_bytes;
+        __syncthreads();  // tables ready / previous block's LDS reads done
+        fwd_pass1<FMT, false>(lds, blk, nullptr, cpx{}, cpx{});
+        __syncthreads();
+        fwd_pass2(lds);
+        __syncthreads();
+        cpx v[R3];
+        fwd_pass3(lds, v);
+
+        // ---- statistics over the spectrum held in registers
+        const int t = opaque_tid();
+        const int kbase = (t >> 5) + 16 * (t & 31);
+        float s2 = 0.f, s1 = 0.f;
+        unsigned long long best = 0;
+        static_for<R3>([&](auto K) {
+            constexpr int k3 = decltype(K)::value;
+            const float p = cnorm(v[brev(k3, R3)]);
+            s2 += p;
+            if constexpr (WANT_STD) s1 += __builtin_amdgcn_sqrtf(p);
+            const unsigned wi = unsigned(kbase + 512 * k3 - cfg.win_lo) & unsigned(N - 1);
+            if (wi < unsigned(cfg.win_count)) {
+                const unsigned long long key =
+                    ((unsigned long long)__float_as_uint(p) << 32) | (0xFFFFFFFFu - wi);
+                best = key > best ? key : best;
+            }
+        });
+        const double tot2 = block_sum((double)s2, sc_d);
+        double tot1 = 0.0;
+        if constexpr (WANT_STD) tot1 = block_sum((double)s1, sc_d);
+        best = block_max(best, sc_u);
+        const unsigned wi = 0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu);
+        int peak_idx = int(wi) + cfg.win_lo;
+        if (peak_idx > N) peak_idx -= N;  // sic: '>' (carrier_detect.py:151)
+        // 7-bin neighbourhood around the peak (indices wrap here; K_fit flags
+        // the cases where the reference would raise IndexError instead)
+        static_for<R3>([&](auto K) {
+            constexpr int k3 = decltype(K)::value;
+            const unsigned d = unsigned(kbase + 512 * k3 - peak_idx + 3) & unsigned(N - 1);
+            if (d < 7u) sc_nb[d] = cnorm(v[brev(k3, R3)]);
+        });
+        if constexpr (DUMP) {
+            cpx* out = dump_fft + size_t(b) * N;
+            static_for<R3>([&](auto K) {
+                constexpr int k3 = decltype(K)::value;
+                out[kbase + 512 * k3] = v[brev(k3, R3)];
+            });
+        }
+        __syncthreads();
+        if (t == 0) {
+            CarStats st;
+            st.sum_mag2 = (float)tot2;
+            st.sum_mag = (float)tot1;
+            st.peak_mag = sqrtf(__uint_as_float(unsigned(best >> 32)));
+            st.peak_idx = peak_idx;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) st.nb[j] = sqrtf(sc_nb[j]);
+            st.pad = 0;
+            stats[b] = st;
+        }
+    }
+}
+
+// =========================================================================
+// K_fit: one lane per block
+// =========================================================================
+__device__ __forceinline__ void dirichlet_eval(double u, double n, double w, double& d,
+                                               double& dd) {
+    // D(u) = sin(pi w u / n) / (w sin(pi u / n)),  dD/du
+    if (fabs(u) < 1e-12) {
+        d = 1.0;
+        dd = 0.0;
+        return;
+    }
+    double sw, cw, s1, c1;
+    sincospi(w * u / n, &sw, &cw);
+    sincospi(u / n, &s1, &c1);
+    const double pi = 3.14159265358979323846;
+    d = sw / (w * s1);
+    dd = (pi * w / n * cw * s1 - sw * pi / n * c1) / (w * s1 * s1);
+}
+
+__device__ inline double dirichlet_fit(const float* y, double n, double w, int* iters) {
+    // Levenberg-Marquardt on f_j(A, o) = A * |D(x_j - o)|, x_j = j - 3, from
+    // p0 = (y[3], 0) -- same model/start as carrier_sync.py:179-194.
+    double A = y[3], o = 0.0;
+    double lambda = 1e-3;
+    auto cost_of = [&](double a, double off) {
+        double c = 0;
+        for (int j = 0; j < 7; ++j) {
+            double d, dd;
+            dirichlet_eval(double(j - 3) - off, n, w, d, dd);
+            const double r = double(y[j]) - a * fabs(d);
+            c += r * r;
+        }
+        return c;
+    };
+    double cost = cost_of(A, o);
+    int it = 0;
+    for (; it < 60; ++it) {
+        double jaa = 0, jao = 0, joo = 0, ga = 0, go = 0;
+        for (int j = 0; j < 7; ++j) {
+            double d, dd;
+            dirichlet_eval(double(j - 3) - o, n, w, d, dd);
+            const double sgn = d < 0 ? -1.0 : 1.0;
+            const double fa = fabs(d);            // df/dA
+            const double fo = -A * sgn * dd;      // df/do  (u = x - o)
+            const double r = double(y[j]) - A * fa;
+            jaa += fa * fa;
+            jao += fa * fo;
+            joo += fo * fo;
+            ga += fa * r;
+            go += fo * r;
+        }
+        bool accepted = false;
+        double dA = 0, dO = 0;
+        for (int tries = 0; tries < 12 && !accepted; ++tries) {
+            const double a11 = jaa * (1 + lambda), a22 = joo * (1 + lambda), a12 = jao;
+            const double det = a11 * a22 - a12 * a12;
+            if (!(fabs(det) > 0)) {
+                lambda *= 10;
+                continue;
+            }
+            dA = (a22 * ga - a12 * go) / det;
+            dO = (a11 * go - a12 * ga) / det;
+            const double c2 = cost_of(A + dA, o + dO);
+            if (c2 <= cost) {
+                A += dA;
+                o += dO;
+                cost = c2;
+                lambda = fmax(lambda * 0.1, 1e-15);
+                accepted = true;
+            } else {
+                lambda *= 10;
+            }
+        }
+        if (!accepted) break;
+        if (fabs(dO) < 1e-11 && fabs(dA) <= 1e-11 * fabs(A)) {
+            ++it;
+            break;
+        }
+    }
+    *iters = it;
+    return o;
+}
+
+__global__ __launch_bounds__(64) void k_fit(int n_blocks, DevCfg cfg,
+                                            const CarStats* __restrict__ stats,
+                                            const long long* __restrict__ block_idx,
+                                            ShiftParams* __restrict__ shifts,
+                                            int* __restrict__ work_list,
+                                            int* __restrict__ work_count,
+                                            thr_record* __restrict__ records) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    const CarStats st = stats[b];
+    const int n = cfg.block_len;
+    // float32 arithmetic on purpose: the reference's carrier statistics are
+    // float32 under NumPy >= 2 (carrier_detect.py:99-115)
+    const float peak_pow = st.peak_mag * st.peak_mag;
+    const float noise_pow = (st.sum_mag2 - 2.0f * peak_pow) / float(n - 1);
+    const float noise_rms = sqrtf(noise_pow);
+    float thr = cfg.car_thr[0] + cfg.car_thr[1] * (noise_rms * noise_rms);
+    if (cfg.car_want_std) {
+        const double m1 = double(st.sum_mag) / n, m2 = double(st.sum_mag2) / n;
+        const float var = float(m2 - m1 * m1);
+        thr += cfg.car_thr[2] * var;
+    }
+    thr = sqrtf(thr);
+    bool detected = st.peak_mag > thr;
+    unsigned flags = 0;
+    double offset = 0.0;
+    if (detected && st.peak_idx + 3 >= n) {
+        flags |= THR_FLAG_INDEX_ERROR;  // carrier_sync.py:187 raises here
+        detected = false;
+    }
+    if (detected) {
+        flags |= THR_FLAG_CARRIER;
+        int iters;
+        offset = dirichlet_fit(st.nb, double(n), double(cfg.carrier_len), &iters);
+        // shift = -(bin + offset)  (carrier_sync.py:71)
+        const double s = -(double(st.peak_idx) + offset);
+        const double si = rint(s);
+        ShiftParams sp;
+        const int r1 = n / 1024;  // first-pass radix: phasor step between sub-sequences
+        for (int j = 0; j < 16; ++j) {
+            double a = s * double(j) / double(r1);
+            a -= rint(a);
+            double sn, cs;
+            sincospi(2.0 * a, &sn, &cs);
+            sp.rpow[j] = float2{float(cs), float(sn)};
+        }
+        {
+            double a = -0.5 * s;  // exp(2 pi i * s * (-1/2))
+            a -= rint(a);
+            double sn, cs;
+            sincospi(2.0 * a, &sn, &cs);
+            sp.c0 = float2{float(cs), float(sn)};
+        }
+        long long sim = (long long)si % n;
+        if (sim < 0) sim += n;
+        sp.si_mod = int(sim);
+        sp.sf_over_n = float((s - si) / double(n));
+        shifts[b] = sp;
+        const int slot = atomicAdd(work_count, 1);
+        work_list[slot] = b;
+    }
+    const long long bi = block_idx ? block_idx[b] : (long long)b;
+    for (int tpl = 0; tpl < cfg.n_templates; ++tpl) {
+        thr_record r;
+        r.block_idx = bi;
+        r.flags = flags;
+        r.template_id = tpl;
+        r.carrier_bin = st.peak_idx;
+        r.corr_sample = -1;
+        r.carrier_offset = offset;
+        r.corr_offset = 0.0;
+        r.carrier_energy = st.peak_mag;
+        r.carrier_noise = noise_rms;
+        r.corr_energy = 0.f;
+        r.corr_noise = 0.f;
+        r.reserved = 0;
+        records[size_t(b) * cfg.n_templates + tpl] = r;
+    }
+}
+
+// =========================================================================
+// K_B: shift + FFT#2 + matched filter + SoA
+// =========================================================================
+// MULTI: more than one template -- the shifted spectrum is parked in a
+// per-workgroup global scratch row (L2-resident) instead of 64 live VGPRs.
+template <int FMT, bool WANT_STD, bool MULTI, bool DUMP>
+__global__ __launch_bounds__(NT) void k_correlate(
+    const void* __restrict__ samples, DevCfg cfg, const cpx* __restrict__ tables,
+    const cpx* __restrict__ twn, const float4* __restrict__ tspec,
+    const ShiftParams* __restrict__ shifts, const int* __restrict__ work_list,
+    const int* __restrict__ work_count, thr_record* __restrict__ records,
+    float4* __restrict__ xhat_scratch, cpx* __restrict__ dump_xhat,
+    cpx* __restrict__ dump_corr, int dump_template) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cpx* lds = reinterpret_cast<cpx*>(smem_raw);
+    double* sc_d = reinterpret_cast<double*>(lds + OFF_S);
+    unsigned long long* sc_u = reinterpret_cast<unsigned long long*>(lds + OFF_S + 16);
+    float* sc_m = reinterpret_cast<float*>(lds + OFF_S + 32);
+
+    load_tables(lds, tables);
+    const size_t blk_bytes = size_t(N) * (FMT == THR_IN_U8 ? 2 : 8);
+    const int n_work = *work_count;
+
+    for (int wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+        const int b = work_list[wi];
+        const int t = opaque_tid();
+        const void* blk = static_cast<const unsigned char*>(samples) + size_t(b) * blk_bytes;
+        const ShiftParams* sp = shifts + b;
+
+        // per-thread phasor for m = 2t, 2t+1: c0 * exp(2 pi i s m / N)
+        cpx p[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int m = 2 * t + e;
+            const int q = (sp->si_mod * m) & (N - 1);
+            const cpx wq = cconj(twn[q]);  // exp(+2 pi i q / N)
+            float sn, cs;
+            sincosf(6.283185307179586f * (sp->sf_over_n * float(m)), &sn, &cs);
+            p[e] = cmul(cmul(wq, cpx{cs, sn}), sp->c0);
+        }
+        __syncthreads();
+        fwd_pass1<FMT, true>(lds, blk, sp->rpow, p[0], p[1]);
+        __syncthreads();
+        fwd_pass2(lds);
+        __syncthreads();
+        cpx xh[R3];
+        fwd_pass3(lds, xh);
+
+        const int kbase = (t >> 5) + 16 * (t & 31);
+        float e2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < R3; ++i) e2 += cnorm(xh[i]);
+        const double xenergy = block_sum((double)e2, sc_d) / double(N);  // mean |X|^2
+        if constexpr (DUMP) {
+          if (dump_xhat != nullptr) {
+            cpx* out = dump_xhat + size_t(b) * N;
+            static_for<R3>([&](auto K) {
+                constexpr int k3 = decltype(K)::value;
+                out[kbase + 512 * k3] = xh[brev(k3, R3)];
+            });
+          }
+        }
+        float4* park = nullptr;
+        if constexpr (MULTI) {
+            park = xhat_scratch + size_t(blockIdx.x) * (N / 2) + t;
+            static_for<R3 / 2>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                park[j * NT] = float4{xh[brev(2 * j, R3)].x, xh[brev(2 * j, R3)].y,
+                                      xh[brev(2 * j + 1, R3)].x, xh[brev(2 * j + 1, R3)].y};
+            });
+        }
+
+        const int n_tpl = MULTI ? cfg.n_templates : 1;
+        for (int tpl = 0; tpl < n_tpl; ++tpl) {
+            // ---- X * conj(T)/N in digit-reversed register order
+            const int t = opaque_tid();  // re-derive per template: keeps LICM off the loop body
+            if constexpr (MULTI) park = xhat_scratch + size_t(blockIdx.x) * (N / 2) + t;
+            const float4* ts = tspec + size_t(tpl) * (N / 2) + t;
+            cpx z[R3];
+            static_for<R3 / 2>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                const float4 q = ts[j * NT];
+                cpx x0, x1;
+                if constexpr (MULTI) {
+                    const float4 xx = park[j * NT];  // own writes: program order suffices
+                    x0 = cpx{xx.x, xx.y};
+                    x1 = cpx{xx.z, xx.w};
+                } else {
+                    x0 = xh[brev(2 * j, R3)];
+                    x1 = xh[brev(2 * j + 1, R3)];
+                }
+                z[brev(2 * j, R3)] = cmul(x0, cpx{q.x, q.y});
+                z[brev(2 * j + 1, R3)] = cmul(x1, cpx{q.z, q.w});
+            });
+            __syncthreads();  // everyone done reading LDS from the previous pass
+            inv_passA(lds, z);
+            __syncthreads();
+            inv_passB(lds);
+            __syncthreads();
+            cpx c0[R1], c1[R1];
+            inv_passC(lds, c0, c1);
+
+            // ---- |corr|^2, windowed first-max, optional std sums
+            unsigned long long best = 0;
+            float s1 = 0.f, s2 = 0.f;
+            static_for<R1>([&](auto K) {
+                constexpr int n1 = decltype(K)::value;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int n = n1 * S1 + 2 * t + e;
+                    const float pw = cnorm(e ? c1[brev(n1, R1)] : c0[brev(n1, R1)]);
+                    if (n >= cfg.corr_lo && n < cfg.corr_hi) {
+                        const unsigned long long key =
+                            ((unsigned long long)__float_as_uint(pw) << 32) |
+                            (0xFFFFFFFFu - unsigned(n));
+                        best = key > best ? key : best;
+                    }
+                    if constexpr (WANT_STD) {
+                        if (n < cfg.corr_len) {
+                            s2 += pw;
+                            s1 += __builtin_amdgcn_sqrtf(pw);
+                        }
+                    }
+                }
+            });
+            best = block_max(best, sc_u);
+            double tot1 = 0, tot2 = 0;
+            if constexpr (WANT_STD) {
+                tot1 = block_sum((double)s1, sc_d);
+                tot2 = block_sum((double)s2, sc_d);
+            }
+            const int pk = int(0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu));
+            static_for<R1>([&](auto K) {
+                constexpr int n1 = decltype(K)::value;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int n = n1 * S1 + 2 * t + e;
+                    const unsigned d = unsigned(n - pk + 1);
+                    if (d < 3u) sc_m[d] = cnorm(e ? c1[brev(n1, R1)] : c0[brev(n1, R1)]);
+                }
+            });
+            if constexpr (DUMP) {
+              if (dump_corr != nullptr && tpl == dump_template) {
+                cpx* out = dump_corr + size_t(b) * N;
+                static_for<R1>([&](auto K) {
+                    constexpr int n1 = decltype(K)::value;
+                    reinterpret_cast<float4*>(out + n1 * S1)[t] =
+                        float4{c0[brev(n1, R1)].x, c0[brev(n1, R1)].y, c1[brev(n1, R1)].x,
+                               c1[brev(n1, R1)].y};
+                });
+              }
+            }
+            __syncthreads();
+            if (t == 0) {
+                // soa_estimator.py:108-134 (float64 in the reference)
+                const double pm2 = (double)__uint_as_float(unsigned(best >> 32));
+                const double peak_mag = sqrt(pm2);
+                const double noise_pow =
+                    (xenergy * (double)cfg.tmpl_energy[tpl] - pm2) / double(N);
+                const double noise_rms = sqrt(noise_pow);
+                double th = cfg.cor_thr[0] + cfg.cor_thr[1] * (noise_rms * noise_rms);
+                if constexpr (WANT_STD) {
+                    const double m1 = tot1 / cfg.corr_len, m2 = tot2 / cfg.corr_len;
+                    th += cfg.cor_thr[2] * (m2 - m1 * m1);
+                }
+                th = sqrt(th);
+                const bool det = peak_mag > th;
+                double off = 0.0;
+                if (det && pk != 0 && pk != cfg.corr_len - 1) {
+                    // log-parabola on magnitudes == same formula on log |.|^2
+                    const double la = log((double)sc_m[0]), lb = log((double)sc_m[1]),
+                                 lc = log((double)sc_m[2]);
+                    off = 0.5 * (lc - la) / (2 * lb - la - lc);
+                    off = off < -0.6 ? -0.6 : off > 0.6 ? 0.6 : off;
+                }
+                thr_record* r = records + size_t(b) * cfg.n_templates + tpl;
+                r->corr_sample = pk;
+                r->corr_offset = off;
+                r->corr_energy = (float)peak_mag;
+                r->corr_noise = (float)noise_rms;
+                if (det) r->flags |= THR_FLAG_CORR;
+            }
+        }
+    }
+}
+
+// =========================================================================
+// K7: order-preserving compaction of detected records (single workgroup scan)
+// =========================================================================
+__global__ __launch_bounds__(1024) void k_compact(const thr_record* __restrict__ in, int n,
+                                                  thr_record* __restrict__ out,
+                                                  int* __restrict__ n_out) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const bool keep = i < n && (in[i].flags & THR_FLAG_CORR);
+        const unsigned long long mask = __ballot(keep);
+        const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wv] = __popcll(mask);
+        __syncthreads();
+        int woff = 0, total = 0;
+        for (int w = 0; w < 16; ++w) {
+            if (w < wv) woff += wsum[w];
+            total += wsum[w];
+        }
+        const int c = carry;
+        if (keep) out[c + woff + prefix] = in[i];
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_out = carry;
+}
+
+// ------------------------------------------------------------------ launchers
+size_t lds_bytes_16k() { return LDS_BYTES; }
+
+namespace {
+typedef void (*carrier_fn)(const void*, int, DevCfg, const cpx*, CarStats*, cpx*);
+typedef void (*correlate_fn)(const void*, DevCfg, const cpx*, const cpx*, const float4*,
+                             const ShiftParams*, const int*, const int*, thr_record*, float4*,
+                             cpx*, cpx*, int);
+
+template <int FMT, bool STD>
+carrier_fn pick_carrier(bool dump) {
+    return dump ? &k_carrier<FMT, STD, true> : &k_carrier<FMT, STD, false>;
+}
+carrier_fn carrier_variant(int fmt, bool want_std, bool dump) {
+    if (fmt == THR_IN_U8)
+        return want_std ? pick_carrier<THR_IN_U8, true>(dump) : pick_carrier<THR_IN_U8, false>(dump);
+    return want_std ? pick_carrier<THR_IN_C64, true>(dump) : pick_carrier<THR_IN_C64, false>(dump);
+}
+template <int FMT, bool STD, bool MULTI>
+correlate_fn pick_correlate(bool dump) {
+    return dump ? &k_correlate<FMT, STD, MULTI, true> : &k_correlate<FMT, STD, MULTI, false>;
+}
+template <int FMT>
+correlate_fn pick_correlate2(bool want_std, bool multi, bool dump) {
+    if (want_std)
+        return multi ? pick_correlate<FMT, true, true>(dump) : pick_correlate<FMT, true, false>(dump);
+    return multi ? pick_correlate<FMT, false, true>(dump) : pick_correlate<FMT, false, false>(dump);
+}
+correlate_fn correlate_variant(int fmt, bool want_std, bool multi, bool dump) {
+    return fmt == THR_IN_U8 ? pick_correlate2<THR_IN_U8>(want_std, multi, dump)
+                            : pick_correlate2<THR_IN_C64>(want_std, multi, dump);
+}
+}  // namespace
+
+hipError_t prepare_16k() {
+    // > 64 KiB of dynamic LDS must be opted into, per device and per kernel variant
+    for (int fmt = 0; fmt < 2; ++fmt)
+        for (int st = 0; st < 2; ++st)
+            for (int d = 0; d < 2; ++d) {
+                hipError_t e = hipFuncSetAttribute(
+                    reinterpret_cast<const void*>(carrier_variant(fmt, st, d)),
+                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+                if (e != hipSuccess) return e;
+                for (int m = 0; m < 2; ++m) {
+                    e = hipFuncSetAttribute(
+                        reinterpret_cast<const void*>(correlate_variant(fmt, st, m, d)),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+                    if (e != hipSuccess) return e;
+                }
+            }
+    return hipSuccess;
+}
+
+hipError_t launch_carrier_16k(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,
+                              const float2* tables, CarStats* stats, float2* dump_fft, int grid,
+                              hipStream_t stream) {
+    carrier_fn fn = carrier_variant(fmt, cfg.car_want_std != 0, dump_fft != nullptr);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(NT), LDS_BYTES, stream, samples, n_blocks, cfg, tables,
+                       stats, dump_fft);
+    return hipGetLastError();
+}
+
+hipError_t launch_fit(int n_blocks, const DevCfg& cfg, const CarStats* stats,
+                      const long long* block_idx, ShiftParams* shifts, int* work_list,
+                      int* work_count, thr_record* records, hipStream_t stream) {
+    hipLaunchKernelGGL(k_fit, dim3((n_blocks + 63) / 64), dim3(64), 0, stream, n_blocks, cfg, stats,
+                       block_idx, shifts, work_list, work_count, records);
+    return hipGetLastError();
+}
+
+hipError_t launch_correlate_16k(int fmt, const void* samples, const DevCfg& cfg,
+                                const float2* tables, const float2* twn, const float4* tspec,
+                                const ShiftParams* shifts, const int* work_list,
+                                const int* work_count, thr_record* records, float4* xhat_scratch,
+                                float2* dump_xhat, float2* dump_corr, int dump_template, int grid,
+                                hipStream_t stream) {
+    const bool dump = dump_xhat != nullptr || dump_corr != nullptr;
+    correlate_fn fn = correlate_variant(fmt, cfg.cor_want_std != 0, cfg.n_templates > 1, dump);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(NT), LDS_BYTES, stream, samples, cfg, tables, twn,
+                       tspec, shifts, work_list, work_count, records, xhat_scratch, dump_xhat,
+                       dump_corr, dump_template);
+    return hipGetLastError();
+}
+
+hipError_t launch_compact(const thr_record* in, int n, thr_record* out, int* n_out,
+                          hipStream_t stream) {
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, stream, in, n, out, n_out);
+    return hipGetLastError();
+}
+
+}  // namespace thr

@@ -1,0 +1,65 @@
+// Shared device/host structures of the detection pipeline.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/thrifty_hip.h"
+
+namespace thr {
+
+constexpr int kMaxTemplates = 8;
+
+// Per-launch constants (passed by value as a kernel argument).
+struct DevCfg {
+    int block_len;
+    int history_len;
+    int n_templates;
+    int carrier_len;   // Dirichlet kernel width W (carrier_sync.py:150-196)
+    int win_lo;        // first FFT index of the carrier window (carrier_detect.py:17-58)
+    int win_count;     // number of bins in the (wrapping, inclusive) window, <= N
+    int corr_lo;       // unique-lag window [corr_lo, corr_hi) (soa_estimator.py:20-39)
+    int corr_hi;
+    int corr_len;      // block_len - template_len + 1
+    int car_want_std;  // carrier threshold has a stddev term
+    int cor_want_std;  // correlation threshold has a stddev term
+    float car_thr[3];
+    float cor_thr[3];
+    float tmpl_energy[kMaxTemplates];  // sum t^2 (soa_estimator.py:65)
+};
+
+// K_A -> K_fit
+struct CarStats {
+    float sum_mag2;  // sum |X|^2
+    float sum_mag;   // sum |X| (only if car_want_std)
+    float peak_mag;  // |X[peak]|
+    int peak_idx;    // reference's peak_idx (may equal N, carrier_detect.py:151)
+    float nb[7];     // |X[peak-3 .. peak+3]| (indices wrapped)
+    int pad;
+};
+
+// K_fit -> K_B: the frequency-shift phasor exp(2 pi i s (n/N - 1/2)), factored
+struct ShiftParams {
+    float2 rpow[16];  // exp(2 pi i s j / R1), j = sub-sequence index of pass 1
+    float2 c0;        // exp(-pi i s)
+    int si_mod;       // round(s) mod N
+    float sf_over_n;  // (s - round(s)) / N
+};
+
+// detect16k.hip
+hipError_t prepare_16k();
+size_t lds_bytes_16k();
+hipError_t launch_carrier_16k(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,
+                              const float2* tables, CarStats* stats, float2* dump_fft, int grid,
+                              hipStream_t stream);
+hipError_t launch_fit(int n_blocks, const DevCfg& cfg, const CarStats* stats,
+                      const long long* block_idx, ShiftParams* shifts, int* work_list,
+                      int* work_count, thr_record* records, hipStream_t stream);
+hipError_t launch_correlate_16k(int fmt, const void* samples, const DevCfg& cfg,
+                                const float2* tables, const float2* twn, const float4* tspec,
+                                const ShiftParams* shifts, const int* work_list,
+                                const int* work_count, thr_record* records, float4* xhat_scratch,
+                                float2* dump_xhat, float2* dump_corr, int dump_template, int grid,
+                                hipStream_t stream);
+hipError_t launch_compact(const thr_record* in, int n, thr_record* out, int* n_out,
+                          hipStream_t stream);
+
+}  // namespace thr
