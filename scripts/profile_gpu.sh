@@ -1,0 +1,25 @@
+#!/bin/bash
+# Run ON THE GPU BOX (via gpurun): kernel-trace stats + PMC passes of bench.py.
+# Usage: scripts/profile_gpu.sh <tag> [bench args...]   -> gpurun_out/prof_<tag>/
+# PMC passes are separate runs with --kernel-trace only (never with sys/hip traces).
+set -u
+TAG=${1:-r01}; shift || true
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/prof_$TAG
+mkdir -p $O
+export TMPDIR=/tmp
+cd $R
+BENCH="python bench.py --steps 16 --warmup 2 --batch 8192 --cpu-seconds 0 $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o stats -- $BENCH > $O/bench_stats.log 2>&1
+pass() {  # name counters...
+  local name=$1; shift
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/$name -o $name -- $BENCH > $O/bench_$name.log 2>&1
+}
+pass pmc_sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
+pass pmc_sq2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT
+pass pmc_grbm GRBM_GUI_ACTIVE GRBM_COUNT
+pass pmc_fetch FETCH_SIZE
+pass pmc_write WRITE_SIZE
+find $O -name "*.csv" | head -40
+python scripts/summarize_profile.py $O > $O/summary.md 2>&1
+cat $O/summary.md

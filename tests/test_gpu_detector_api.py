@@ -1,0 +1,118 @@
+"""GPU tests of the drop-in operator API (thrifty_amd.detect) -- they read like the
+reference's usage: build DetectorSettings, iterate a Detector over card_reader
+blocks, print result.serialize()."""
+import io
+
+import numpy as np
+import pytest
+
+from thrifty_amd import block_data
+from thrifty_amd.detect import (Detector, DetectorSettings, MultiTemplateDetector,
+                                SummaryLineFormatter, detector_cli)
+
+pytestmark = pytest.mark.gpu
+
+
+def settings_of(g, template=None):
+    tpl = g["template"] if template is None else template
+    return DetectorSettings(int(g["block_len"]), int(g["history_len"]), int(np.asarray(tpl).shape[-1]),
+                            tuple(g["carrier_thresh"]), tuple(int(v) for v in g["carrier_window"]),
+                            tpl, tuple(g["corr_thresh"]))
+
+
+def card_text(g):
+    return "# synthetic\n" + "".join(
+        block_data.card_line(1000.0 + i, int(g["block_idx"][i]), g["blocks"][i])
+        for i in range(len(g["blocks"])))
+
+
+def assert_toad_close(got_lines, want_text):
+    want_lines = str(want_text).split("\n") if len(str(want_text)) else []
+    assert len(got_lines) == len(want_lines)
+    for got, want in zip(got_lines, want_lines):
+        a, b = got.split(), want.split()
+        assert a[0] == b[0] and a[2] == b[2]                      # rxid, block
+        assert float(a[1]) == float(b[1])                          # timestamp
+        assert a[4] == b[4] and a[8] == b[8]                       # corr sample, carrier bin: exact
+        np.testing.assert_allclose(float(a[3]), float(b[3]), atol=2e-4, rtol=0)      # soa
+        np.testing.assert_allclose(float(a[5]), float(b[5]), atol=1e-4, rtol=1e-4)   # offset
+        for k in (6, 7, 10, 11):                                   # energies / noises
+            np.testing.assert_allclose(float(a[k]), float(b[k]), rtol=1e-4)
+        np.testing.assert_allclose(float(a[9]), float(b[9]), atol=1e-3, rtol=0)      # carrier offset
+
+
+@pytest.mark.parametrize("name,batch", [("c2", 5), ("c2", 256), ("c1", 7)])
+def test_iterating_detector_reproduces_reference_toad(golden, name, batch):
+    g = golden(name)
+    det = Detector(settings_of(g), block_data.card_reader(io.StringIO(card_text(g))),
+                   rxid=int(g["rxid"]), batch_size=batch)
+    lines, n = [], 0
+    for i, (detected, result) in enumerate(det):
+        n += 1
+        assert result.block == g["block_idx"][i]                   # input order preserved
+        assert detected == bool(g["det"][i])
+        assert (result.corr_info is not None) == bool(g["carrier_det"][i])
+        if result.corr_info is None:
+            assert result.soa is None
+        if detected:
+            lines.append(result.serialize())
+    assert n == len(g["blocks"])
+    assert_toad_close(lines, g["toad"])
+
+
+def test_single_block_detect_and_yield_data(golden):
+    g = golden("c2")
+    st = settings_of(g)
+    det = Detector(st, None, rxid=0, yield_data=True)
+    assert det.new_len == 16384 - 4096
+    assert det.soa_estimate.window == (1537, 13825)
+    blk = block_data.IQBlock(block_data.raw_to_complex(g["blocks"][0]))   # complex Signal, no raw
+    detected, res, xhat, corr = det.detect(1000.0, int(g["block_idx"][0]), blk)
+    assert detected and res.corr_info.sample == g["sample"][0]
+    assert xhat.shape == (16384,) and corr.shape == (16384 - 1023 + 1,)
+    assert int(np.argmax(np.abs(corr[1537:13825]))) + 1537 == g["sample"][0]
+    np.testing.assert_allclose(np.mean(np.abs(xhat) ** 2), g["xhat_energy"][0], rtol=1e-5)
+    # noise-only block: 4-tuple with Nones (detect.py:70-78)
+    k = int(np.flatnonzero(~g["carrier_det"])[0])
+    detected, res, xhat, corr = det.detect(1.0, 0, block_data.IQBlock(
+        block_data.raw_to_complex(g["blocks"][k]), g["blocks"][k]))
+    assert not detected and res.corr_info is None and xhat is None and corr is None
+    line = SummaryLineFormatter(2.4e6, 16384)(detected, res)
+    assert line.startswith("blk=0; carrier: no ")
+
+
+def test_index_error_is_mirrored(golden):
+    g = golden("c2_straddle")
+    det = Detector(settings_of(g), None)
+    bad = int(np.flatnonzero(g["index_error"])[0])
+    with pytest.raises(IndexError):
+        det.detect(0.0, 0, g["blocks"][bad])
+
+
+def test_detector_cli_end_to_end(golden, tmp_path, capsys):
+    g = golden("c2")
+    np.save(tmp_path / "template.npy", g["template"])
+    (tmp_path / "detector.cfg").write_text(
+        "rxid: 0\nsample_rate: 2.4M\nblock_size: 16384\nblock_history: 4096\n"
+        "carrier_window: 7 - 110\ncarrier_threshold: 15 * snr\ncorr_threshold: 15*snr\n"
+        "template: %s\n" % (tmp_path / "template.npy"))
+    (tmp_path / "rx.card").write_text(card_text(g))
+    detector_cli(Detector, argv=[str(tmp_path / "rx.card"), "-o", str(tmp_path / "rx.toad"),
+                                 "-c", str(tmp_path / "detector.cfg")])
+    assert_toad_close((tmp_path / "rx.toad").read_text().strip().split("\n"), g["toad"])
+    summary = capsys.readouterr().out.strip().split("\n")
+    assert len(summary) == len(g["blocks"]) and summary[0].startswith("blk=5; carrier: yes")
+
+
+def test_multi_template_detector(golden):
+    gs = [golden("c5_tx%d" % i) for i in range(4)]
+    tpls = np.stack([g["template"] for g in gs])
+    st = settings_of(gs[0], tpls)
+    items = [(1000.0 + i, int(gs[0]["block_idx"][i]), gs[0]["blocks"][i]) for i in range(12)]
+    out = list(MultiTemplateDetector(st, iter(items), rxid=0, batch_size=5))
+    assert len(out) == 12 and all(len(o) == 4 for o in out)
+    for t, g in enumerate(gs):
+        lines = [o[t][1].serialize() for o in out if o[t][0]]
+        for ln in lines:
+            assert ln.split()[1] == str(t)                          # txid column
+        assert_toad_close([" ".join(ln.split()[:1] + ln.split()[2:]) for ln in lines], g["toad"])

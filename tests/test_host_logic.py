@@ -1,0 +1,222 @@
+"""CPU tests of the host side: settings grammar, block framing, .toad text, the C-ABI
+library's exports and its refusal to run without a GPU.  Known answers are the
+tables of the reference's own unit tests (tests/test_setting_parsers.py:12-99,
+test_settings.py, test_block_data.py:13-71) re-expressed against thrifty_amd.
+"""
+import argparse
+import io
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from thrifty_amd import _native, block_data, setting_parsers, settings, toads_data, util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---------------------------------------------------------------- parsers
+@pytest.mark.parametrize("string,expected", [
+    ("100", (100.0, 100.0, False)), ("-123.4", (-123.4, -123.4, False)),
+    ("100-200", (100.0, 200.0, False)), ("10e1 - 20e1", (100.0, 200.0, False)),
+    ("-100-100", (-100.0, 100.0, False)), ("-200--100", (-200.0, -100.0, False)),
+    ("100hz", (100.0, 100.0, True)), ("100-200 Hz", (100.0, 200.0, True)),
+    ("10-20 khz", (10000.0, 20000.0, True)), ("1.2345-2.3456 KHZ", (1.2345e3, 2.3456e3, True)),
+    ("433-435Mhz", (433e6, 435e6, True)), ("1.2345-2.3456 mhz", (1.2345e6, 2.3456e6, True)),
+    ("0--1", (0.0, -1.0, False)), ("7 - 110", (7.0, 110.0, False))])
+def test_freq_range(string, expected):
+    assert setting_parsers.freq_range(string) == expected
+
+
+def test_freq_range_invalid():
+    with pytest.raises(ValueError):
+        setting_parsers.freq_range("garbage")
+
+
+def test_normalize_freq_range():
+    assert setting_parsers.normalize_freq_range((7.0, 110.0, False), 146.48) == (7, 110)
+    assert setting_parsers.normalize_freq_range((-81e3, -79e3, True), 2.2e6 / 8192) == (-301, -294)
+
+
+@pytest.mark.parametrize("string,expected", [("1337.15", 1337.15), ("15.2M", 15200000.0),
+                                             ("987k", 987000.0), ("55m", 0.055), ("164u ", 164e-6)])
+def test_metric_float(string, expected):
+    assert setting_parsers.metric_float(string) == expected
+
+
+@pytest.mark.parametrize("string", ["garbage", "x53m", "500A"])
+def test_metric_float_invalid(string):
+    with pytest.raises(ValueError):
+        setting_parsers.metric_float(string)
+
+
+@pytest.mark.parametrize("string,expected", [
+    ("0", (0.0, 0.0, 0.0)), ("10.2", (10.2, 0.0, 0.0)), ("c", (1.0, 0.0, 0.0)),
+    ("11c", (11.0, 0.0, 0.0)), ("100 * constant", (100.0, 0.0, 0.0)), ("snr", (0.0, 1.0, 0.0)),
+    ("5.2*snr", (0.0, 5.2, 0.0)), (" 8s ", (0.0, 8.0, 0.0)), ("stddev", (0.0, 0.0, 1.0)),
+    ("2.1stddev", (0.0, 0.0, 2.1)), ("8.7*d", (0.0, 0.0, 8.7)), ("10 + 4*snr", (10.0, 4.0, 0)),
+    ("40 + 3.8*snr + 2 stddev", (40.0, 3.8, 2.0)), ("1+2s+3d+4+5s+6d", (5.0, 7.0, 9.0)),
+    ("c + s + d", (1.0, 1.0, 1.0)), ("15 * snr", (0.0, 15.0, 0.0))])
+def test_threshold(string, expected):
+    assert setting_parsers.threshold(string) == expected
+
+
+@pytest.mark.parametrize("string", ["", " ", "5+", "junk", "+5*stddev", "*snr", "stddev*snr",
+                                    "5 * stdde", "2 * sn", "const"])
+def test_threshold_invalid(string):
+    with pytest.raises(ValueError):
+        setting_parsers.threshold(string)
+
+
+# ---------------------------------------------------------------- settings
+DEFS = {
+    "foo": settings.Definition(["--foo", "-f"], float, "2e6", None),
+    "bar.baz": settings.Definition(["--baz", "-b"], float, "1e6", None),
+    "xyzzy": settings.Definition(["--xyzzy", "-x"], str, None, None),
+}
+
+
+def test_settings_defaults_config_args():
+    assert settings.load(None, None, DEFS) == {"foo": 2e6, "bar.baz": 1e6}
+    assert settings.load(None, io.StringIO("bar.baz:   1234.56"), DEFS)["bar.baz"] == 1234.56
+    assert settings.load(None, io.BytesIO(b"bar.baz:   1234.56 # c"), DEFS)["bar.baz"] == 1234.56
+    vals = settings.load({"bar.baz": "7.8", "foo": "9.0"}, io.StringIO("bar.baz: 12.34"), DEFS)
+    assert vals == {"foo": 9.0, "bar.baz": 7.8}
+
+
+def test_settings_errors():
+    with pytest.raises(settings.ConfigSyntaxError):
+        settings.load(None, io.StringIO("foobar"), DEFS)
+    with pytest.raises(settings.SettingKeyError):
+        settings.load(None, io.StringIO("foobar: 1"), DEFS)
+    with pytest.raises(settings.SettingKeyError):
+        settings.load({"foobar": "1"}, None, DEFS)
+
+
+def test_settings_argparse_and_load_args(tmp_path):
+    parser = argparse.ArgumentParser()
+    settings.add_argparse_arguments(parser, ["foo", "bar.baz"], definitions=DEFS)
+    args = vars(parser.parse_args(["-f", "12.34", "--baz=56.78"]))
+    assert args["foo"] == "12.34" and args["bar.baz"] == "56.78"
+    cfg = tmp_path / "thrift.cfg"
+    cfg.write_text("xyzzy: xyz\nfoo: 1.2\nbar.baz: 3.6")
+    parser = argparse.ArgumentParser()
+    parser.add_argument("-a", dest="a")
+    config, extra = settings.load_args(parser, ["xyzzy", "foo"],
+                                       argv=["-a", "extra", "--foo=2.3", "-c", str(cfg)],
+                                       definitions=DEFS)
+    extra.pop("verbose")
+    assert dict(config) == {"xyzzy": "xyz", "foo": 2.3} and dict(extra) == {"a": "extra"}
+
+
+def test_example_detector_cfg_keys():
+    """The reference's example/detector.cfg (values restated) parses to config #1."""
+    text = ("rxid: 0\nsample_rate: 2.4M\nchip_rate: 0.999707M\ntuner_freq: 433.83M\n"
+            "tuner_gain: 0.0\ncapture_skip: 20000\nblock_size: 16384\nblock_history: 4920\n"
+            "carrier_window: 7 - 110\ncarrier_threshold: 15 * snr\ncorr_threshold: 15 * snr\n"
+            "template: template.npy\n")
+    v = settings.load(None, io.StringIO(text))
+    assert v["block_size"] == 16384 and v["block_history"] == 4920 and v["rxid"] == 0
+    assert v["carrier_window"] == (7.0, 110.0, False)
+    assert v["carrier_threshold"] == (0.0, 15.0, 0.0) and v["sample_rate"] == 2.4e6
+
+
+# ---------------------------------------------------------------- block framing
+def test_raw_complex_round_trip():
+    raw = np.array([0, 0, 127, 128, 255, 255], dtype=np.uint8)
+    cplx = np.array([-0.9953 - 0.9953j, -0.0031 + 0.0047j, 0.9969 + 0.9969j], dtype=np.complex64)
+    np.testing.assert_allclose(block_data.raw_to_complex(raw), cplx, rtol=1e-2)
+    np.testing.assert_array_equal(block_data.complex_to_raw(cplx), raw)
+    every = np.arange(256, dtype=np.uint8)
+    np.testing.assert_array_equal(block_data.complex_to_raw(block_data.raw_to_complex(every)), every)
+
+
+def test_block_reader_history():
+    blocks = list(block_data.block_reader(io.BytesIO(bytes(range(14))), 3, 1))
+    assert [b[1] for b in blocks] == [0, 1, 2]
+    assert [list(block_data.complex_to_raw(b[2])) for b in blocks] == [
+        [0x7f, 0x7f, 0, 1, 2, 3], [2, 3, 4, 5, 6, 7], [6, 7, 8, 9, 10, 11]]
+    assert blocks[0][2].raw is None          # zero history is not a u8 value
+    assert list(blocks[1][2].raw) == [2, 3, 4, 5, 6, 7]
+    assert list(blocks[2][2].raw) == [6, 7, 8, 9, 10, 11]
+
+
+def test_card_reader_and_writer(golden):
+    stream = io.StringIO("# Some comments\n# more comments\n1000.5425 10 r0+Om5==\n"
+                         "Using Volk machine: avx2\n\n1000.5442 20 aaaaaa==")
+    blocks = list(block_data.card_reader(stream))
+    assert [b[0] for b in blocks] == [1000.5425, 1000.5442]
+    assert [b[1] for b in blocks] == [10, 20]
+    assert [tuple(block_data.complex_to_raw(b[2])) for b in blocks] == [(175, 79, 142, 155),
+                                                                        (105, 166, 154, 105)]
+    g = golden("small")
+    got = list(block_data.card_reader(io.BytesIO(str(g["card_text"]).encode())))
+    assert [b[1] for b in got] == list(g["block_idx"])
+    for b, raw in zip(got, g["blocks"]):
+        np.testing.assert_array_equal(b[2].raw, raw)
+    line = block_data.card_line(got[3][0], got[3][1], got[3][2].raw)
+    assert line in str(g["card_text"])
+
+
+# ---------------------------------------------------------------- .toad text
+def test_toad_serialize_matches_reference_text(golden):
+    """Re-serialising the reference's own .toad lines is the identity."""
+    g = golden("c2")
+    for line in str(g["toad"]).split("\n"):
+        rec = toads_data.DetectionResult.deserialize(line, with_rxid=True)
+        parts = line.split()
+        # rebuild with the exact float reprs the reference printed
+        assert rec.rxid == 0 and rec.block == int(parts[2])
+        assert rec.serialize().split()[:3] == parts[:3]
+        assert float(rec.serialize().split()[3]) == float(parts[3])
+    loaded = toads_data.load_toad(io.StringIO(str(g["toad"])))
+    assert len(loaded) == int(g["det"].sum())
+    arr = toads_data.toads_array(loaded)
+    assert np.array_equal(arr["sample"], g["sample"][g["det"]])
+
+
+def test_fft_bin_and_snr():
+    for num in (15, 16):
+        got = np.array([util.fft_bin(i, num) for i in range(num)])
+        np.testing.assert_array_equal(got, np.fft.fftfreq(num, 1. / num))
+    assert abs(util.snr(10.0, 1.0) - 20.0) < 1e-12
+
+
+# ---------------------------------------------------------------- C ABI library
+def _lib_or_skip():
+    if not os.path.exists(_native.LIB_PATH):
+        pytest.skip("libthriftyhip.so not built (run __graft_entry__.build())")
+
+
+def test_library_exports_every_declared_symbol():
+    _lib_or_skip()
+    header = open(os.path.join(ROOT, "include", "thrifty_hip.h")).read()
+    declared = set(re.findall(r"\b(thr_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(_native.EXPORTS)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _native.LIB_PATH]).decode()
+    for sym in declared:
+        assert (" T " + sym) in out, sym
+    lib = _native.load_library()
+    assert lib.thr_abi_version() == 1
+    assert _native.RECORD_DTYPE.itemsize == 64
+
+
+def test_engine_fails_loudly_without_gpu():
+    """No silent CPU fallback: without a HIP device construction raises."""
+    _lib_or_skip()
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("a GPU is present")
+    except ImportError:
+        pass
+    with pytest.raises(_native.NativeError):
+        _native.Engine(16384, 4096, np.ones(1023), (0, 15, 0), (7, 110), (0, 15, 0))
+
+
+def test_bad_settings_rejected():
+    _lib_or_skip()
+    with pytest.raises(_native.NativeError):
+        _native.Engine(16000, 4096, np.ones(1023), (0, 15, 0), (7, 110), (0, 15, 0))  # not 2^k

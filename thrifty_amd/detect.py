@@ -1,0 +1,297 @@
+"""Detect positioning signals and estimate sample-of-arrival -- on an MI355X.
+
+Drop-in for the reference's operator API (thrifty/detect.py): same
+`DetectorSettings` tuple, same `Detector(settings, blocks=None, rxid=-1,
+yield_data=False)` constructor, `.detect()` / iterator protocol, result types and
+`.toad` text, same `detector_cli` factory hook.  The per-block work
+(carrier_sync.py + soa_estimator.py in the reference) runs in the HIP engine
+behind include/thrifty_hip.h; this module only batches blocks, calls the C ABI
+and re-hydrates records in input order.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import argparse
+import sys
+from collections import deque, namedtuple
+from types import SimpleNamespace
+
+import numpy as np
+
+from thrifty_amd import _native, toads_data, util
+from thrifty_amd.block_data import block_reader, card_reader
+from thrifty_amd.setting_parsers import normalize_freq_range
+from thrifty_amd.settings import load_args
+
+DetectorSettings = namedtuple("DetectorSettings", [
+    "block_len", "history_len", "carrier_len", "carrier_thresh", "carrier_window",
+    "template", "corr_thresh"])
+
+
+def unique_window(block_len, history_len, template_len):
+    """Half-open range of correlation lags owned by one block (reference
+    soa_estimator.py:20-39)."""
+    assert history_len >= template_len - 1
+    corr_len = block_len - template_len + 1
+    pad = history_len - template_len + 1
+    return pad // 2, corr_len - (pad - pad // 2)
+
+
+class Detector(object):
+    """All-in-one carrier sync + matched filter + SoA estimator, batched on the GPU.
+
+    Parameters are the reference's (detect.py:40); `batch_size` and `device_id`
+    are additions: up to `batch_size` blocks are pulled from `blocks` and
+    processed per launch, results are handed out one per input block, in order.
+    """
+
+    def __init__(self, settings, blocks=None, rxid=-1, yield_data=False, batch_size=256,
+                 device_id=0):
+        self.settings = settings
+        self.blocks = iter(blocks) if blocks is not None else None
+        self.rxid = rxid
+        self.yield_data = yield_data
+        self.batch_size = max(1, int(batch_size))
+        self.new_len = settings.block_len - settings.history_len
+        template = np.asarray(settings.template)
+        if template.ndim != 1:
+            raise ValueError("Detector takes one 1-D template (see MultiTemplateDetector)")
+        self._engine = _native.Engine(
+            settings.block_len, settings.history_len, template, settings.carrier_thresh,
+            settings.carrier_window, settings.corr_thresh, carrier_len=settings.carrier_len,
+            device_id=device_id, max_batch=self.batch_size)
+        self._ready = deque()
+        self._exhausted = False
+        corr_len = settings.block_len - len(template) + 1
+        # descriptive twins of the reference's sub-objects (read-only facts)
+        self.sync = SimpleNamespace(thresh_coeffs=settings.carrier_thresh,
+                                    window=settings.carrier_window, weights=None)
+        self.soa_estimate = SimpleNamespace(
+            template=template, template_energy=float(np.sum(np.abs(template) ** 2)),
+            corr_len=corr_len, thresh_coeffs=settings.corr_thresh,
+            window=unique_window(settings.block_len, settings.history_len, len(template)))
+
+    # ------------------------------------------------------------------ core
+    def _stack(self, blocks):
+        """-> (array, is_u8).  u8 fast path only if every block still has its raw bytes."""
+        n = self.settings.block_len
+        raws = [getattr(b, "raw", None) if not (isinstance(b, np.ndarray) and b.dtype == np.uint8)
+                else b for b in blocks]
+        if all(r is not None and len(r) == 2 * n for r in raws):
+            return np.stack([np.asarray(r, dtype=np.uint8) for r in raws])
+        for b in blocks:
+            assert len(b) == n
+        return np.stack([np.asarray(b).astype(np.complex64) for b in blocks])
+
+    def _result(self, timestamp, block_idx, rec):
+        flags = int(rec["flags"])
+        if flags & _native.FLAG_INDEX_ERROR:
+            n = self.settings.block_len
+            # the reference indexes fft_mag[peak_idx + 3] without wrapping (carrier_sync.py:187)
+            raise IndexError("index {} is out of bounds for axis 0 with size {}".format(
+                max(int(rec["carrier_bin"]) + 3, n), n))
+        has_carrier = bool(flags & _native.FLAG_CARRIER)
+        carrier = toads_data.CarrierSyncInfo(
+            int(rec["carrier_bin"]), float(rec["carrier_offset"]) if has_carrier else 0,
+            np.float32(rec["carrier_energy"]), np.float32(rec["carrier_noise"]))
+        if not has_carrier:
+            return False, toads_data.DetectionResult(timestamp, block_idx, None, carrier, None,
+                                                     self.rxid)
+        detected = bool(flags & _native.FLAG_CORR)
+        corr = toads_data.CorrDetectionInfo(
+            int(rec["corr_sample"]), float(rec["corr_offset"]) if detected else 0,
+            float(rec["corr_energy"]), float(rec["corr_noise"]))
+        soa = self.new_len * block_idx + corr.sample + corr.offset
+        return detected, toads_data.DetectionResult(timestamp, block_idx, soa, carrier, corr,
+                                                    self.rxid)
+
+    def detect_batch(self, items):
+        """[(timestamp, block_idx, block), ...] -> [(detected, DetectionResult), ...]."""
+        if not items:
+            return []
+        arr = self._stack([it[2] for it in items])
+        idx = np.array([int(it[1]) for it in items], dtype=np.int64)
+        recs = self._engine.detect(arr, idx)[:, 0]
+        return [self._result(it[0], int(it[1]), recs[i]) for i, it in enumerate(items)]
+
+    def detect(self, timestamp, block_idx, block):
+        """Process one block (reference detect.py:60-78)."""
+        assert len(block) == self.settings.block_len or (
+            getattr(block, "dtype", None) == np.uint8 and len(block) == 2 * self.settings.block_len)
+        detected, result = self.detect_batch([(timestamp, block_idx, block)])[0]
+        if not self.yield_data:
+            return detected, result
+        shifted_fft = corr = None
+        if result.corr_info is not None:
+            xhat, cc = self._engine.debug_stage(self._stack([block]))
+            shifted_fft, corr = xhat[0], cc[0][:self.soa_estimate.corr_len]
+        return detected, result, shifted_fft, corr
+
+    # -------------------------------------------------------------- iterator
+    def _refill(self):
+        items = []
+        while len(items) < self.batch_size and not self._exhausted:
+            try:
+                items.append(next(self.blocks))
+            except StopIteration:
+                self._exhausted = True
+        if self.yield_data:
+            self._ready.extend(self.detect(*it) for it in items)
+        else:
+            self._ready.extend(self.detect_batch(items))
+
+    def next(self):
+        """Result for the next block of the `blocks` iterator."""
+        if not self._ready:
+            if self.blocks is None:
+                raise TypeError("Detector was constructed without a block source")
+            self._refill()
+        if not self._ready:
+            raise StopIteration
+        return self._ready.popleft()
+
+    def __call__(self, timestamp, block_idx, block):
+        self.detect(timestamp, block_idx, block)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        return self.next()
+
+
+class MultiTemplateDetector(object):
+    """Several TX templates correlated per block with ONE carrier stage / FFT#2
+    (BASELINE config "multi-template detect").  Yields, per input block, a list of
+    (detected, DetectionResult) -- one per template, `txid` set to the template index."""
+
+    def __init__(self, settings, blocks=None, rxid=-1, batch_size=256, device_id=0):
+        templates = np.asarray(settings.template)
+        if templates.ndim != 2:
+            raise ValueError("settings.template must be [n_templates, template_len]")
+        self.settings = settings
+        self.blocks = iter(blocks) if blocks is not None else None
+        self.rxid = rxid
+        self.batch_size = max(1, int(batch_size))
+        self.new_len = settings.block_len - settings.history_len
+        self._engine = _native.Engine(
+            settings.block_len, settings.history_len, templates, settings.carrier_thresh,
+            settings.carrier_window, settings.corr_thresh, carrier_len=settings.carrier_len,
+            device_id=device_id, max_batch=self.batch_size)
+        self._single = Detector.__new__(Detector)  # reuse record re-hydration
+        self._single.settings, self._single.rxid, self._single.new_len = settings, rxid, self.new_len
+        self._ready = deque()
+
+    def detect_batch(self, items):
+        if not items:
+            return []
+        arr = Detector._stack(self._single, [it[2] for it in items])
+        idx = np.array([int(it[1]) for it in items], dtype=np.int64)
+        recs = self._engine.detect(arr, idx)
+        out = []
+        for i, it in enumerate(items):
+            per_tx = []
+            for t in range(recs.shape[1]):
+                det, res = Detector._result(self._single, it[0], int(it[1]), recs[i, t])
+                res.txid = t
+                per_tx.append((det, res))
+            out.append(per_tx)
+        return out
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if not self._ready:
+            items = []
+            for it in self.blocks:
+                items.append(it)
+                if len(items) >= self.batch_size:
+                    break
+            self._ready.extend(self.detect_batch(items))
+        if not self._ready:
+            raise StopIteration
+        return self._ready.popleft()
+
+
+def _carrier_freq(carrier_info, block_len, sample_rate):
+    bin_freq = sample_rate / block_len
+    return (util.fft_bin(carrier_info.bin, block_len) + carrier_info.offset) * bin_freq
+
+
+class SummaryLineFormatter(object):
+    """One human-readable line per block (reference detect.py:103-158)."""
+
+    def __init__(self, sample_rate, block_len, add_dt=False):
+        self.sample_rate = sample_rate
+        self.block_len = block_len
+        self.add_dt = add_dt
+
+    def __call__(self, detected, result):
+        car = result.carrier_info
+        has_carrier = result.corr_info is not None
+        text = ("blk={blk}; carrier: {det} @ {freq:.3f} kHz / {idx:>3.0f}:{offset:+.2f}, "
+                "SNR = {ampl:>4.0f} / {noise:>2.0f} = {snr:>5.2f} dB").format(
+            blk=result.block, det="yes" if has_carrier else "no ",
+            freq=_carrier_freq(car, self.block_len, self.sample_rate) / 1e3, idx=car.bin,
+            offset=car.offset, ampl=car.energy, noise=car.noise,
+            snr=util.snr(car.energy, car.noise))
+        if has_carrier:
+            cor = result.corr_info
+            text += ("; corr: {det} @ {idx:>4}{offset:+.3f}{dt}, "
+                     "SNR = {ampl:>4.0f}/{noise:>2.0f} = {snr:>5.2f} dB").format(
+                det="yes" if detected else "no ", idx=cor.sample, offset=cor.offset, dt="",
+                ampl=cor.energy, noise=cor.noise, snr=util.snr(cor.energy, cor.noise))
+        return text
+
+
+def detector_cli(detector_class, parser=None, extra_args=None, argv=None):
+    """`thrifty detect` front end (reference detect.py:161-223): same arguments and
+    settings keys; `detector_class(settings, blocks, rxid=..., **kwargs)` must iterate
+    to `(detected, result)` pairs."""
+    if parser is None:
+        parser = argparse.ArgumentParser(description=__doc__,
+                                         formatter_class=argparse.RawDescriptionHelpFormatter)
+    parser.add_argument("input", type=argparse.FileType("rb"), default="-",
+                        help="input data ('-' streams from stdin)")
+    parser.add_argument("--raw", dest="raw", action="store_true", help="input data is raw binary data")
+    parser.add_argument("--quiet", dest="quiet", action="store_true",
+                        help="do not write anything to standard output")
+    group = parser.add_mutually_exclusive_group()
+    group.add_argument("-o", "--output", dest="output", type=argparse.FileType("w"),
+                       help="Output file (.toad) ('-' for stdout)")
+    group.add_argument("-a", "--append", dest="append", type=argparse.FileType("a"),
+                       help="Output file to append to (.toad)")
+    keys = ["sample_rate", "block_size", "block_history", "carrier_window", "carrier_threshold",
+            "corr_threshold", "template", "rxid"]
+    config, args = load_args(parser, keys, argv=argv)
+    kwargs = {a: args[a] for a in extra_args} if extra_args is not None else {}
+
+    output_file = args.output if args.append is None else args.append
+    info_out = sys.stderr if output_file is sys.stdout else sys.stdout
+    window = normalize_freq_range(config.carrier_window, config.sample_rate / config.block_size)
+    if args.raw:
+        blocks = block_reader(args.input, config.block_size, config.block_history)
+    else:
+        blocks = card_reader(args.input)
+    template = np.load(config.template)
+    settings = DetectorSettings(block_len=config.block_size, history_len=config.block_history,
+                                carrier_len=len(template), carrier_thresh=config.carrier_threshold,
+                                carrier_window=window, template=template,
+                                corr_thresh=config.corr_threshold)
+    detections = detector_class(settings, blocks, rxid=config.rxid, **kwargs)
+    summary = SummaryLineFormatter(config.sample_rate, config.block_size, add_dt=True)
+    for detected, result in detections:
+        if detected and output_file is not None:
+            print(result.serialize(), file=output_file)
+        if not args.quiet:
+            print(summary(detected, result), file=info_out)
+    if output_file is not None:
+        output_file.flush()
+
+
+def _main():
+    detector_cli(Detector)
+
+
+if __name__ == "__main__":
+    _main()

@@ -1,0 +1,148 @@
+"""Detector settings: `key: value` config file + argparse overrides.
+
+Python-3 counterpart of the part of reference thrifty/settings.py the detect
+path uses (DEFINITIONS 23-109, load 170-231, load_args 234-306,
+parse_kvconfig 309-321): same keys, flags, defaults and error types.
+"""
+from __future__ import annotations
+
+import logging
+from collections import namedtuple
+
+from thrifty_amd import setting_parsers as sp
+
+Definition = namedtuple("SettingDefinition", "args parser default description")
+
+DEFINITIONS = {
+    "sample_rate": Definition(["--sample-rate", "-s"], sp.metric_float, "2.4M", "Sample rate (sps)"),
+    "chip_rate": Definition(["--chip-rate", "-p"], sp.metric_float, "0.999707M",
+                            "Rate at which the code is being transmitted (bps)"),
+    "tuner_freq": Definition(["--freq", "-f"], sp.metric_float, "433.83M", "Tuner center frequency (Hz)"),
+    "tuner_gain": Definition(["--gain", "-g"], float, "0", "Tuner gain (dB)"),
+    "capture_skip": Definition(["--skip", "-k"], int, "1",
+                               "Number of blocks to skip before starting capturing from the SDR"),
+    "block_size": Definition(["--block-size", "-b"], int, "16384",
+                             "Length of fixed-sized blocks, which should be a power of two (samples)"),
+    "block_history": Definition(["--history", "-y"], int, "4920",
+                                "The number of samples at the end of a block that should be repeated "
+                                "at the start of the next block (samples)"),
+    "carrier_window": Definition(["--carrier-window", "-w"], sp.freq_range, "0--1",
+                                 "Range of frequencies or frequency bins to look for carrier"),
+    "carrier_threshold": Definition(["--carrier-threshold", "-t"], sp.threshold, "15*snr",
+                                    "Threshold formula for carrier detector"),
+    "corr_threshold": Definition(["--corr-threshold", "-u"], sp.threshold, "15*snr",
+                                 "Threshold formula for correlation peak detector"),
+    "template": Definition(["--template", "-z"], str, "template.npy",
+                           "Load template from a Numpy .npy file"),
+    "rxid": Definition(["--rxid", "-r"], int, -1, "Unique identifier of this receiver"),
+}
+
+DEFAULT_CONFIG_PATH = "detector.cfg"
+CONFIG_COMMENT_CHAR = "#"
+CONFIG_DELIMITER = ":"
+CONFIG_DEST = "config"
+
+
+class Error(Exception):
+    """Base class for settings errors."""
+
+
+class ConfigSyntaxError(Error):
+    def __init__(self, line_no, msg):
+        Error.__init__(self)
+        self.line_no, self.msg = line_no, msg
+
+    def __str__(self):
+        return "line #%d: %s" % (self.line_no, self.msg)
+
+
+class SettingKeyError(Error):
+    def __init__(self, msg):
+        Error.__init__(self)
+        self.msg = msg
+
+    def __str__(self):
+        return repr(self.msg)
+
+
+class Namespace(dict):
+    """dict whose items are also attributes."""
+
+    def __init__(self, mapping):
+        dict.__init__(self, mapping)
+        self.__dict__.update(mapping)
+
+
+def parse_kvconfig(config_file):
+    out = {}
+    for line_no, line in enumerate(config_file, 1):
+        if isinstance(line, bytes):
+            line = line.decode()
+        line = line.split(CONFIG_COMMENT_CHAR, 1)[0]
+        if not line.strip():
+            continue
+        if CONFIG_DELIMITER not in line:
+            raise ConfigSyntaxError(line_no, "No delimiter found")
+        key, value = line.split(CONFIG_DELIMITER, 1)
+        out[key.strip()] = value.strip()
+    return out
+
+
+def add_argparse_arguments(parser, keys, definitions=None):
+    definitions = DEFINITIONS if definitions is None else definitions
+    for key in keys:
+        if key not in definitions:
+            raise SettingKeyError("Unknown key: {}".format(key))
+        d = definitions[key]
+        if d.args:
+            text = str(d.description)
+            if d.default is not None:
+                text += " [default: {}]".format(d.default)
+            parser.add_argument(*d.args, dest=key, type=str, help=text)
+
+
+def load(args=None, config_file=None, definitions=None):
+    """defaults <- config file <- explicit args; every value parsed by its definition."""
+    definitions = DEFINITIONS if definitions is None else definitions
+    strings = {k: d.default for k, d in definitions.items() if d.default is not None}
+    for source, what in ((parse_kvconfig(config_file) if config_file is not None else None, "setting"),
+                         (args, "setting")):
+        if source is None:
+            continue
+        for key in source:
+            if key not in definitions:
+                raise SettingKeyError("Unknown {}: {}".format(what, key))
+        strings.update(source)
+    return {k: (definitions[k].parser(v) if isinstance(v, str) else v) for k, v in strings.items()}
+
+
+def load_args(parser, keys, argv=None, definitions=None):
+    """Add -v/-c and the settings' own flags to `parser`, parse, load the config
+    (explicit -c, else ./detector.cfg if present), return (settings, extra_args)."""
+    definitions = DEFINITIONS if definitions is None else definitions
+    parser.add_argument("-v", "--verbose", help="Increase output verbosity", action="store_true")
+    parser.add_argument("-c", "--config", dest=CONFIG_DEST, type=str, default=None,
+                        help="Config file to load settings from [default: {}]".format(DEFAULT_CONFIG_PATH))
+    add_argparse_arguments(parser, keys, definitions=definitions)
+    args = vars(parser.parse_args(argv))
+    if args["verbose"]:
+        logging.basicConfig(level=logging.DEBUG)
+    config_file = None
+    path = args.pop(CONFIG_DEST)
+    if path is None:
+        try:
+            config_file = open(DEFAULT_CONFIG_PATH)
+            logging.info("Loaded default config file from %s", DEFAULT_CONFIG_PATH)
+        except IOError:
+            logging.warning("No config file found. Using default values.")
+    else:
+        config_file = open(path)
+        logging.info("Loaded config file from %s", path)
+    try:
+        chosen = {k: v for k, v in args.items() if k in keys and v is not None}
+        values = load(chosen, config_file, definitions)
+    finally:
+        if config_file is not None:
+            config_file.close()
+    return (Namespace({k: v for k, v in values.items() if k in keys}),
+            Namespace({k: v for k, v in args.items() if k not in keys}))

@@ -1,0 +1,106 @@
+"""Detection records and the .toad text format.
+
+Mirrors the reference's data model (thrifty/toads_data.py:8-90): field names and
+order of `CarrierSyncInfo` / `CorrDetectionInfo` / `DetectionResult` are API, and
+`serialize()` produces the same whitespace-separated line
+(`[rxid] [txid] t block soa sample offset energy noise cbin coffset cenergy cnoise`,
+floats printed with Python's shortest repr except t (%.6f) and soa (%.8f)).
+"""
+from __future__ import annotations
+
+from collections import namedtuple
+
+import numpy as np
+
+CarrierSyncInfo = namedtuple("CarrierSyncInfo", ["bin", "offset", "energy", "noise"])
+CorrDetectionInfo = namedtuple("CorrDetectionInfo", ["sample", "offset", "energy", "noise"])
+
+_LINE = "{t:.6f} {b} {s:.8f} {ps} {po} {pe} {pn} {cb} {co} {ce} {cn}"
+
+
+class DetectionResult(object):
+    """One block's verdict: timestamp, block index, SoA and both info tuples."""
+
+    __slots__ = ("timestamp", "block", "soa", "carrier_info", "corr_info", "rxid", "txid")
+
+    def __init__(self, timestamp, block, soa, carrier_info, corr_info, rxid=None, txid=None):
+        self.timestamp = timestamp
+        self.block = block
+        self.soa = soa
+        self.carrier_info = carrier_info
+        self.corr_info = corr_info
+        self.rxid = rxid
+        self.txid = txid
+
+    def serialize(self):
+        cor, car = self.corr_info, self.carrier_info
+        text = _LINE.format(t=self.timestamp, b=self.block, s=self.soa,
+                            ps=cor.sample, po=cor.offset, pe=cor.energy, pn=cor.noise,
+                            cb=car.bin, co=car.offset, ce=car.energy, cn=car.noise)
+        ids = [str(v) for v in (self.rxid, self.txid) if v is not None]
+        return " ".join(ids + [text])
+
+    @classmethod
+    def deserialize(cls, string, with_rxid=False, with_txid=False):
+        parts = string.split()
+        if len(parts) < 11 + bool(with_rxid) + bool(with_txid):
+            return None
+        rxid = int(parts.pop(0)) if with_rxid else None
+        txid = int(parts.pop(0)) if with_txid else None
+        t, b, s, ps, po, pe, pn, cb, co, ce, cn = (float(p) for p in parts[:11])
+        return cls(timestamp=t, block=int(b), soa=s,
+                   carrier_info=CarrierSyncInfo(int(cb), co, ce, cn),
+                   corr_info=CorrDetectionInfo(int(ps), po, pe, pn), rxid=rxid, txid=txid)
+
+    def __repr__(self):
+        return "DetectionResult(block=%r, soa=%r, carrier=%r, corr=%r)" % (
+            self.block, self.soa, self.carrier_info, self.corr_info)
+
+
+def _read(stream, with_rxid, with_txid):
+    own = isinstance(stream, str)
+    if own:
+        stream = open(stream, "r")
+    try:
+        out = []
+        for lineno, line in enumerate(stream, 1):
+            if isinstance(line, bytes):
+                line = line.decode()
+            if not line or line[0] == "#":
+                continue
+            rec = DetectionResult.deserialize(line, with_rxid=with_rxid, with_txid=with_txid)
+            if rec is None:
+                print("WARNING: skipped line #{}: line's formatting is invalid".format(lineno))
+                continue
+            out.append(rec)
+        return out
+    finally:
+        if own:
+            stream.close()
+
+
+def load_toad(stream):
+    """Single receiver's detections (.toad: rxid, no txid)."""
+    return _read(stream, True, False)
+
+
+def load_toads(stream):
+    """Merged detections (.toads: rxid and txid)."""
+    return _read(stream, True, True)
+
+
+TOADS_DTYPE = [("idx", "i4"), ("rxid", "i4"), ("txid", "i4"), ("timestamp", "f8"),
+               ("block", "i4"), ("soa", "f8"), ("sample", "i4"), ("offset", "f8"),
+               ("energy", "f8"), ("noise", "f8"), ("carrier_bin", "i4"),
+               ("carrier_offset", "f8"), ("carrier_energy", "f8"), ("carrier_noise", "f8")]
+
+
+def toads_array(detections, with_ids=True):
+    def _id(v):
+        return -1 if (v is None or not with_ids) else v
+
+    rows = [(i, _id(d.rxid), _id(d.txid), d.timestamp, d.block,
+             d.soa, d.corr_info.sample, d.corr_info.offset, d.corr_info.energy,
+             d.corr_info.noise, d.carrier_info.bin, d.carrier_info.offset,
+             d.carrier_info.energy, d.carrier_info.noise) for i, d in enumerate(detections)]
+    return np.array(rows, dtype=TOADS_DTYPE)
