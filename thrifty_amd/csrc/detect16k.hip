@@ -72,29 +72,38 @@ __device__ __forceinline__ unsigned long long wave_max(unsigned long long v) {
     return v;
 }
 
-// scratch must hold >= 8 doubles; all 512 threads call; result valid in all threads
-__device__ __forceinline__ double block_sum(double v, double* scratch) {
-    v = wave_sum(v);
+// Combined block reduction: NS float sums (returned as double) + one u64 max,
+// ONE barrier.  `scratch` is double-buffered by `parity` (flip it on every call)
+// so a fast wave's next reduction cannot overwrite slots a slow wave still reads.
+constexpr int RED_SLOT_BYTES = 256;  // per parity: 8 waves x 3 doubles + 8 x u64
+template <int NS>
+__device__ __forceinline__ void block_reduce(float (&s)[NS], double (&out)[NS],
+                                             unsigned long long& m, unsigned char* scratch,
+                                             int parity) {
+    static_assert(NS <= 3, "scratch layout holds 3 sums");
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) scratch[wv] = v;
-    __syncthreads();
-    double t = 0;
+    double* sd = reinterpret_cast<double*>(scratch + parity * RED_SLOT_BYTES);
+    unsigned long long* su = reinterpret_cast<unsigned long long*>(sd + 24);
 #pragma unroll
-    for (int i = 0; i < NT / 64; ++i) t += scratch[i];
-    return t;
-}
-__device__ __forceinline__ unsigned long long block_max(unsigned long long v,
-                                                         unsigned long long* scratch) {
-    v = wave_max(v);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int i = 0; i < NS; ++i) s[i] = wave_sum(s[i]);
+    m = wave_max(m);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) sd[wv * 3 + i] = (double)s[i];
+        su[wv] = m;
+    }
     __syncthreads();
-    if (lane == 0) scratch[wv] = v;
-    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        double t = 0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) t += sd[w * 3 + i];
+        out[i] = t;
+    }
     unsigned long long t = 0;
 #pragma unroll
-    for (int i = 0; i < NT / 64; ++i) t = scratch[i] > t ? scratch[i] : t;
-    return t;
+    for (int w = 0; w < NT / 64; ++w) t = su[w] > t ? su[w] : t;
+    m = t;
 }
 
 // ---------------------------------------------------------------- LDS tables
@@ -274,33 +283,34 @@ __global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples
                                                 cpx* __restrict__ dump_fft) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cpx* lds = reinterpret_cast<cpx*>(smem_raw);
-    double* sc_d = reinterpret_cast<double*>(lds + OFF_S);
-    unsigned long long* sc_u = reinterpret_cast<unsigned long long*>(lds + OFF_S + 16);
-    float* sc_nb = reinterpret_cast<float*>(lds + OFF_S + 32);
+    unsigned char* sc_red = reinterpret_cast<unsigned char*>(lds + OFF_S);
 
     load_tables(lds, tables);
+    __syncthreads();
     const size_t blk_bytes = size_t(N) * (FMT == THR_IN_U8 ? 2 : 8);
+    int parity = 0;
 
     for (int b = blockIdx.x; b < n_blocks; b += gridDim.x) {
         const void* blk = static_cast<const unsigned char*>(samples) + size_t(b) * blk_bytes;
-        __syncthreads();  // tables ready / previous block's LDS reads done
+        // (previous block's pass-3 LDS reads all precede its reduction barrier)
         fwd_pass1<FMT, false>(lds, blk, nullptr, cpx{}, cpx{});
         __syncthreads();
+        // passes 2 and 3 of row k1 are done by the same half-wave: no barrier between them
         fwd_pass2(lds);
-        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);  // keep the passes' register working sets apart
         cpx v[R3];
         fwd_pass3(lds, v);
 
         // ---- statistics over the spectrum held in registers
         const int t = opaque_tid();
         const int kbase = (t >> 5) + 16 * (t & 31);
-        float s2 = 0.f, s1 = 0.f;
+        float sums[2] = {0.f, 0.f};
         unsigned long long best = 0;
         static_for<R3>([&](auto K) {
             constexpr int k3 = decltype(K)::value;
             const float p = cnorm(v[brev(k3, R3)]);
-            s2 += p;
-            if constexpr (WANT_STD) s1 += __builtin_amdgcn_sqrtf(p);
+            sums[0] += p;
+            if constexpr (WANT_STD) sums[1] += __builtin_amdgcn_sqrtf(p);
             const unsigned wi = unsigned(kbase + 512 * k3 - cfg.win_lo) & unsigned(N - 1);
             if (wi < unsigned(cfg.win_count)) {
                 const unsigned long long key =
@@ -308,19 +318,22 @@ __global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples
                 best = key > best ? key : best;
             }
         });
-        const double tot2 = block_sum((double)s2, sc_d);
-        double tot1 = 0.0;
-        if constexpr (WANT_STD) tot1 = block_sum((double)s1, sc_d);
-        best = block_max(best, sc_u);
+        double tot[2];
+        block_reduce<WANT_STD ? 2 : 1>(reinterpret_cast<float(&)[WANT_STD ? 2 : 1]>(sums),
+                                       reinterpret_cast<double(&)[WANT_STD ? 2 : 1]>(tot), best,
+                                       sc_red, parity);
+        parity ^= 1;
         const unsigned wi = 0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu);
         int peak_idx = int(wi) + cfg.win_lo;
         if (peak_idx > N) peak_idx -= N;  // sic: '>' (carrier_detect.py:151)
-        // 7-bin neighbourhood around the peak (indices wrap here; K_fit flags
-        // the cases where the reference would raise IndexError instead)
+        // 7-bin neighbourhood around the peak, written straight to the stats record by
+        // whichever threads hold those bins (indices wrap here; K_fit flags the cases
+        // where the reference would raise IndexError instead)
+        CarStats* st = stats + b;
         static_for<R3>([&](auto K) {
             constexpr int k3 = decltype(K)::value;
             const unsigned d = unsigned(kbase + 512 * k3 - peak_idx + 3) & unsigned(N - 1);
-            if (d < 7u) sc_nb[d] = cnorm(v[brev(k3, R3)]);
+            if (d < 7u) st->nb[d] = sqrtf(cnorm(v[brev(k3, R3)]));
         });
         if constexpr (DUMP) {
             cpx* out = dump_fft + size_t(b) * N;
@@ -329,23 +342,18 @@ __global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples
                 out[kbase + 512 * k3] = v[brev(k3, R3)];
             });
         }
-        __syncthreads();
         if (t == 0) {
-            CarStats st;
-            st.sum_mag2 = (float)tot2;
-            st.sum_mag = (float)tot1;
-            st.peak_mag = sqrtf(__uint_as_float(unsigned(best >> 32)));
-            st.peak_idx = peak_idx;
-#pragma unroll
-            for (int j = 0; j < 7; ++j) st.nb[j] = sqrtf(sc_nb[j]);
-            st.pad = 0;
-            stats[b] = st;
+            st->sum_mag2 = (float)tot[0];
+            st->sum_mag = WANT_STD ? (float)tot[1] : 0.f;
+            st->peak_mag = sqrtf(__uint_as_float(unsigned(best >> 32)));
+            st->peak_idx = peak_idx;
+            st->pad = 0;
         }
     }
 }
 
 // =========================================================================
-// K_fit: one lane per block
+// K_fit: 8 lanes per block (one per fitted point, lane 7 idles in the sums)
 // =========================================================================
 __device__ __forceinline__ void dirichlet_eval(double u, double n, double w, double& d,
                                                double& dd) {
@@ -363,38 +371,43 @@ __device__ __forceinline__ void dirichlet_eval(double u, double n, double w, dou
     dd = (pi * w / n * cw * s1 - sw * pi / n * c1) / (w * s1 * s1);
 }
 
-__device__ inline double dirichlet_fit(const float* y, double n, double w, int* iters) {
-    // Levenberg-Marquardt on f_j(A, o) = A * |D(x_j - o)|, x_j = j - 3, from
-    // p0 = (y[3], 0) -- same model/start as carrier_sync.py:179-194.
-    double A = y[3], o = 0.0;
-    double lambda = 1e-3;
+// Sum over the 8-lane group, bitwise identical in all 8 lanes.  The xor butterfly alone
+// is NOT enough: with HIP's default -ffp-contract=fast the caller's `x*x` gets fused
+// into the first add as fma(x, x, partner) on one side and fma(y, y, ...) on the other,
+// partner lanes then differ by an ulp, and an accept/reject decision in the LM loop
+// eventually flips in some lanes only.  So: contraction off here, and every lane takes
+// the group leader's value.
+__device__ __forceinline__ double group8_sum(double v) {
+#pragma clang fp contract(off)
+    v = v + __shfl_xor(v, 1, 64);
+    v = v + __shfl_xor(v, 2, 64);
+    v = v + __shfl_xor(v, 4, 64);
+    return __shfl(v, (threadIdx.x & 63) & ~7, 64);
+}
+
+// Levenberg-Marquardt on f_j(A, o) = A * |D(x_j - o)|, x_j = j - 3, from
+// p0 = (y[3], 0) -- same model and start as carrier_sync.py:179-194.  Lane j of
+// the 8-lane group owns point j; every lane follows the same control flow.
+__device__ inline double dirichlet_fit8(float yj, float y_peak, int j, double n, double w) {
+    const bool live = j < 7;
+    const double y = live ? (double)yj : 0.0;
+    const double x = double(j - 3);
+    double A = y_peak, o = 0.0, lambda = 1e-3;
     auto cost_of = [&](double a, double off) {
-        double c = 0;
-        for (int j = 0; j < 7; ++j) {
-            double d, dd;
-            dirichlet_eval(double(j - 3) - off, n, w, d, dd);
-            const double r = double(y[j]) - a * fabs(d);
-            c += r * r;
-        }
-        return c;
+        double d, dd;
+        dirichlet_eval(x - off, n, w, d, dd);
+        const double r = live ? y - a * fabs(d) : 0.0;
+        return group8_sum(r * r);
     };
     double cost = cost_of(A, o);
-    int it = 0;
-    for (; it < 60; ++it) {
-        double jaa = 0, jao = 0, joo = 0, ga = 0, go = 0;
-        for (int j = 0; j < 7; ++j) {
-            double d, dd;
-            dirichlet_eval(double(j - 3) - o, n, w, d, dd);
-            const double sgn = d < 0 ? -1.0 : 1.0;
-            const double fa = fabs(d);            // df/dA
-            const double fo = -A * sgn * dd;      // df/do  (u = x - o)
-            const double r = double(y[j]) - A * fa;
-            jaa += fa * fa;
-            jao += fa * fo;
-            joo += fo * fo;
-            ga += fa * r;
-            go += fo * r;
-        }
+    for (int it = 0; it < 60; ++it) {
+        double d, dd;
+        dirichlet_eval(x - o, n, w, d, dd);
+        const double fa = live ? fabs(d) : 0.0;                       // df/dA
+        const double fo = live ? -A * (d < 0 ? -1.0 : 1.0) * dd : 0.0;  // df/do (u = x - o)
+        const double r = live ? y - A * fa : 0.0;
+        const double jaa = group8_sum(fa * fa), jao = group8_sum(fa * fo),
+                     joo = group8_sum(fo * fo), ga = group8_sum(fa * r), go = group8_sum(fo * r);
         bool accepted = false;
         double dA = 0, dO = 0;
         for (int tries = 0; tries < 12 && !accepted; ++tries) {
@@ -418,12 +431,8 @@ __device__ inline double dirichlet_fit(const float* y, double n, double w, int* 
             }
         }
         if (!accepted) break;
-        if (fabs(dO) < 1e-11 && fabs(dA) <= 1e-11 * fabs(A)) {
-            ++it;
-            break;
-        }
+        if (fabs(dO) < 1e-11 && fabs(dA) <= 1e-11 * fabs(A)) break;
     }
-    *iters = it;
     return o;
 }
 
@@ -434,76 +443,93 @@ __global__ __launch_bounds__(64) void k_fit(int n_blocks, DevCfg cfg,
                                             int* __restrict__ work_list,
                                             int* __restrict__ work_count,
                                             thr_record* __restrict__ records) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= n_blocks) return;
-    const CarStats st = stats[b];
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = gid & 7;
+    int b = gid >> 3;
+    const bool valid = b < n_blocks;
+    if (!valid) b = n_blocks - 1;  // keep the whole group in the shuffles
+    const CarStats* st = stats + b;
     const int n = cfg.block_len;
+    const float peak_mag = st->peak_mag, sum_mag2 = st->sum_mag2;
+    const int peak_idx = st->peak_idx;
     // float32 arithmetic on purpose: the reference's carrier statistics are
     // float32 under NumPy >= 2 (carrier_detect.py:99-115)
-    const float peak_pow = st.peak_mag * st.peak_mag;
-    const float noise_pow = (st.sum_mag2 - 2.0f * peak_pow) / float(n - 1);
+    const float peak_pow = peak_mag * peak_mag;
+    const float noise_pow = (sum_mag2 - 2.0f * peak_pow) / float(n - 1);
     const float noise_rms = sqrtf(noise_pow);
     float thr = cfg.car_thr[0] + cfg.car_thr[1] * (noise_rms * noise_rms);
     if (cfg.car_want_std) {
-        const double m1 = double(st.sum_mag) / n, m2 = double(st.sum_mag2) / n;
-        const float var = float(m2 - m1 * m1);
-        thr += cfg.car_thr[2] * var;
+        const double m1 = double(st->sum_mag) / n, m2 = double(sum_mag2) / n;
+        thr += cfg.car_thr[2] * float(m2 - m1 * m1);
     }
     thr = sqrtf(thr);
-    bool detected = st.peak_mag > thr;
+    bool detected = peak_mag > thr;
     unsigned flags = 0;
     double offset = 0.0;
-    if (detected && st.peak_idx + 3 >= n) {
+    if (detected && peak_idx + 3 >= n) {
         flags |= THR_FLAG_INDEX_ERROR;  // carrier_sync.py:187 raises here
         detected = false;
     }
+    // the fit is group-uniform only if `detected` is; it is (same inputs in all 8 lanes)
     if (detected) {
         flags |= THR_FLAG_CARRIER;
-        int iters;
-        offset = dirichlet_fit(st.nb, double(n), double(cfg.carrier_len), &iters);
-        // shift = -(bin + offset)  (carrier_sync.py:71)
-        const double s = -(double(st.peak_idx) + offset);
-        const double si = rint(s);
-        ShiftParams sp;
-        const int r1 = n / 1024;  // first-pass radix: phasor step between sub-sequences
-        for (int j = 0; j < 16; ++j) {
-            double a = s * double(j) / double(r1);
-            a -= rint(a);
-            double sn, cs;
-            sincospi(2.0 * a, &sn, &cs);
-            sp.rpow[j] = float2{float(cs), float(sn)};
-        }
+        offset = dirichlet_fit8(st->nb[j < 7 ? j : 6], st->nb[3], j, double(n),
+                                double(cfg.carrier_len));
+#ifdef THR_DEBUG_FIT
         {
-            double a = -0.5 * s;  // exp(2 pi i * s * (-1/2))
-            a -= rint(a);
-            double sn, cs;
-            sincospi(2.0 * a, &sn, &cs);
-            sp.c0 = float2{float(cs), float(sn)};
+            double lo = offset, hi = offset;
+            for (int m = 1; m < 8; m <<= 1) {
+                lo = fmin(lo, __shfl_xor(lo, m, 64));
+                hi = fmax(hi, __shfl_xor(hi, m, 64));
+            }
+            if (hi != lo && j == 0) printf("fit disagreement blk %d: lo %.17g hi %.17g\n", b, lo, hi);
         }
-        long long sim = (long long)si % n;
-        if (sim < 0) sim += n;
-        sp.si_mod = int(sim);
-        sp.sf_over_n = float((s - si) / double(n));
-        shifts[b] = sp;
-        const int slot = atomicAdd(work_count, 1);
-        work_list[slot] = b;
+#endif
+        // shift = -(bin + offset)  (carrier_sync.py:71)
+        const double s = -(double(peak_idx) + offset);
+        const double si = rint(s);
+        const int r1 = n / 1024;  // first-pass radix: phasor step between sub-sequences
+        ShiftParams* sp = shifts + b;
+        if (valid) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int jj = 2 * j + q;
+                double a = s * double(jj) / double(r1);
+                a -= rint(a);
+                double sn, cs;
+                sincospi(2.0 * a, &sn, &cs);
+                sp->rpow[jj] = float2{float(cs), float(sn)};
+            }
+            if (j == 0) {
+                double a = -0.5 * s;  // exp(2 pi i * s * (-1/2))
+                a -= rint(a);
+                double sn, cs;
+                sincospi(2.0 * a, &sn, &cs);
+                sp->c0 = float2{float(cs), float(sn)};
+                long long sim = (long long)si % n;
+                if (sim < 0) sim += n;
+                sp->si_mod = int(sim);
+                sp->sf_over_n = float((s - si) / double(n));
+                const int slot = atomicAdd(work_count, 1);
+                work_list[slot] = b;
+            }
+        }
     }
-    const long long bi = block_idx ? block_idx[b] : (long long)b;
-    for (int tpl = 0; tpl < cfg.n_templates; ++tpl) {
+    if (valid && j < cfg.n_templates) {
         thr_record r;
-        r.block_idx = bi;
+        r.block_idx = block_idx ? block_idx[b] : (long long)b;
         r.flags = flags;
-        r.template_id = tpl;
-        r.carrier_bin = st.peak_idx;
+        r.template_id = j;
+        r.carrier_bin = peak_idx;
         r.corr_sample = -1;
         r.carrier_offset = offset;
         r.corr_offset = 0.0;
-        r.carrier_energy = st.peak_mag;
+        r.carrier_energy = peak_mag;
         r.carrier_noise = noise_rms;
         r.corr_energy = 0.f;
         r.corr_noise = 0.f;
         r.reserved = 0;
-        records[size_t(b) * cfg.n_templates + tpl] = r;
+        records[size_t(b) * cfg.n_templates + j] = r;
     }
 }
 
@@ -522,13 +548,14 @@ __global__ __launch_bounds__(NT) void k_correlate(
     cpx* __restrict__ dump_corr, int dump_template) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cpx* lds = reinterpret_cast<cpx*>(smem_raw);
-    double* sc_d = reinterpret_cast<double*>(lds + OFF_S);
-    unsigned long long* sc_u = reinterpret_cast<unsigned long long*>(lds + OFF_S + 16);
-    float* sc_m = reinterpret_cast<float*>(lds + OFF_S + 32);
+    unsigned char* sc_red = reinterpret_cast<unsigned char*>(lds + OFF_S);
+    float* sc_m = reinterpret_cast<float*>(sc_red + 2 * RED_SLOT_BYTES);  // [2][4]
 
     load_tables(lds, tables);
+    __syncthreads();
     const size_t blk_bytes = size_t(N) * (FMT == THR_IN_U8 ? 2 : 8);
     const int n_work = *work_count;
+    int parity = 0;
 
     for (int wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
         const int b = work_list[wi];
@@ -547,11 +574,12 @@ __global__ __launch_bounds__(NT) void k_correlate(
             sincosf(6.283185307179586f * (sp->sf_over_n * float(m)), &sn, &cs);
             p[e] = cmul(cmul(wq, cpx{cs, sn}), sp->c0);
         }
-        __syncthreads();
+        // (the previous block's pass-C LDS reads all precede its reduction barrier)
         fwd_pass1<FMT, true>(lds, blk, sp->rpow, p[0], p[1]);
         __syncthreads();
+        // rows k1 = 2w, 2w+1 belong to wave w through passes 2, 3, A and B: no barriers
         fwd_pass2(lds);
-        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);  // keep the passes' register working sets apart
         cpx xh[R3];
         fwd_pass3(lds, xh);
 
@@ -559,15 +587,15 @@ __global__ __launch_bounds__(NT) void k_correlate(
         float e2 = 0.f;
 #pragma unroll
         for (int i = 0; i < R3; ++i) e2 += cnorm(xh[i]);
-        const double xenergy = block_sum((double)e2, sc_d) / double(N);  // mean |X|^2
+        asm volatile("" : "+v"(e2));  // pin here: else LLVM sinks the sum (and 64 live VGPRs) to its use
         if constexpr (DUMP) {
-          if (dump_xhat != nullptr) {
-            cpx* out = dump_xhat + size_t(b) * N;
-            static_for<R3>([&](auto K) {
-                constexpr int k3 = decltype(K)::value;
-                out[kbase + 512 * k3] = xh[brev(k3, R3)];
-            });
-          }
+            if (dump_xhat != nullptr) {
+                cpx* out = dump_xhat + size_t(b) * N;
+                static_for<R3>([&](auto K) {
+                    constexpr int k3 = decltype(K)::value;
+                    out[kbase + 512 * k3] = xh[brev(k3, R3)];
+                });
+            }
         }
         float4* park = nullptr;
         if constexpr (MULTI) {
@@ -601,9 +629,10 @@ __global__ __launch_bounds__(NT) void k_correlate(
                 z[brev(2 * j, R3)] = cmul(x0, cpx{q.x, q.y});
                 z[brev(2 * j + 1, R3)] = cmul(x1, cpx{q.z, q.w});
             });
-            __syncthreads();  // everyone done reading LDS from the previous pass
+            // pass A overwrites exactly the chunk this thread read in pass 3 (or, for
+            // tpl > 0, rows whose pass-C readers are behind the previous reduction barrier)
             inv_passA(lds, z);
-            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
             inv_passB(lds);
             __syncthreads();
             cpx c0[R1], c1[R1];
@@ -611,7 +640,7 @@ __global__ __launch_bounds__(NT) void k_correlate(
 
             // ---- |corr|^2, windowed first-max, optional std sums
             unsigned long long best = 0;
-            float s1 = 0.f, s2 = 0.f;
+            float sums[3] = {tpl == 0 ? e2 : 0.f, 0.f, 0.f};
             static_for<R1>([&](auto K) {
                 constexpr int n1 = decltype(K)::value;
 #pragma unroll
@@ -626,18 +655,18 @@ __global__ __launch_bounds__(NT) void k_correlate(
                     }
                     if constexpr (WANT_STD) {
                         if (n < cfg.corr_len) {
-                            s2 += pw;
-                            s1 += __builtin_amdgcn_sqrtf(pw);
+                            sums[2] += pw;
+                            sums[1] += __builtin_amdgcn_sqrtf(pw);
                         }
                     }
                 }
             });
-            best = block_max(best, sc_u);
-            double tot1 = 0, tot2 = 0;
-            if constexpr (WANT_STD) {
-                tot1 = block_sum((double)s1, sc_d);
-                tot2 = block_sum((double)s2, sc_d);
-            }
+            constexpr int NS = WANT_STD ? 3 : 1;
+            double tot[3] = {0, 0, 0};
+            block_reduce<NS>(reinterpret_cast<float(&)[NS]>(sums),
+                             reinterpret_cast<double(&)[NS]>(tot), best, sc_red, parity);
+            float* scm = sc_m + 4 * parity;
+            parity ^= 1;
             const int pk = int(0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu));
             static_for<R1>([&](auto K) {
                 constexpr int n1 = decltype(K)::value;
@@ -645,19 +674,29 @@ __global__ __launch_bounds__(NT) void k_correlate(
                 for (int e = 0; e < 2; ++e) {
                     const int n = n1 * S1 + 2 * t + e;
                     const unsigned d = unsigned(n - pk + 1);
-                    if (d < 3u) sc_m[d] = cnorm(e ? c1[brev(n1, R1)] : c0[brev(n1, R1)]);
+                    if (d < 3u) scm[d] = cnorm(e ? c1[brev(n1, R1)] : c0[brev(n1, R1)]);
                 }
             });
             if constexpr (DUMP) {
-              if (dump_corr != nullptr && tpl == dump_template) {
-                cpx* out = dump_corr + size_t(b) * N;
-                static_for<R1>([&](auto K) {
-                    constexpr int n1 = decltype(K)::value;
-                    reinterpret_cast<float4*>(out + n1 * S1)[t] =
-                        float4{c0[brev(n1, R1)].x, c0[brev(n1, R1)].y, c1[brev(n1, R1)].x,
-                               c1[brev(n1, R1)].y};
-                });
-              }
+                if (dump_corr != nullptr && tpl == dump_template) {
+                    cpx* out = dump_corr + size_t(b) * N;
+                    static_for<R1>([&](auto K) {
+                        constexpr int n1 = decltype(K)::value;
+                        reinterpret_cast<float4*>(out + n1 * S1)[t] =
+                            float4{c0[brev(n1, R1)].x, c0[brev(n1, R1)].y, c1[brev(n1, R1)].x,
+                                   c1[brev(n1, R1)].y};
+                    });
+                }
+            }
+            // mean |X|^2 of the shifted spectrum rides along with template 0's reduction
+            double xenergy = tot[0] / double(N);
+            if constexpr (MULTI) {
+                double* keep = reinterpret_cast<double*>(sc_m + 8);
+                if (tpl == 0) {
+                    if (t == 0) *keep = xenergy;
+                } else {
+                    xenergy = *keep;  // written by thread 0 before >= 1 barrier ago
+                }
             }
             __syncthreads();
             if (t == 0) {
@@ -669,7 +708,7 @@ __global__ __launch_bounds__(NT) void k_correlate(
                 const double noise_rms = sqrt(noise_pow);
                 double th = cfg.cor_thr[0] + cfg.cor_thr[1] * (noise_rms * noise_rms);
                 if constexpr (WANT_STD) {
-                    const double m1 = tot1 / cfg.corr_len, m2 = tot2 / cfg.corr_len;
+                    const double m1 = tot[1] / cfg.corr_len, m2 = tot[2] / cfg.corr_len;
                     th += cfg.cor_thr[2] * (m2 - m1 * m1);
                 }
                 th = sqrt(th);
@@ -677,8 +716,8 @@ __global__ __launch_bounds__(NT) void k_correlate(
                 double off = 0.0;
                 if (det && pk != 0 && pk != cfg.corr_len - 1) {
                     // log-parabola on magnitudes == same formula on log |.|^2
-                    const double la = log((double)sc_m[0]), lb = log((double)sc_m[1]),
-                                 lc = log((double)sc_m[2]);
+                    const double la = log((double)scm[0]), lb = log((double)scm[1]),
+                                 lc = log((double)scm[2]);
                     off = 0.5 * (lc - la) / (2 * lb - la - lc);
                     off = off < -0.6 ? -0.6 : off > 0.6 ? 0.6 : off;
                 }
@@ -734,6 +773,12 @@ typedef void (*correlate_fn)(const void*, DevCfg, const cpx*, const cpx*, const 
                              const ShiftParams*, const int*, const int*, thr_record*, float4*,
                              cpx*, cpx*, int);
 
+#ifdef THR_DEV_MINIMAL  // compile-time experiments only: one variant each, fast rebuilds
+carrier_fn carrier_variant(int, bool, bool) { return &k_carrier<THR_IN_U8, false, false>; }
+correlate_fn correlate_variant(int, bool, bool, bool) {
+    return &k_correlate<THR_IN_U8, false, false, false>;
+}
+#else
 template <int FMT, bool STD>
 carrier_fn pick_carrier(bool dump) {
     return dump ? &k_carrier<FMT, STD, true> : &k_carrier<FMT, STD, false>;
@@ -757,6 +802,7 @@ correlate_fn correlate_variant(int fmt, bool want_std, bool multi, bool dump) {
     return fmt == THR_IN_U8 ? pick_correlate2<THR_IN_U8>(want_std, multi, dump)
                             : pick_correlate2<THR_IN_C64>(want_std, multi, dump);
 }
+#endif
 }  // namespace
 
 hipError_t prepare_16k() {
@@ -790,8 +836,8 @@ hipError_t launch_carrier_16k(int fmt, const void* samples, int n_blocks, const 
 hipError_t launch_fit(int n_blocks, const DevCfg& cfg, const CarStats* stats,
                       const long long* block_idx, ShiftParams* shifts, int* work_list,
                       int* work_count, thr_record* records, hipStream_t stream) {
-    hipLaunchKernelGGL(k_fit, dim3((n_blocks + 63) / 64), dim3(64), 0, stream, n_blocks, cfg, stats,
-                       block_idx, shifts, work_list, work_count, records);
+    hipLaunchKernelGGL(k_fit, dim3((n_blocks * 8 + 63) / 64), dim3(64), 0, stream, n_blocks, cfg,
+                       stats, block_idx, shifts, work_list, work_count, records);
     return hipGetLastError();
 }
 
