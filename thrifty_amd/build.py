@@ -38,8 +38,10 @@ def build_native(force=False, verbose=False):
     objs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c",
-               os.path.join(CSRC, src), "-o", obj]
+        # -fno-slp-vectorize: the kernels are hand-vectorised with ext-vector float2;
+        # the SLP vectorizer only adds v_mov shuffles (see csrc/fft_regs.hpp)
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+               "-fno-slp-vectorize", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -5,6 +5,7 @@
 #include <complex>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -308,6 +309,7 @@ int thr_create(const thr_settings* s, thr_handle** out) {
             d.car_thr[i] = float(s->carrier_thresh[i]);
             d.cor_thr[i] = float(s->corr_thresh[i]);
         }
+        d.ablate = getenv("THR_ABLATE") ? atoi(getenv("THR_ABLATE")) : 0;
         d.car_want_std = s->carrier_thresh[2] != 0.0;
         d.cor_want_std = s->corr_thresh[2] != 0.0;
 

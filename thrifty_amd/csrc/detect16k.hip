@@ -109,42 +109,62 @@ __device__ __forceinline__ void block_reduce(float (&s)[NS], double (&out)[NS],
 // ---------------------------------------------------------------- LDS tables
 __device__ __forceinline__ void load_tables(cpx* lds, const cpx* __restrict__ tables) {
     // 2048 complex = 16 KiB: 512 threads x 2 x float4
-    const float4* src = reinterpret_cast<const float4*>(tables);
-    float4* dst = reinterpret_cast<float4*>(lds + OFF_C);
+    const f4* src = reinterpret_cast<const f4*>(tables);
+    f4* dst = reinterpret_cast<f4*>(lds + OFF_C);
     dst[threadIdx.x] = src[threadIdx.x];
     dst[threadIdx.x + NT] = src[threadIdx.x + NT];
 }
 
 // ---------------------------------------------------------------- sample load
-// Two adjacent samples m = 2t, 2t+1 of sub-sequence n1 (n = n1*1024 + m).
+// Per-thread raw samples of one block: for each sub-sequence n1 the two adjacent
+// samples m = 2t, 2t+1 (n = n1*1024 + m).  The u8 flavour holds them in 16 VGPRs so
+// the NEXT block's HBM loads can be in flight while the current block is computed;
+// the c64 flavour (64 VGPRs if held) just remembers the address and loads at use.
 template <int FMT>
-__device__ __forceinline__ void load_pair(const void* __restrict__ blk, int n1, int t, cpx& a,
-                                          cpx& b) {
-    if constexpr (FMT == THR_IN_U8) {
-        const uchar4 q = reinterpret_cast<const uchar4*>(blk)[n1 * (S1 / 2) + t];
-        constexpr float sc = 1.0f / 128.0f, of = -127.4f / 128.0f;  // == (v - 127.4f) / 128 exactly
-        a = cpx{fmaf((float)q.x, sc, of), fmaf((float)q.y, sc, of)};
-        b = cpx{fmaf((float)q.z, sc, of), fmaf((float)q.w, sc, of)};
-    } else {
-        const float4 q = reinterpret_cast<const float4*>(blk)[n1 * (S1 / 2) + t];
-        a = cpx{q.x, q.y};
-        b = cpx{q.z, q.w};
+struct RawSamples;
+
+template <>
+struct RawSamples<THR_IN_U8> {
+    unsigned q[R1];
+    __device__ __forceinline__ void load(const void* __restrict__ blk, int t) {
+        const unsigned* p = reinterpret_cast<const unsigned*>(blk) + t;
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) q[n1] = p[n1 * (S1 / 2)];
     }
-}
+    __device__ __forceinline__ void get(int n1, cpx& a, cpx& b) const {
+        const unsigned w = q[n1];
+        constexpr float sc = 1.0f / 128.0f, of = -127.4f / 128.0f;  // == (v - 127.4f) / 128 exactly
+        a = cpx{fmaf(float(w & 0xffu), sc, of), fmaf(float((w >> 8) & 0xffu), sc, of)};
+        b = cpx{fmaf(float((w >> 16) & 0xffu), sc, of), fmaf(float(w >> 24), sc, of)};
+    }
+};
+
+template <>
+struct RawSamples<THR_IN_C64> {
+    const f4* p;
+    __device__ __forceinline__ void load(const void* __restrict__ blk, int t) {
+        p = reinterpret_cast<const f4*>(blk) + t;
+    }
+    __device__ __forceinline__ void get(int n1, cpx& a, cpx& b) const {
+        const f4 w = p[n1 * (S1 / 2)];
+        a = cpx{w.x, w.y};
+        b = cpx{w.z, w.w};
+    }
+};
 
 // ------------------------------------------------------------ forward passes
 // Pass 1 (radix 16 over n1, two adjacent m per thread) -> LDS.
 // If PH: pre-rotate x[n1] by rpow[n1] and fold the per-m phasor p0/p1 into the twiddle.
 template <int FMT, bool PH>
-__device__ __forceinline__ void fwd_pass1(cpx* lds, const void* __restrict__ blk,
-                                          const cpx* __restrict__ rpow, cpx p0, cpx p1) {
+__device__ __forceinline__ void fwd_pass1(cpx* lds, const RawSamples<FMT>& raw,
+                                          const float2* __restrict__ rpow, cpx p0, cpx p1) {
     const int t = opaque_tid();
     cpx v0[R1], v1[R1];
 #pragma unroll
     for (int n1 = 0; n1 < R1; ++n1) {
-        load_pair<FMT>(blk, n1, t, v0[n1], v1[n1]);
+        raw.get(n1, v0[n1], v1[n1]);
         if constexpr (PH) {
-            const cpx r = rpow[n1];
+            const cpx r = cpx{rpow[n1].x, rpow[n1].y};
             v0[n1] = cmul(v0[n1], r);
             v1[n1] = cmul(v1[n1], r);
         }
@@ -154,7 +174,7 @@ __device__ __forceinline__ void fwd_pass1(cpx* lds, const void* __restrict__ blk
     const int n2 = t >> 4, mp = 2 * (t & 15);
     const cpx* tA = lds + OFF_A;
     const cpx* tB = lds + OFF_B;
-    float4* out = reinterpret_cast<float4*>(lds + n2 * CHUNK + mp);
+    f4* out = reinterpret_cast<f4*>(lds + n2 * CHUNK + mp);
     static_for<R1>([&](auto K) {
         constexpr int k1 = decltype(K)::value;
         constexpr int src = brev(k1, R1);
@@ -166,7 +186,7 @@ __device__ __forceinline__ void fwd_pass1(cpx* lds, const void* __restrict__ blk
             }
         } else {
             const cpx a = tA[k1 * 32 + n2];
-            const float4 bb = *reinterpret_cast<const float4*>(tB + k1 * 32 + mp);
+            const f4 bb = *reinterpret_cast<const f4*>(tB + k1 * 32 + mp);
             cpx w0 = cmul(a, cpx{bb.x, bb.y});
             cpx w1 = cmul(a, cpx{bb.z, bb.w});
             if constexpr (PH) {
@@ -176,7 +196,7 @@ __device__ __forceinline__ void fwd_pass1(cpx* lds, const void* __restrict__ blk
             y0 = cmul(y0, w0);
             y1 = cmul(y1, w1);
         }
-        out[k1 * (ROW / 2)] = float4{y0.x, y0.y, y1.x, y1.y};
+        out[k1 * (ROW / 2)] = f4{y0.x, y0.y, y1.x, y1.y};
     });
 }
 
@@ -202,10 +222,10 @@ __device__ __forceinline__ void fwd_pass2(cpx* lds) {
 // On return bin k = k1 + 16*k2 + 512*k3 is in v[brev(k3, 32)].
 __device__ __forceinline__ void fwd_pass3(const cpx* lds, cpx* v) {
     const int t = opaque_tid();
-    const float4* src = reinterpret_cast<const float4*>(lds + (t >> 5) * ROW + (t & 31) * CHUNK);
+    const f4* src = reinterpret_cast<const f4*>(lds + (t >> 5) * ROW + (t & 31) * CHUNK);
 #pragma unroll
     for (int j = 0; j < R3 / 2; ++j) {
-        const float4 q = src[j];
+        const f4 q = src[j];
         v[2 * j] = cpx{q.x, q.y};
         v[2 * j + 1] = cpx{q.z, q.w};
     }
@@ -226,13 +246,13 @@ __device__ __forceinline__ void inv_passA(cpx* lds, cpx* z) {
     });
     dft_dif<R3, +1>(v);
     const cpx* tC = lds + OFF_C + k2;
-    float4* dst = reinterpret_cast<float4*>(lds + (t >> 5) * ROW + k2 * CHUNK);
+    f4* dst = reinterpret_cast<f4*>(lds + (t >> 5) * ROW + k2 * CHUNK);
     static_for<R3 / 2>([&](auto J) {
         constexpr int j = decltype(J)::value;
         cpx y0 = v[brev(2 * j, R3)], y1 = v[brev(2 * j + 1, R3)];
         if constexpr (j != 0) y0 = cmulc(y0, tC[(2 * j) * 32]);
         y1 = cmulc(y1, tC[(2 * j + 1) * 32]);
-        dst[j] = float4{y0.x, y0.y, y1.x, y1.y};
+        dst[j] = f4{y0.x, y0.y, y1.x, y1.y};
     });
 }
 
@@ -262,10 +282,10 @@ __device__ __forceinline__ void inv_passB(cpx* lds) {
 __device__ __forceinline__ void inv_passC(const cpx* lds, cpx* c0, cpx* c1) {
     const int t = opaque_tid();
     const int n2 = t >> 4, mp = 2 * (t & 15);
-    const float4* src = reinterpret_cast<const float4*>(lds + n2 * CHUNK + mp);
+    const f4* src = reinterpret_cast<const f4*>(lds + n2 * CHUNK + mp);
 #pragma unroll
     for (int k1 = 0; k1 < R1; ++k1) {
-        const float4 q = src[k1 * (ROW / 2)];
+        const f4 q = src[k1 * (ROW / 2)];
         c0[k1] = cpx{q.x, q.y};
         c1[k1] = cpx{q.z, q.w};
     }
@@ -290,16 +310,35 @@ __global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples
     const size_t blk_bytes = size_t(N) * (FMT == THR_IN_U8 ? 2 : 8);
     int parity = 0;
 
+    RawSamples<FMT> cur;
+    if (int(blockIdx.x) < n_blocks)
+        cur.load(static_cast<const unsigned char*>(samples) + size_t(blockIdx.x) * blk_bytes,
+                 opaque_tid());
     for (int b = blockIdx.x; b < n_blocks; b += gridDim.x) {
-        const void* blk = static_cast<const unsigned char*>(samples) + size_t(b) * blk_bytes;
+        // next block's samples: issued now, consumed one iteration later
+        RawSamples<FMT> nxt = cur;
+        if (b + int(gridDim.x) < n_blocks)
+            nxt.load(static_cast<const unsigned char*>(samples) + size_t(b + gridDim.x) * blk_bytes,
+                     opaque_tid());
         // (previous block's pass-3 LDS reads all precede its reduction barrier)
-        fwd_pass1<FMT, false>(lds, blk, nullptr, cpx{}, cpx{});
+        fwd_pass1<FMT, false>(lds, cur, nullptr, cpx{}, cpx{});
+        cur = nxt;
         __syncthreads();
+        if (cfg.ablate == 1) continue;
         // passes 2 and 3 of row k1 are done by the same half-wave: no barrier between them
         fwd_pass2(lds);
         __builtin_amdgcn_sched_barrier(0);  // keep the passes' register working sets apart
+        if (cfg.ablate == 2) { __syncthreads(); continue; }
         cpx v[R3];
         fwd_pass3(lds, v);
+        if (cfg.ablate == 3) {
+            float acc = 0;
+#pragma unroll
+            for (int i = 0; i < R3; ++i) acc += v[i].x + v[i].y;
+            if (acc == 1.2345f) stats[b].pad = 1;  // keep pass 3 alive
+            __syncthreads();
+            continue;
+        }
 
         // ---- statistics over the spectrum held in registers
         const int t = opaque_tid();
@@ -541,10 +580,10 @@ __global__ __launch_bounds__(64) void k_fit(int n_blocks, DevCfg cfg,
 template <int FMT, bool WANT_STD, bool MULTI, bool DUMP>
 __global__ __launch_bounds__(NT) void k_correlate(
     const void* __restrict__ samples, DevCfg cfg, const cpx* __restrict__ tables,
-    const cpx* __restrict__ twn, const float4* __restrict__ tspec,
+    const cpx* __restrict__ twn, const f4* __restrict__ tspec,
     const ShiftParams* __restrict__ shifts, const int* __restrict__ work_list,
     const int* __restrict__ work_count, thr_record* __restrict__ records,
-    float4* __restrict__ xhat_scratch, cpx* __restrict__ dump_xhat,
+    f4* __restrict__ xhat_scratch, cpx* __restrict__ dump_xhat,
     cpx* __restrict__ dump_corr, int dump_template) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cpx* lds = reinterpret_cast<cpx*>(smem_raw);
@@ -557,11 +596,21 @@ __global__ __launch_bounds__(NT) void k_correlate(
     const int n_work = *work_count;
     int parity = 0;
 
+    RawSamples<FMT> cur;
+    int b_next = int(blockIdx.x) < n_work ? work_list[blockIdx.x] : 0;
+    if (int(blockIdx.x) < n_work)
+        cur.load(static_cast<const unsigned char*>(samples) + size_t(b_next) * blk_bytes,
+                 opaque_tid());
     for (int wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
-        const int b = work_list[wi];
+        const int b = b_next;
         const int t = opaque_tid();
-        const void* blk = static_cast<const unsigned char*>(samples) + size_t(b) * blk_bytes;
         const ShiftParams* sp = shifts + b;
+        // next block's samples: issued now, consumed one iteration later
+        RawSamples<FMT> nxt = cur;
+        if (wi + int(gridDim.x) < n_work) {
+            b_next = work_list[wi + gridDim.x];
+            nxt.load(static_cast<const unsigned char*>(samples) + size_t(b_next) * blk_bytes, t);
+        }
 
         // per-thread phasor for m = 2t, 2t+1: c0 * exp(2 pi i s m / N)
         cpx p[2];
@@ -572,16 +621,27 @@ __global__ __launch_bounds__(NT) void k_correlate(
             const cpx wq = cconj(twn[q]);  // exp(+2 pi i q / N)
             float sn, cs;
             sincosf(6.283185307179586f * (sp->sf_over_n * float(m)), &sn, &cs);
-            p[e] = cmul(cmul(wq, cpx{cs, sn}), sp->c0);
+            p[e] = cmul(cmul(wq, cpx{cs, sn}), cpx{sp->c0.x, sp->c0.y});
         }
         // (the previous block's pass-C LDS reads all precede its reduction barrier)
-        fwd_pass1<FMT, true>(lds, blk, sp->rpow, p[0], p[1]);
+        fwd_pass1<FMT, true>(lds, cur, sp->rpow, p[0], p[1]);
+        cur = nxt;
         __syncthreads();
+        if (cfg.ablate == 1) continue;
         // rows k1 = 2w, 2w+1 belong to wave w through passes 2, 3, A and B: no barriers
         fwd_pass2(lds);
         __builtin_amdgcn_sched_barrier(0);  // keep the passes' register working sets apart
+        if (cfg.ablate == 2) { __syncthreads(); continue; }
         cpx xh[R3];
         fwd_pass3(lds, xh);
+        if (cfg.ablate == 3) {
+            float acc = 0;
+#pragma unroll
+            for (int i = 0; i < R3; ++i) acc += xh[i].x + xh[i].y;
+            if (acc == 1.2345f) records[b].reserved = 1;
+            __syncthreads();
+            continue;
+        }
 
         const int kbase = (t >> 5) + 16 * (t & 31);
         float e2 = 0.f;
@@ -597,12 +657,12 @@ __global__ __launch_bounds__(NT) void k_correlate(
                 });
             }
         }
-        float4* park = nullptr;
+        f4* park = nullptr;
         if constexpr (MULTI) {
             park = xhat_scratch + size_t(blockIdx.x) * (N / 2) + t;
             static_for<R3 / 2>([&](auto J) {
                 constexpr int j = decltype(J)::value;
-                park[j * NT] = float4{xh[brev(2 * j, R3)].x, xh[brev(2 * j, R3)].y,
+                park[j * NT] = f4{xh[brev(2 * j, R3)].x, xh[brev(2 * j, R3)].y,
                                       xh[brev(2 * j + 1, R3)].x, xh[brev(2 * j + 1, R3)].y};
             });
         }
@@ -612,14 +672,14 @@ __global__ __launch_bounds__(NT) void k_correlate(
             // ---- X * conj(T)/N in digit-reversed register order
             const int t = opaque_tid();  // re-derive per template: keeps LICM off the loop body
             if constexpr (MULTI) park = xhat_scratch + size_t(blockIdx.x) * (N / 2) + t;
-            const float4* ts = tspec + size_t(tpl) * (N / 2) + t;
+            const f4* ts = tspec + size_t(tpl) * (N / 2) + t;
             cpx z[R3];
             static_for<R3 / 2>([&](auto J) {
                 constexpr int j = decltype(J)::value;
-                const float4 q = ts[j * NT];
+                const f4 q = ts[j * NT];
                 cpx x0, x1;
                 if constexpr (MULTI) {
-                    const float4 xx = park[j * NT];  // own writes: program order suffices
+                    const f4 xx = park[j * NT];  // own writes: program order suffices
                     x0 = cpx{xx.x, xx.y};
                     x1 = cpx{xx.z, xx.w};
                 } else {
@@ -633,10 +693,20 @@ __global__ __launch_bounds__(NT) void k_correlate(
             // tpl > 0, rows whose pass-C readers are behind the previous reduction barrier)
             inv_passA(lds, z);
             __builtin_amdgcn_sched_barrier(0);
+            if (cfg.ablate == 4) { __syncthreads(); continue; }
             inv_passB(lds);
             __syncthreads();
+            if (cfg.ablate == 5) continue;
             cpx c0[R1], c1[R1];
             inv_passC(lds, c0, c1);
+            if (cfg.ablate == 6) {
+                float acc = 0;
+#pragma unroll
+                for (int i = 0; i < R1; ++i) acc += c0[i].x + c0[i].y + c1[i].x + c1[i].y;
+                if (acc == 1.2345f) records[b].reserved = 1;
+                __syncthreads();
+                continue;
+            }
 
             // ---- |corr|^2, windowed first-max, optional std sums
             unsigned long long best = 0;
@@ -682,8 +752,8 @@ __global__ __launch_bounds__(NT) void k_correlate(
                     cpx* out = dump_corr + size_t(b) * N;
                     static_for<R1>([&](auto K) {
                         constexpr int n1 = decltype(K)::value;
-                        reinterpret_cast<float4*>(out + n1 * S1)[t] =
-                            float4{c0[brev(n1, R1)].x, c0[brev(n1, R1)].y, c1[brev(n1, R1)].x,
+                        reinterpret_cast<f4*>(out + n1 * S1)[t] =
+                            f4{c0[brev(n1, R1)].x, c0[brev(n1, R1)].y, c1[brev(n1, R1)].x,
                                    c1[brev(n1, R1)].y};
                     });
                 }
@@ -769,8 +839,8 @@ size_t lds_bytes_16k() { return LDS_BYTES; }
 
 namespace {
 typedef void (*carrier_fn)(const void*, int, DevCfg, const cpx*, CarStats*, cpx*);
-typedef void (*correlate_fn)(const void*, DevCfg, const cpx*, const cpx*, const float4*,
-                             const ShiftParams*, const int*, const int*, thr_record*, float4*,
+typedef void (*correlate_fn)(const void*, DevCfg, const cpx*, const cpx*, const f4*,
+                             const ShiftParams*, const int*, const int*, thr_record*, f4*,
                              cpx*, cpx*, int);
 
 #ifdef THR_DEV_MINIMAL  // compile-time experiments only: one variant each, fast rebuilds
@@ -828,8 +898,8 @@ hipError_t launch_carrier_16k(int fmt, const void* samples, int n_blocks, const 
                               const float2* tables, CarStats* stats, float2* dump_fft, int grid,
                               hipStream_t stream) {
     carrier_fn fn = carrier_variant(fmt, cfg.car_want_std != 0, dump_fft != nullptr);
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(NT), LDS_BYTES, stream, samples, n_blocks, cfg, tables,
-                       stats, dump_fft);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(NT), LDS_BYTES, stream, samples, n_blocks, cfg,
+                       reinterpret_cast<const cpx*>(tables), stats, reinterpret_cast<cpx*>(dump_fft));
     return hipGetLastError();
 }
 
@@ -849,9 +919,11 @@ hipError_t launch_correlate_16k(int fmt, const void* samples, const DevCfg& cfg,
                                 hipStream_t stream) {
     const bool dump = dump_xhat != nullptr || dump_corr != nullptr;
     correlate_fn fn = correlate_variant(fmt, cfg.cor_want_std != 0, cfg.n_templates > 1, dump);
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(NT), LDS_BYTES, stream, samples, cfg, tables, twn,
-                       tspec, shifts, work_list, work_count, records, xhat_scratch, dump_xhat,
-                       dump_corr, dump_template);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(NT), LDS_BYTES, stream, samples, cfg,
+                       reinterpret_cast<const cpx*>(tables), reinterpret_cast<const cpx*>(twn),
+                       reinterpret_cast<const f4*>(tspec), shifts, work_list, work_count, records,
+                       reinterpret_cast<f4*>(xhat_scratch), reinterpret_cast<cpx*>(dump_xhat),
+                       reinterpret_cast<cpx*>(dump_corr), dump_template);
     return hipGetLastError();
 }
 

@@ -1,9 +1,17 @@
 // In-register complex DFT building blocks for gfx950 (wave64, fp32).
 //
-// Every array index below is a compile-time constant after inlining, so the
-// `cpx v[R]` working sets live entirely in VGPRs.  Twiddles internal to a
-// butterfly are compile-time constants (multiples of 2*pi/32); multiplications
-// by +-1 and +-i are eliminated at compile time.
+// Complex values are clang ext-vector float2 (`cpx`), so a complex add/sub is one
+// v_pk_add_f32 and a rotation by a compile-time twiddle is v_pk_mul + v_pk_fma with
+// op_sel swizzles -- no register shuffling.  On CDNA4 a packed op costs the same
+// VALU cycles as its two scalar halves (32 lane-ops/clk/SIMD either way), so the
+// aim is simply the fewest lane-ops and zero v_mov: products with run-time twiddles
+// are written as 4 scalar mul/fma, and multiplications by -+i are folded into the
+// radix-4 butterflies as a v_pk_fma with a (+-1, -+1) constant.  This translation unit must be
+// compiled with -fno-slp-vectorize (the SLP vectorizer re-packs the scalar forms
+// and pays for it in v_mov/v_pk_mov -- measured ~40 % extra VALU).
+//
+// Every array index is a compile-time constant after inlining: `cpx v[R]` lives
+// entirely in VGPRs.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -11,19 +19,31 @@
 
 namespace thr {
 
-typedef float2 cpx;
+typedef float cpx __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ cpx cadd(cpx a, cpx b) { return cpx{a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ cpx csub(cpx a, cpx b) { return cpx{a.x - b.x, a.y - b.y}; }
 __device__ __forceinline__ cpx cmul(cpx a, cpx b) {
-    return cpx{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+    cpx r;
+    r.x = fmaf(-a.y, b.y, a.x * b.x);
+    r.y = fmaf(a.y, b.x, a.x * b.y);
+    return r;
 }
 // a * conj(b)
 __device__ __forceinline__ cpx cmulc(cpx a, cpx b) {
-    return cpx{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y};
+    cpx r;
+    r.x = fmaf(a.y, b.y, a.x * b.x);
+    r.y = fmaf(a.y, b.x, -(a.x * b.y));
+    return r;
 }
 __device__ __forceinline__ cpx cconj(cpx a) { return cpx{a.x, -a.y}; }
-__device__ __forceinline__ float cnorm(cpx a) { return a.x * a.x + a.y * a.y; }
+__device__ __forceinline__ float cnorm(cpx a) { return fmaf(a.x, a.x, a.y * a.y); }
+// a + DIR*i*b  (DIR = +1 or -1) as ONE v_pk_fma_f32: b.yx * (-+1, +-1) + a.  The swap is an
+// op_sel modifier, so the multiplication by +-i is free.  (Writing it as a scalar
+// add/sub pair makes the backend re-pack it with v_mov shuffles.)
+template <int DIR>
+__device__ __forceinline__ cpx add_irot(cpx a, cpx b) {
+    return __builtin_elementwise_fma(b.yx, DIR > 0 ? cpx{-1.0f, 1.0f} : cpx{1.0f, -1.0f}, a);
+}
 
 // cos(2*pi*j/32), j = 0..8
 constexpr float kCos32[9] = {1.0f,
@@ -50,7 +70,7 @@ __device__ __forceinline__ cpx rot32(cpx z) {
     if constexpr (q == 0) {
         return z;
     } else if constexpr (q == 16) {
-        return cpx{-z.x, -z.y};
+        return -z;
     } else if constexpr (q == 8) {
         return DIR > 0 ? cpx{-z.y, z.x} : cpx{z.y, -z.x};
     } else if constexpr (q == 24) {
@@ -58,7 +78,8 @@ __device__ __forceinline__ cpx rot32(cpx z) {
     } else {
         constexpr float C = cos32(q);
         constexpr float S = (DIR > 0 ? 1.0f : -1.0f) * sin32(q);
-        return cpx{z.x * C - z.y * S, z.x * S + z.y * C};
+        // (x*C - y*S, x*S + y*C) = z*(C,C) + z.yx*(-S,S)
+        return __builtin_elementwise_fma(z.yx, cpx{-S, S}, z * cpx{C, C});
     }
 }
 
@@ -79,21 +100,34 @@ constexpr int brev(int k, int r) {
     return out;
 }
 
-// In-place radix-2 decimation-in-frequency DFT of v[0..R), R | 32.
+// In-place decimation-in-frequency DFT of v[0..R), R in {2,4,8,16,32}, built from
+// radix-4 stages (plus one radix-2 stage when log2 R is odd).
 // DIR = -1: forward (exp(-i...)), +1: inverse (unnormalised).
-// Output bin k ends up in v[brev(k, R)].
+// Output bin k ends up in v[brev(k, R)] (same placement as a radix-2 DIF cascade).
 template <int R, int DIR>
 __device__ __forceinline__ void dft_dif(cpx* v) {
-    if constexpr (R >= 2) {
-        constexpr int H = R / 2;
+    if constexpr (R == 2) {
+        const cpx a = v[0], b = v[1];
+        v[0] = a + b;
+        v[1] = a - b;
+    } else if constexpr (R >= 4) {
+        constexpr int H = R / 4;
         static_for<H>([&](auto J) {
             constexpr int j = decltype(J)::value;
-            const cpx a = v[j], b = v[j + H];
-            v[j] = cadd(a, b);
-            v[j + H] = rot32<j*(32 / R), DIR>(csub(a, b));
+            constexpr int s = 32 / R;  // W_R^j == W_32^(j*s)
+            const cpx a = v[j], b = v[j + H], c = v[j + 2 * H], d = v[j + 3 * H];
+            const cpx t0 = a + c, t1 = a - c, t2 = b + d, t3 = b - d;
+            v[j] = t0 + t2;                                             // k = 0 mod 4
+            v[j + H] = rot32<2 * j * s, DIR>(t0 - t2);                   // k = 2 mod 4
+            v[j + 2 * H] = rot32<j * s, DIR>(add_irot<DIR>(t1, t3));     // k = 1 mod 4
+            v[j + 3 * H] = rot32<3 * j * s, DIR>(add_irot<-DIR>(t1, t3));  // k = 3 mod 4
         });
-        dft_dif<H, DIR>(v);
-        dft_dif<H, DIR>(v + H);
+        if constexpr (H > 1) {
+            dft_dif<H, DIR>(v);
+            dft_dif<H, DIR>(v + H);
+            dft_dif<H, DIR>(v + 2 * H);
+            dft_dif<H, DIR>(v + 3 * H);
+        }
     }
 }
 
