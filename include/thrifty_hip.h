@@ -135,12 +135,13 @@ int thr_compact_device(thr_handle* h, const thr_record* d_in, size_t n_records,
 
 /*
  * Per-kernel timing with HIP events on the handle's stream (bench.py's
- * roofline leg).  After enabling, every thr_detect*() call brackets each
- * kernel with events; thr_profile_read() syncs and returns accumulated
+ * roofline leg).  `on` = n > 0 brackets each kernel of every n-th thr_detect*()
+ * batch with events (n = 1: all; sampling keeps the ~35 us/batch cost of the event
+ * packets out of most steps); 0 disables.  thr_profile_read() syncs and returns accumulated
  * milliseconds and launch counts per kernel slot and resets the accumulators.
- * Slots: 0 = carrier (FFT#1 + peak), 1 = fit, 2 = correlate (FFT#2..SoA).
+ * Slots: 0 = carrier (FFT#1 + peak), 1 = fit, 2 = correlate (FFT#2..peak), 3 = finish (SoA).
  */
-#define THR_N_KERNEL_SLOTS 3
+#define THR_N_KERNEL_SLOTS 4
 int thr_profile_enable(thr_handle* h, int on);
 int thr_profile_read(thr_handle* h, double ms[THR_N_KERNEL_SLOTS],
                      int64_t launches[THR_N_KERNEL_SLOTS]);

@@ -18,7 +18,7 @@ THR_IN_C64 = 1
 FLAG_CARRIER = 1
 FLAG_CORR = 2
 FLAG_INDEX_ERROR = 4
-N_KERNEL_SLOTS = 3
+N_KERNEL_SLOTS = 4
 
 EXPORTS = [
     "thr_abi_version", "thr_last_error", "thr_create", "thr_destroy", "thr_detect",
@@ -198,8 +198,9 @@ class Engine(object):
     def set_stream(self, stream_ptr):
         _check(self._lib, self._lib.thr_set_stream(self._h, stream_ptr))
 
-    def profile_enable(self, on=True):
-        _check(self._lib, self._lib.thr_profile_enable(self._h, int(bool(on))))
+    def profile_enable(self, every=1):
+        """every = n > 0: time the kernels of every n-th batch; 0/False: off."""
+        _check(self._lib, self._lib.thr_profile_enable(self._h, int(every)))
 
     def profile_read(self):
         ms = (C.c_double * N_KERNEL_SLOTS)()

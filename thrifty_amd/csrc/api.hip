@@ -89,6 +89,7 @@ struct thr_handle {
     // per-batch work buffers
     thr::CarStats* d_stats = nullptr;
     thr::ShiftParams* d_shifts = nullptr;
+    thr::CorrStats* d_corr_stats = nullptr;
     int* d_work_list = nullptr;
     int* d_work_count = nullptr;
     float4* d_xhat_scratch = nullptr;
@@ -99,10 +100,13 @@ struct thr_handle {
     long long* d_idx = nullptr;
     thr_record* d_rec = nullptr;
     // profiling
-    bool prof = false;
+    int prof_every = 0;      // 0 = off, n = bracket the kernels of every n-th batch
+    long long batch_no = 0;
+    bool prof = false;       // this batch is being timed
+    std::vector<EventPair> free_events;
     std::vector<EventPair> pending[THR_N_KERNEL_SLOTS];
-    double ms[THR_N_KERNEL_SLOTS] = {0, 0, 0};
-    int64_t launches[THR_N_KERNEL_SLOTS] = {0, 0, 0};
+    double ms[THR_N_KERNEL_SLOTS] = {};
+    int64_t launches[THR_N_KERNEL_SLOTS] = {};
 };
 
 namespace {
@@ -114,8 +118,13 @@ struct ProfScope {
     bool on;
     ProfScope(thr_handle* h_, int slot_) : h(h_), slot(slot_), on(h_->prof) {
         if (on) {
-            hipEventCreate(&ev.a);
-            hipEventCreate(&ev.b);
+            if (!h->free_events.empty()) {
+                ev = h->free_events.back();
+                h->free_events.pop_back();
+            } else {
+                hipEventCreate(&ev.a);
+                hipEventCreate(&ev.b);
+            }
             hipEventRecord(ev.a, h->stream);
         }
     }
@@ -207,6 +216,7 @@ int run_batch(thr_handle* h, const void* d_samples, int format, const long long*
               int n_blocks, thr_record* d_out, float2* dump_fft, float2* dump_xhat,
               float2* dump_corr, int dump_template, bool carrier_only) {
     const int grid = std::min(n_blocks, h->n_cu);
+    h->prof = h->prof_every > 0 && (h->batch_no++ % h->prof_every) == 0;
     HIP_TRY(hipMemsetAsync(h->d_work_count, 0, sizeof(int), h->stream));
     {
         ProfScope p(h, 0);
@@ -223,8 +233,13 @@ int run_batch(thr_handle* h, const void* d_samples, int format, const long long*
         ProfScope p(h, 2);
         HIP_TRY(thr::launch_correlate_16k(format, d_samples, h->dev, h->d_tables, h->d_twn,
                                           h->d_tspec, h->d_shifts, h->d_work_list, h->d_work_count,
-                                          d_out, h->d_xhat_scratch, dump_xhat, dump_corr,
-                                          dump_template, grid, h->stream));
+                                          h->d_corr_stats, d_out, h->d_xhat_scratch, dump_xhat,
+                                          dump_corr, dump_template, grid, h->stream));
+    }
+    {
+        ProfScope p(h, 3);
+        HIP_TRY(thr::launch_finish(n_blocks * h->cfg.n_templates, h->dev, h->d_corr_stats, d_out,
+                                   h->stream));
     }
     return THR_OK;
 }
@@ -238,7 +253,7 @@ int thr_abi_version(void) { return THR_ABI_VERSION; }
 const char* thr_last_error(void) { return g_last_error.c_str(); }
 
 const char* thr_kernel_name(int slot) {
-    static const char* names[THR_N_KERNEL_SLOTS] = {"k_carrier", "k_fit", "k_correlate"};
+    static const char* names[THR_N_KERNEL_SLOTS] = {"k_carrier", "k_fit", "k_correlate", "k_finish"};
     return (slot >= 0 && slot < THR_N_KERNEL_SLOTS) ? names[slot] : "";
 }
 
@@ -329,6 +344,7 @@ int thr_create(const thr_settings* s, thr_handle** out) {
         const size_t mb = size_t(s->max_batch);
         CREATE_TRY(hipMalloc(&h->d_stats, mb * sizeof(thr::CarStats)));
         CREATE_TRY(hipMalloc(&h->d_shifts, mb * sizeof(thr::ShiftParams)));
+        CREATE_TRY(hipMalloc(&h->d_corr_stats, mb * s->n_templates * sizeof(thr::CorrStats)));
         CREATE_TRY(hipMalloc(&h->d_work_list, mb * sizeof(int)));
         CREATE_TRY(hipMalloc(&h->d_work_count, sizeof(int)));
         CREATE_TRY(hipMalloc(&h->d_ncompact, sizeof(int)));
@@ -349,11 +365,12 @@ void thr_destroy(thr_handle* h) {
     hipSetDevice(h->device);
     if (h->own_stream) hipStreamSynchronize(h->own_stream);
     for (auto& v : h->pending)
-        for (auto& e : v) {
-            hipEventDestroy(e.a);
-            hipEventDestroy(e.b);
-        }
-    void* bufs[] = {h->d_tables, h->d_twn, h->d_tspec, h->d_stats, h->d_shifts, h->d_work_list,
+        for (auto& e : v) h->free_events.push_back(e);
+    for (auto& e : h->free_events) {
+        hipEventDestroy(e.a);
+        hipEventDestroy(e.b);
+    }
+    void* bufs[] = {h->d_tables, h->d_twn, h->d_tspec, h->d_stats, h->d_shifts, h->d_corr_stats, h->d_work_list,
                     h->d_work_count, h->d_xhat_scratch, h->d_ncompact, h->d_in, h->d_idx, h->d_rec};
     for (void* b : bufs)
         if (b) hipFree(b);
@@ -435,7 +452,8 @@ int thr_compact_device(thr_handle* h, const thr_record* d_in, size_t n_records, 
 
 int thr_profile_enable(thr_handle* h, int on) {
     if (!h) return fail(THR_ERR_ARG, "null handle");
-    h->prof = on != 0;
+    h->prof_every = on < 0 ? 0 : on;
+    h->batch_no = 0;
     return THR_OK;
 }
 
@@ -451,8 +469,7 @@ int thr_profile_read(thr_handle* h, double ms[THR_N_KERNEL_SLOTS],
                 h->ms[s] += t;
                 h->launches[s] += 1;
             }
-            hipEventDestroy(e.a);
-            hipEventDestroy(e.b);
+            h->free_events.push_back(e);
         }
         h->pending[s].clear();
         ms[s] = h->ms[s];

@@ -51,25 +51,46 @@ __device__ __forceinline__ int opaque_tid() {
 }
 
 // ---------------------------------------------------------------- reductions
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// Wave-level reductions on the VALU's DPP path (row_shr 1/2/4/8 inside each 16-lane
+// row, then row_bcast15 / row_bcast31 across rows): ~10 VALU ops instead of six
+// LDS-crossbar ds_bpermute round trips.  The result is valid in lane 63 and is
+// broadcast from there with v_readlane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_u32(unsigned identity, unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xf, false);
 }
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114,
+              DPP_ROW_SHR8 = 0x118, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#define THR_STEP(CTRL, MASK) v += __uint_as_float(dpp_u32<CTRL, MASK>(0u, __float_as_uint(v)))
+    THR_STEP(DPP_ROW_SHR1, 0xf);
+    THR_STEP(DPP_ROW_SHR2, 0xf);
+    THR_STEP(DPP_ROW_SHR4, 0xf);
+    THR_STEP(DPP_ROW_SHR8, 0xf);
+    THR_STEP(DPP_ROW_BCAST15, 0xa);
+    THR_STEP(DPP_ROW_BCAST31, 0xc);
+#undef THR_STEP
+    return __uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
 }
 __device__ __forceinline__ unsigned long long wave_max(unsigned long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        unsigned lo = __shfl_xor((unsigned)v, o, 64);
-        unsigned hi = __shfl_xor((unsigned)(v >> 32), o, 64);
-        unsigned long long w = ((unsigned long long)hi << 32) | lo;
-        v = w > v ? w : v;
+#define THR_STEP(CTRL, MASK)                                                       \
+    {                                                                              \
+        const unsigned lo = dpp_u32<CTRL, MASK>(0u, (unsigned)v);                  \
+        const unsigned hi = dpp_u32<CTRL, MASK>(0u, (unsigned)(v >> 32));          \
+        const unsigned long long w = ((unsigned long long)hi << 32) | lo;          \
+        v = w > v ? w : v;                                                         \
     }
-    return v;
+    THR_STEP(DPP_ROW_SHR1, 0xf)
+    THR_STEP(DPP_ROW_SHR2, 0xf)
+    THR_STEP(DPP_ROW_SHR4, 0xf)
+    THR_STEP(DPP_ROW_SHR8, 0xf)
+    THR_STEP(DPP_ROW_BCAST15, 0xa)
+    THR_STEP(DPP_ROW_BCAST31, 0xc)
+#undef THR_STEP
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
 }
 
 // Combined block reduction: NS float sums (returned as double) + one u64 max,
@@ -345,9 +366,11 @@ __global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples
         const int kbase = (t >> 5) + 16 * (t & 31);
         float sums[2] = {0.f, 0.f};
         unsigned long long best = 0;
+        float pw[R3];
         static_for<R3>([&](auto K) {
             constexpr int k3 = decltype(K)::value;
             const float p = cnorm(v[brev(k3, R3)]);
+            pw[k3] = p;
             sums[0] += p;
             if constexpr (WANT_STD) sums[1] += __builtin_amdgcn_sqrtf(p);
             const unsigned wi = unsigned(kbase + 512 * k3 - cfg.win_lo) & unsigned(N - 1);
@@ -365,15 +388,21 @@ __global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples
         const unsigned wi = 0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu);
         int peak_idx = int(wi) + cfg.win_lo;
         if (peak_idx > N) peak_idx -= N;  // sic: '>' (carrier_detect.py:151)
-        // 7-bin neighbourhood around the peak, written straight to the stats record by
-        // whichever threads hold those bins (indices wrap here; K_fit flags the cases
-        // where the reference would raise IndexError instead)
+        // 7-bin neighbourhood |X[peak-3..peak+3]| (indices wrap here; K_fit flags the cases
+        // where the reference would raise IndexError).  This thread's bins are
+        // kbase + 512*k3, so it holds neighbour d iff (kbase - peak + 3) mod 512 == d < 7,
+        // at k3 = -((kbase - peak + 3) >> 9) mod 32: exactly seven threads store one float.
         CarStats* st = stats + b;
-        static_for<R3>([&](auto K) {
-            constexpr int k3 = decltype(K)::value;
-            const unsigned d = unsigned(kbase + 512 * k3 - peak_idx + 3) & unsigned(N - 1);
-            if (d < 7u) st->nb[d] = sqrtf(cnorm(v[brev(k3, R3)]));
-        });
+        {
+            const unsigned u = unsigned(kbase - peak_idx + 3) & unsigned(N - 1);
+            const unsigned r = u & 511u, k3s = (32u - (u >> 9)) & 31u;
+            float val = 0.f;
+            static_for<R3>([&](auto K) {
+                constexpr int k3 = decltype(K)::value;
+                val = (k3s == unsigned(k3)) ? pw[k3] : val;
+            });
+            if (r < 7u) st->nb[r] = sqrtf(val);
+        }
         if constexpr (DUMP) {
             cpx* out = dump_fft + size_t(b) * N;
             static_for<R3>([&](auto K) {
@@ -582,13 +611,12 @@ __global__ __launch_bounds__(NT) void k_correlate(
     const void* __restrict__ samples, DevCfg cfg, const cpx* __restrict__ tables,
     const cpx* __restrict__ twn, const f4* __restrict__ tspec,
     const ShiftParams* __restrict__ shifts, const int* __restrict__ work_list,
-    const int* __restrict__ work_count, thr_record* __restrict__ records,
-    f4* __restrict__ xhat_scratch, cpx* __restrict__ dump_xhat,
-    cpx* __restrict__ dump_corr, int dump_template) {
+    const int* __restrict__ work_count, CorrStats* __restrict__ corr_stats,
+    thr_record* __restrict__ records, f4* __restrict__ xhat_scratch,
+    cpx* __restrict__ dump_xhat, cpx* __restrict__ dump_corr, int dump_template) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cpx* lds = reinterpret_cast<cpx*>(smem_raw);
     unsigned char* sc_red = reinterpret_cast<unsigned char*>(lds + OFF_S);
-    float* sc_m = reinterpret_cast<float*>(sc_red + 2 * RED_SLOT_BYTES);  // [2][4]
 
     load_tables(lds, tables);
     __syncthreads();
@@ -711,12 +739,15 @@ __global__ __launch_bounds__(NT) void k_correlate(
             // ---- |corr|^2, windowed first-max, optional std sums
             unsigned long long best = 0;
             float sums[3] = {tpl == 0 ? e2 : 0.f, 0.f, 0.f};
+            float pw0[R1], pw1[R1];
             static_for<R1>([&](auto K) {
                 constexpr int n1 = decltype(K)::value;
+                pw0[n1] = cnorm(c0[brev(n1, R1)]);
+                pw1[n1] = cnorm(c1[brev(n1, R1)]);
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int n = n1 * S1 + 2 * t + e;
-                    const float pw = cnorm(e ? c1[brev(n1, R1)] : c0[brev(n1, R1)]);
+                    const float pw = e ? pw1[n1] : pw0[n1];
                     if (n >= cfg.corr_lo && n < cfg.corr_hi) {
                         const unsigned long long key =
                             ((unsigned long long)__float_as_uint(pw) << 32) |
@@ -735,18 +766,24 @@ __global__ __launch_bounds__(NT) void k_correlate(
             double tot[3] = {0, 0, 0};
             block_reduce<NS>(reinterpret_cast<float(&)[NS]>(sums),
                              reinterpret_cast<double(&)[NS]>(tot), best, sc_red, parity);
-            float* scm = sc_m + 4 * parity;
             parity ^= 1;
             const int pk = int(0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu));
-            static_for<R1>([&](auto K) {
-                constexpr int n1 = decltype(K)::value;
+            // |corr[pk-1..pk+1]|^2 for the log-parabola: lag n = n1*1024 + 2t + e, so this
+            // thread holds pk-1+d iff (2t + e - pk + 1 - d) mod 1024 == 0; the three owners
+            // store straight into the per-record stats (finalised by k_finish).
+            CorrStats* cs = corr_stats + size_t(b) * cfg.n_templates + tpl;
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int n = n1 * S1 + 2 * t + e;
-                    const unsigned d = unsigned(n - pk + 1);
-                    if (d < 3u) scm[d] = cnorm(e ? c1[brev(n1, R1)] : c0[brev(n1, R1)]);
-                }
-            });
+            for (int e = 0; e < 2; ++e) {
+                const int delta = pk - 1 - (2 * t + e);        // want n1*1024 == delta + d
+                const unsigned d = unsigned(-delta) & 1023u;    // d in [0,1024)
+                const int n1s = (delta + int(d)) >> 10;
+                float val = 0.f;
+                static_for<R1>([&](auto K) {
+                    constexpr int n1 = decltype(K)::value;
+                    val = (n1s == n1) ? (e ? pw1[n1] : pw0[n1]) : val;
+                });
+                if (d < 3u && n1s >= 0 && n1s < R1) cs->m2[d] = val;
+            }
             if constexpr (DUMP) {
                 if (dump_corr != nullptr && tpl == dump_template) {
                     cpx* out = dump_corr + size_t(b) * N;
@@ -754,52 +791,61 @@ __global__ __launch_bounds__(NT) void k_correlate(
                         constexpr int n1 = decltype(K)::value;
                         reinterpret_cast<f4*>(out + n1 * S1)[t] =
                             f4{c0[brev(n1, R1)].x, c0[brev(n1, R1)].y, c1[brev(n1, R1)].x,
-                                   c1[brev(n1, R1)].y};
+                               c1[brev(n1, R1)].y};
                     });
                 }
             }
-            // mean |X|^2 of the shifted spectrum rides along with template 0's reduction
-            double xenergy = tot[0] / double(N);
-            if constexpr (MULTI) {
-                double* keep = reinterpret_cast<double*>(sc_m + 8);
-                if (tpl == 0) {
-                    if (t == 0) *keep = xenergy;
-                } else {
-                    xenergy = *keep;  // written by thread 0 before >= 1 barrier ago
-                }
-            }
-            __syncthreads();
             if (t == 0) {
-                // soa_estimator.py:108-134 (float64 in the reference)
-                const double pm2 = (double)__uint_as_float(unsigned(best >> 32));
-                const double peak_mag = sqrt(pm2);
-                const double noise_pow =
-                    (xenergy * (double)cfg.tmpl_energy[tpl] - pm2) / double(N);
-                const double noise_rms = sqrt(noise_pow);
-                double th = cfg.cor_thr[0] + cfg.cor_thr[1] * (noise_rms * noise_rms);
-                if constexpr (WANT_STD) {
-                    const double m1 = tot[1] / cfg.corr_len, m2 = tot[2] / cfg.corr_len;
-                    th += cfg.cor_thr[2] * (m2 - m1 * m1);
-                }
-                th = sqrt(th);
-                const bool det = peak_mag > th;
-                double off = 0.0;
-                if (det && pk != 0 && pk != cfg.corr_len - 1) {
-                    // log-parabola on magnitudes == same formula on log |.|^2
-                    const double la = log((double)scm[0]), lb = log((double)scm[1]),
-                                 lc = log((double)scm[2]);
-                    off = 0.5 * (lc - la) / (2 * lb - la - lc);
-                    off = off < -0.6 ? -0.6 : off > 0.6 ? 0.6 : off;
-                }
-                thr_record* r = records + size_t(b) * cfg.n_templates + tpl;
-                r->corr_sample = pk;
-                r->corr_offset = off;
-                r->corr_energy = (float)peak_mag;
-                r->corr_noise = (float)noise_rms;
-                if (det) r->flags |= THR_FLAG_CORR;
+                cs->pm2 = __uint_as_float(unsigned(best >> 32));
+                cs->pk = pk;
+                if (tpl == 0) cs->sum_x2 = (float)tot[0];  // sum |X^|^2, shared by all templates
+                cs->sum_mag = WANT_STD ? (float)tot[1] : 0.f;
+                cs->sum_mag2 = WANT_STD ? (float)tot[2] : 0.f;
             }
         }
     }
+}
+
+// =========================================================================
+// K_finish: one lane per (block, template) -- noise, threshold verdict, sub-sample
+// offset (soa_estimator.py:108-170; float64 like the reference).  Kept out of
+// k_correlate so that no workgroup ever waits on one thread's log()/sqrt() chain.
+// =========================================================================
+__global__ __launch_bounds__(256) void k_finish(int n_records, DevCfg cfg,
+                                                const CorrStats* __restrict__ corr_stats,
+                                                thr_record* __restrict__ records) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_records) return;
+    thr_record* r = records + i;
+    if (!(r->flags & THR_FLAG_CARRIER)) return;
+    const int tpl = i % cfg.n_templates;
+    const CorrStats cs = corr_stats[i];
+    const double n = double(cfg.block_len);
+    const double xenergy = double(corr_stats[i - tpl].sum_x2) / n;  // mean |X^|^2
+    const double pm2 = double(cs.pm2);
+    const double peak_mag = sqrt(pm2);
+    const double noise_pow = (xenergy * double(cfg.tmpl_energy[tpl]) - pm2) / n;
+    const double noise_rms = sqrt(noise_pow);
+    double th = cfg.cor_thr[0] + cfg.cor_thr[1] * (noise_rms * noise_rms);
+    if (cfg.cor_want_std) {
+        const double m1 = double(cs.sum_mag) / cfg.corr_len, m2 = double(cs.sum_mag2) / cfg.corr_len;
+        th += cfg.cor_thr[2] * (m2 - m1 * m1);
+    }
+    th = sqrt(th);
+    const bool det = peak_mag > th;
+    double off = 0.0;
+    if (det && cs.pk != 0 && cs.pk != cfg.corr_len - 1) {
+        // log-parabola on magnitudes == the same formula on log |.|^2
+        const double la = log(double(cs.m2[0])), lb = log(double(cs.m2[1])),
+                     lc = log(double(cs.m2[2]));
+        off = 0.5 * (lc - la) / (2 * lb - la - lc);
+        off = off < -0.6 ? -0.6 : off > 0.6 ? 0.6 : off;
+    }
+    r->corr_sample = cs.pk;
+    r->corr_offset = off;
+    r->corr_energy = (float)peak_mag;
+    r->corr_noise = (float)noise_rms;
+    if (det) r->flags |= THR_FLAG_CORR;
 }
 
 // =========================================================================
@@ -840,8 +886,8 @@ size_t lds_bytes_16k() { return LDS_BYTES; }
 namespace {
 typedef void (*carrier_fn)(const void*, int, DevCfg, const cpx*, CarStats*, cpx*);
 typedef void (*correlate_fn)(const void*, DevCfg, const cpx*, const cpx*, const f4*,
-                             const ShiftParams*, const int*, const int*, thr_record*, f4*,
-                             cpx*, cpx*, int);
+                             const ShiftParams*, const int*, const int*, CorrStats*, thr_record*,
+                             f4*, cpx*, cpx*, int);
 
 #ifdef THR_DEV_MINIMAL  // compile-time experiments only: one variant each, fast rebuilds
 carrier_fn carrier_variant(int, bool, bool) { return &k_carrier<THR_IN_U8, false, false>; }
@@ -914,16 +960,25 @@ hipError_t launch_fit(int n_blocks, const DevCfg& cfg, const CarStats* stats,
 hipError_t launch_correlate_16k(int fmt, const void* samples, const DevCfg& cfg,
                                 const float2* tables, const float2* twn, const float4* tspec,
                                 const ShiftParams* shifts, const int* work_list,
-                                const int* work_count, thr_record* records, float4* xhat_scratch,
+                                const int* work_count, CorrStats* corr_stats,
+                                thr_record* records, float4* xhat_scratch,
                                 float2* dump_xhat, float2* dump_corr, int dump_template, int grid,
                                 hipStream_t stream) {
     const bool dump = dump_xhat != nullptr || dump_corr != nullptr;
     correlate_fn fn = correlate_variant(fmt, cfg.cor_want_std != 0, cfg.n_templates > 1, dump);
     hipLaunchKernelGGL(fn, dim3(grid), dim3(NT), LDS_BYTES, stream, samples, cfg,
                        reinterpret_cast<const cpx*>(tables), reinterpret_cast<const cpx*>(twn),
-                       reinterpret_cast<const f4*>(tspec), shifts, work_list, work_count, records,
+                       reinterpret_cast<const f4*>(tspec), shifts, work_list, work_count,
+                       corr_stats, records,
                        reinterpret_cast<f4*>(xhat_scratch), reinterpret_cast<cpx*>(dump_xhat),
                        reinterpret_cast<cpx*>(dump_corr), dump_template);
+    return hipGetLastError();
+}
+
+hipError_t launch_finish(int n_records, const DevCfg& cfg, const CorrStats* corr_stats,
+                         thr_record* records, hipStream_t stream) {
+    hipLaunchKernelGGL(k_finish, dim3((n_records + 255) / 256), dim3(256), 0, stream, n_records,
+                       cfg, corr_stats, records);
     return hipGetLastError();
 }
 

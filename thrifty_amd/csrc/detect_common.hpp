@@ -37,6 +37,16 @@ struct CarStats {
     int pad;
 };
 
+// K_B -> K_finish, one per (block, template)
+struct CorrStats {
+    float pm2;       // |corr[pk]|^2
+    float m2[3];     // |corr[pk-1..pk+1]|^2
+    float sum_x2;    // sum |X^|^2 of the shifted spectrum (template 0's slot only)
+    float sum_mag;   // sum |corr| over [0, corr_len)   (only if cor_want_std)
+    float sum_mag2;  // sum |corr|^2 over [0, corr_len) (only if cor_want_std)
+    int pk;          // windowed first-max lag
+};
+
 // K_fit -> K_B: the frequency-shift phasor exp(2 pi i s (n/N - 1/2)), factored
 struct ShiftParams {
     float2 rpow[16];  // exp(2 pi i s j / R1), j = sub-sequence index of pass 1
@@ -57,9 +67,12 @@ hipError_t launch_fit(int n_blocks, const DevCfg& cfg, const CarStats* stats,
 hipError_t launch_correlate_16k(int fmt, const void* samples, const DevCfg& cfg,
                                 const float2* tables, const float2* twn, const float4* tspec,
                                 const ShiftParams* shifts, const int* work_list,
-                                const int* work_count, thr_record* records, float4* xhat_scratch,
+                                const int* work_count, CorrStats* corr_stats,
+                                thr_record* records, float4* xhat_scratch,
                                 float2* dump_xhat, float2* dump_corr, int dump_template, int grid,
                                 hipStream_t stream);
+hipError_t launch_finish(int n_records, const DevCfg& cfg, const CorrStats* corr_stats,
+                         thr_record* records, hipStream_t stream);
 hipError_t launch_compact(const thr_record* in, int n, thr_record* out, int* n_out,
                           hipStream_t stream);
 
