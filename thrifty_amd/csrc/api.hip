@@ -217,7 +217,6 @@ int run_batch(thr_handle* h, const void* d_samples, int format, const long long*
               float2* dump_corr, int dump_template, bool carrier_only) {
     const int grid = std::min(n_blocks, h->n_cu);
     h->prof = h->prof_every > 0 && (h->batch_no++ % h->prof_every) == 0;
-    HIP_TRY(hipMemsetAsync(h->d_work_count, 0, sizeof(int), h->stream));
     {
         ProfScope p(h, 0);
         HIP_TRY(thr::launch_carrier_16k(format, d_samples, n_blocks, h->dev, h->d_tables, h->d_stats,
@@ -239,7 +238,7 @@ int run_batch(thr_handle* h, const void* d_samples, int format, const long long*
     {
         ProfScope p(h, 3);
         HIP_TRY(thr::launch_finish(n_blocks * h->cfg.n_templates, h->dev, h->d_corr_stats, d_out,
-                                   h->stream));
+                                   h->d_work_count, h->stream));
     }
     return THR_OK;
 }
@@ -347,6 +346,7 @@ int thr_create(const thr_settings* s, thr_handle** out) {
         CREATE_TRY(hipMalloc(&h->d_corr_stats, mb * s->n_templates * sizeof(thr::CorrStats)));
         CREATE_TRY(hipMalloc(&h->d_work_list, mb * sizeof(int)));
         CREATE_TRY(hipMalloc(&h->d_work_count, sizeof(int)));
+        CREATE_TRY(hipMemset(h->d_work_count, 0, sizeof(int)));  // re-armed by k_finish
         CREATE_TRY(hipMalloc(&h->d_ncompact, sizeof(int)));
         if (s->n_templates > 1)
             CREATE_TRY(hipMalloc(&h->d_xhat_scratch, size_t(h->n_cu) * n * sizeof(float2)));

@@ -604,6 +604,25 @@ __global__ __launch_bounds__(64) void k_fit(int n_blocks, DevCfg cfg,
 // =========================================================================
 // K_B: shift + FFT#2 + matched filter + SoA
 // =========================================================================
+// Per-thread shift phasor for samples m = 2t, 2t+1: c0 * exp(2 pi i s m / N), from the
+// factored ShiftParams (integer part via the exact root table, fractional part via a
+// small-angle sincosf).
+__device__ __forceinline__ void shift_phasor(const ShiftParams* __restrict__ sp,
+                                             const cpx* __restrict__ twn, int t, cpx (&p)[2]) {
+    const int si = sp->si_mod;
+    const float sf = sp->sf_over_n;
+    const cpx c0 = cpx{sp->c0.x, sp->c0.y};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int m = 2 * t + e;
+        const int q = (si * m) & (N - 1);
+        const cpx wq = cconj(twn[q]);  // exp(+2 pi i q / N)
+        float sn, cs;
+        sincosf(6.283185307179586f * (sf * float(m)), &sn, &cs);
+        p[e] = cmul(cmul(wq, cpx{cs, sn}), c0);
+    }
+}
+
 // MULTI: more than one template -- the shifted spectrum is parked in a
 // per-workgroup global scratch row (L2-resident) instead of 64 live VGPRs.
 template <int FMT, bool WANT_STD, bool MULTI, bool DUMP>
@@ -625,35 +644,30 @@ __global__ __launch_bounds__(NT) void k_correlate(
     int parity = 0;
 
     RawSamples<FMT> cur;
+    cpx p[2] = {cpx{0.f, 0.f}, cpx{0.f, 0.f}};
     int b_next = int(blockIdx.x) < n_work ? work_list[blockIdx.x] : 0;
-    if (int(blockIdx.x) < n_work)
+    if (int(blockIdx.x) < n_work) {
         cur.load(static_cast<const unsigned char*>(samples) + size_t(b_next) * blk_bytes,
                  opaque_tid());
+        shift_phasor(shifts + b_next, twn, opaque_tid(), p);
+    }
     for (int wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
         const int b = b_next;
         const int t = opaque_tid();
         const ShiftParams* sp = shifts + b;
         // next block's samples: issued now, consumed one iteration later
         RawSamples<FMT> nxt = cur;
-        if (wi + int(gridDim.x) < n_work) {
+        const bool more = wi + int(gridDim.x) < n_work;
+        if (more) {
             b_next = work_list[wi + gridDim.x];
             nxt.load(static_cast<const unsigned char*>(samples) + size_t(b_next) * blk_bytes, t);
         }
 
-        // per-thread phasor for m = 2t, 2t+1: c0 * exp(2 pi i s m / N)
-        cpx p[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int m = 2 * t + e;
-            const int q = (sp->si_mod * m) & (N - 1);
-            const cpx wq = cconj(twn[q]);  // exp(+2 pi i q / N)
-            float sn, cs;
-            sincosf(6.283185307179586f * (sp->sf_over_n * float(m)), &sn, &cs);
-            p[e] = cmul(cmul(wq, cpx{cs, sn}), cpx{sp->c0.x, sp->c0.y});
-        }
         // (the previous block's pass-C LDS reads all precede its reduction barrier)
         fwd_pass1<FMT, true>(lds, cur, sp->rpow, p[0], p[1]);
         cur = nxt;
+        // the next block's phasor (root-table gather + sincosf) overlaps this block's passes
+        if (more) shift_phasor(shifts + b_next, twn, t, p);
         __syncthreads();
         if (cfg.ablate == 1) continue;
         // rows k1 = 2w, 2w+1 belong to wave w through passes 2, 3, A and B: no barriers
@@ -813,8 +827,10 @@ __global__ __launch_bounds__(NT) void k_correlate(
 // =========================================================================
 __global__ __launch_bounds__(256) void k_finish(int n_records, DevCfg cfg,
                                                 const CorrStats* __restrict__ corr_stats,
-                                                thr_record* __restrict__ records) {
+                                                thr_record* __restrict__ records,
+                                                int* __restrict__ work_count) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *work_count = 0;  // k_correlate is done with it: re-arm for the next batch
     if (i >= n_records) return;
     thr_record* r = records + i;
     if (!(r->flags & THR_FLAG_CARRIER)) return;
@@ -976,9 +992,9 @@ hipError_t launch_correlate_16k(int fmt, const void* samples, const DevCfg& cfg,
 }
 
 hipError_t launch_finish(int n_records, const DevCfg& cfg, const CorrStats* corr_stats,
-                         thr_record* records, hipStream_t stream) {
+                         thr_record* records, int* work_count, hipStream_t stream) {
     hipLaunchKernelGGL(k_finish, dim3((n_records + 255) / 256), dim3(256), 0, stream, n_records,
-                       cfg, corr_stats, records);
+                       cfg, corr_stats, records, work_count);
     return hipGetLastError();
 }
 

@@ -72,7 +72,7 @@ hipError_t launch_correlate_16k(int fmt, const void* samples, const DevCfg& cfg,
                                 float2* dump_xhat, float2* dump_corr, int dump_template, int grid,
                                 hipStream_t stream);
 hipError_t launch_finish(int n_records, const DevCfg& cfg, const CorrStats* corr_stats,
-                         thr_record* records, hipStream_t stream);
+                         thr_record* records, int* work_count, hipStream_t stream);
 hipError_t launch_compact(const thr_record* in, int n, thr_record* out, int* n_out,
                           hipStream_t stream);
 
