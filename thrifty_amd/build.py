@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libthriftyhip.so")
-SOURCES = ["api.hip", "detect16k.hip"]
+SOURCES = ["api.hip", "detect16k.hip", "generic.hip"]
 HEADERS = ["detect_common.hpp", "fft_regs.hpp", os.path.join("..", "..", "include", "thrifty_hip.h")]
 
 

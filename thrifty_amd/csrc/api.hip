@@ -80,6 +80,10 @@ struct thr_handle {
     thr::DevCfg dev{};
     int device = 0;
     int n_cu = 0;
+    bool fast = false;       // LDS-resident 16384 kernels; else the generic multi-pass path
+    int gen_batch = 0;       // generic path: blocks per internal sub-batch
+    float2* d_gen_scratch = nullptr;  // generic path: 3 * gen_batch * N complex
+    float2* d_tspec_nat = nullptr;    // generic path: conj(FFT(template))/N, natural order
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     // constants
@@ -154,7 +158,7 @@ int window_indices(int start, int stop, int n, int* lo, int* count) {
 
 int build_constants(thr_handle* h) {
     const int n = h->cfg.block_len;
-    // --- LDS twiddle tables (forward sign): C[32][32], A[16][32], Bt[16][32]
+    // --- LDS twiddle tables (forward sign): C[32][32], A[16][32], Bt[16][32]  (fast path)
     std::vector<float2> tab(2048);
     for (int a = 0; a < 32; ++a)
         for (int b = 0; b < 32; ++b) tab[a * 32 + b] = unit_root((long long)a * b, 1024);
@@ -184,15 +188,28 @@ int build_constants(thr_handle* h) {
         h->dev.tmpl_energy[t] = float(energy);
         host_fft(buf);
         float2* out = spec.data() + size_t(t) * n;
-        for (int tid = 0; tid < 512; ++tid)
-            for (int k3 = 0; k3 < 32; ++k3) {
-                const int k = (tid >> 5) + 16 * (tid & 31) + 512 * k3;
+        if (h->fast) {
+            for (int tid = 0; tid < 512; ++tid)
+                for (int k3 = 0; k3 < 32; ++k3) {
+                    const int k = (tid >> 5) + 16 * (tid & 31) + 512 * k3;
+                    const std::complex<double> c = std::conj(buf[k]) / double(n);
+                    out[((k3 >> 1) * 512 + tid) * 2 + (k3 & 1)] =
+                        float2{float(c.real()), float(c.imag())};
+                }
+        } else {
+            for (int k = 0; k < n; ++k) {
                 const std::complex<double> c = std::conj(buf[k]) / double(n);
-                out[((k3 >> 1) * 512 + tid) * 2 + (k3 & 1)] = float2{float(c.real()), float(c.imag())};
+                out[k] = float2{float(c.real()), float(c.imag())};
             }
+        }
     }
-    HIP_TRY(hipMalloc(&h->d_tspec, spec.size() * sizeof(float2)));
-    HIP_TRY(hipMemcpy(h->d_tspec, spec.data(), spec.size() * sizeof(float2), hipMemcpyHostToDevice));
+    float2* d_spec = nullptr;
+    HIP_TRY(hipMalloc(&d_spec, spec.size() * sizeof(float2)));
+    HIP_TRY(hipMemcpy(d_spec, spec.data(), spec.size() * sizeof(float2), hipMemcpyHostToDevice));
+    if (h->fast)
+        h->d_tspec = reinterpret_cast<float4*>(d_spec);
+    else
+        h->d_tspec_nat = d_spec;
     return THR_OK;
 }
 
@@ -212,9 +229,9 @@ int ensure_staging(thr_handle* h, int format) {
     return THR_OK;
 }
 
-int run_batch(thr_handle* h, const void* d_samples, int format, const long long* d_block_idx,
-              int n_blocks, thr_record* d_out, float2* dump_fft, float2* dump_xhat,
-              float2* dump_corr, int dump_template, bool carrier_only) {
+int run_batch_fast(thr_handle* h, const void* d_samples, int format,
+                   const long long* d_block_idx, int n_blocks, thr_record* d_out, float2* dump_fft,
+                   float2* dump_xhat, float2* dump_corr, int dump_template, bool carrier_only) {
     const int grid = std::min(n_blocks, h->n_cu);
     h->prof = h->prof_every > 0 && (h->batch_no++ % h->prof_every) == 0;
     {
@@ -243,6 +260,65 @@ int run_batch(thr_handle* h, const void* d_samples, int format, const long long*
     return THR_OK;
 }
 
+// Generic block lengths: multi-pass pipeline through HBM, in sub-batches of gen_batch blocks.
+// The dump_* pointers (debug only) receive copies of the natural-order intermediates.
+int run_batch_generic(thr_handle* h, const void* d_samples, int format,
+                      const long long* d_block_idx, int n_blocks, thr_record* d_out,
+                      float2* dump_fft, float2* dump_xhat, float2* dump_corr, int dump_template,
+                      bool carrier_only) {
+    const size_t n = size_t(h->cfg.block_len), T = size_t(h->cfg.n_templates);
+    const size_t blk_bytes = n * (format == THR_IN_U8 ? 2 : 8);
+    h->prof = h->prof_every > 0 && (h->batch_no++ % h->prof_every) == 0;
+    for (int off = 0; off < n_blocks; off += h->gen_batch) {
+        const int nb = std::min(h->gen_batch, n_blocks - off);
+        const void* in = static_cast<const unsigned char*>(d_samples) + size_t(off) * blk_bytes;
+        thr_record* out = d_out + size_t(off) * T;
+        float2* spectrum = nullptr;
+        {
+            ProfScope p(h, 0);
+            HIP_TRY(thr::generic_carrier(format, in, nb, h->dev, h->d_twn, h->d_gen_scratch,
+                                         h->d_stats, &spectrum, h->stream));
+        }
+        if (dump_fft)
+            HIP_TRY(hipMemcpyAsync(dump_fft + size_t(off) * n, spectrum, size_t(nb) * n * sizeof(float2),
+                                   hipMemcpyDeviceToDevice, h->stream));
+        if (carrier_only) continue;
+        {
+            ProfScope p(h, 1);
+            HIP_TRY(thr::launch_fit(nb, h->dev, h->d_stats, d_block_idx ? d_block_idx + off : nullptr,
+                                    h->d_shifts, h->d_work_list, h->d_work_count, out, h->stream));
+        }
+        float2 *xh = nullptr, *cc = nullptr;
+        {
+            ProfScope p(h, 2);
+            HIP_TRY(thr::generic_correlate(format, in, nb, h->dev, h->d_twn, h->d_tspec_nat,
+                                           h->d_shifts, out, h->d_gen_scratch, h->d_corr_stats,
+                                           dump_template, dump_xhat ? &xh : nullptr,
+                                           dump_corr ? &cc : nullptr, h->stream));
+        }
+        if (dump_xhat && xh)
+            HIP_TRY(hipMemcpyAsync(dump_xhat + size_t(off) * n, xh, size_t(nb) * n * sizeof(float2),
+                                   hipMemcpyDeviceToDevice, h->stream));
+        if (dump_corr && cc)
+            HIP_TRY(hipMemcpyAsync(dump_corr + size_t(off) * n, cc, size_t(nb) * n * sizeof(float2),
+                                   hipMemcpyDeviceToDevice, h->stream));
+        {
+            ProfScope p(h, 3);
+            HIP_TRY(thr::launch_finish(nb * int(T), h->dev, h->d_corr_stats, out, h->d_work_count,
+                                       h->stream));
+        }
+    }
+    return THR_OK;
+}
+
+int run_batch(thr_handle* h, const void* d_samples, int format, const long long* d_block_idx,
+              int n_blocks, thr_record* d_out, float2* dump_fft, float2* dump_xhat,
+              float2* dump_corr, int dump_template, bool carrier_only) {
+    return (h->fast ? run_batch_fast : run_batch_generic)(h, d_samples, format, d_block_idx, n_blocks,
+                                                          d_out, dump_fft, dump_xhat, dump_corr,
+                                                          dump_template, carrier_only);
+}
+
 }  // namespace
 
 extern "C" {
@@ -261,9 +337,8 @@ int thr_create(const thr_settings* s, thr_handle** out) {
     *out = nullptr;
     const int n = s->block_len;
     if (n <= 0 || (n & (n - 1))) return fail(THR_ERR_ARG, "block_len %d is not a power of two", n);
-    if (n != 16384)
-        return fail(THR_ERR_ARG,
-                    "block_len %d not supported by this build (LDS-resident path: 16384 only)", n);
+    if (n < 64 || n > (1 << 20))
+        return fail(THR_ERR_ARG, "block_len %d out of range [64, 1048576]", n);
     if (s->n_templates < 1 || s->n_templates > thr::kMaxTemplates)
         return fail(THR_ERR_ARG, "n_templates %d out of range [1, %d]", s->n_templates,
                     thr::kMaxTemplates);
@@ -284,6 +359,7 @@ int thr_create(const thr_settings* s, thr_handle** out) {
     h->cfg = *s;
     h->cfg.templates = nullptr;  // not retained beyond this call (re-pointed below)
     h->device = s->device_id;
+    h->fast = (n == 16384) && getenv("THR_FORCE_GENERIC") == nullptr;
     int rc = THR_OK;
     do {
         if (hipSetDevice(h->device) != hipSuccess) {
@@ -296,7 +372,7 @@ int thr_create(const thr_settings* s, thr_handle** out) {
             break;
         }
         h->n_cu = prop.multiProcessorCount;
-        if (size_t(prop.maxSharedMemoryPerMultiProcessor) < thr::lds_bytes_16k()) {
+        if (h->fast && size_t(prop.maxSharedMemoryPerMultiProcessor) < thr::lds_bytes_16k()) {
             rc = fail(THR_ERR_DEVICE, "device has %zu B LDS per CU, need %zu",
                       size_t(prop.maxSharedMemoryPerMultiProcessor), thr::lds_bytes_16k());
             break;
@@ -337,7 +413,14 @@ int thr_create(const thr_settings* s, thr_handle** out) {
         rc = fail(THR_ERR_DEVICE, "%s failed (%s)", #expr, hipGetErrorString(hipGetLastError())); \
         break;                                                                        \
     }
-        CREATE_TRY(thr::prepare_16k());
+        if (h->fast) CREATE_TRY(thr::prepare_16k());
+        if (!h->fast) {
+            // sub-batch so that the 3 ping-pong buffers stay near 256 MiB (Infinity-Cache sized)
+            const size_t per_block = size_t(3) * n * sizeof(float2);
+            h->gen_batch = int(std::max<size_t>(1, std::min<size_t>(size_t(s->max_batch),
+                                                                    (size_t(256) << 20) / per_block)));
+            CREATE_TRY(hipMalloc(&h->d_gen_scratch, thr::generic_scratch_bytes(n, h->gen_batch)));
+        }
         CREATE_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
         h->stream = h->own_stream;
         const size_t mb = size_t(s->max_batch);
@@ -348,7 +431,7 @@ int thr_create(const thr_settings* s, thr_handle** out) {
         CREATE_TRY(hipMalloc(&h->d_work_count, sizeof(int)));
         CREATE_TRY(hipMemset(h->d_work_count, 0, sizeof(int)));  // re-armed by k_finish
         CREATE_TRY(hipMalloc(&h->d_ncompact, sizeof(int)));
-        if (s->n_templates > 1)
+        if (h->fast && s->n_templates > 1)
             CREATE_TRY(hipMalloc(&h->d_xhat_scratch, size_t(h->n_cu) * n * sizeof(float2)));
 #undef CREATE_TRY
     } while (0);
@@ -370,7 +453,7 @@ void thr_destroy(thr_handle* h) {
         hipEventDestroy(e.a);
         hipEventDestroy(e.b);
     }
-    void* bufs[] = {h->d_tables, h->d_twn, h->d_tspec, h->d_stats, h->d_shifts, h->d_corr_stats, h->d_work_list,
+    void* bufs[] = {h->d_tables, h->d_twn, h->d_tspec, h->d_stats, h->d_shifts, h->d_corr_stats, h->d_gen_scratch, h->d_tspec_nat, h->d_work_list,
                     h->d_work_count, h->d_xhat_scratch, h->d_ncompact, h->d_in, h->d_idx, h->d_rec};
     for (void* b : bufs)
         if (b) hipFree(b);

@@ -556,7 +556,7 @@ __global__ __launch_bounds__(64) void k_fit(int n_blocks, DevCfg cfg,
         // shift = -(bin + offset)  (carrier_sync.py:71)
         const double s = -(double(peak_idx) + offset);
         const double si = rint(s);
-        const int r1 = n / 1024;  // first-pass radix: phasor step between sub-sequences
+        const int r1 = n >= 1024 ? n / 1024 : 1;  // first-pass radix of the LDS path (unused otherwise)
         ShiftParams* sp = shifts + b;
         if (valid) {
 #pragma unroll

@@ -76,4 +76,15 @@ hipError_t launch_finish(int n_records, const DevCfg& cfg, const CorrStats* corr
 hipError_t launch_compact(const thr_record* in, int n, thr_record* out, int* n_out,
                           hipStream_t stream);
 
+// generic.hip (any power-of-two block length; multi-pass through HBM)
+size_t generic_scratch_bytes(int n, int n_blocks);
+hipError_t generic_carrier(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,
+                           const float2* twn, float2* scratch, CarStats* stats, float2** spectrum,
+                           hipStream_t stream);
+hipError_t generic_correlate(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,
+                             const float2* twn, const float2* tspec_nat,
+                             const ShiftParams* shifts, const thr_record* records, float2* scratch,
+                             CorrStats* corr_stats, int dump_template, float2** keep_xhat,
+                             float2** keep_corr, hipStream_t stream);
+
 }  // namespace thr
