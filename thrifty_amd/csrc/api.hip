@@ -401,6 +401,8 @@ int thr_create(const thr_settings* s, thr_handle** out) {
         }
         d.ablate = getenv("THR_ABLATE") ? atoi(getenv("THR_ABLATE")) : 0;
         d.car_want_std = s->carrier_thresh[2] != 0.0;
+        d.car_prune = !d.car_want_std && d.win_lo >= 3 && d.win_lo + d.win_count + 3 <= 128 &&
+                      getenv("THR_NO_PRUNE") == nullptr;
         d.cor_want_std = s->corr_thresh[2] != 0.0;
 
         h->cfg.templates = s->templates;

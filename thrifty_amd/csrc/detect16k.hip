@@ -178,18 +178,22 @@ struct RawSamples<THR_IN_C64> {
 // If PH: pre-rotate x[n1] by rpow[n1] and fold the per-m phasor p0/p1 into the twiddle.
 template <int FMT, bool PH>
 __device__ __forceinline__ void fwd_pass1(cpx* lds, const RawSamples<FMT>& raw,
-                                          const float2* __restrict__ rpow, cpx p0, cpx p1) {
+                                          const float2* __restrict__ rpow, cpx p0, cpx p1,
+                                          float* energy = nullptr) {
     const int t = opaque_tid();
     cpx v0[R1], v1[R1];
+    float e = 0.f;
 #pragma unroll
     for (int n1 = 0; n1 < R1; ++n1) {
         raw.get(n1, v0[n1], v1[n1]);
+        if (energy != nullptr) e += cnorm(v0[n1]) + cnorm(v1[n1]);  // time-domain sum |x|^2
         if constexpr (PH) {
             const cpx r = cpx{rpow[n1].x, rpow[n1].y};
             v0[n1] = cmul(v0[n1], r);
             v1[n1] = cmul(v1[n1], r);
         }
     }
+    if (energy != nullptr) *energy = e;
     dft_dif<R1, -1>(v0);
     dft_dif<R1, -1>(v1);
     const int n2 = t >> 4, mp = 2 * (t & 15);
@@ -222,6 +226,8 @@ __device__ __forceinline__ void fwd_pass1(cpx* lds, const RawSamples<FMT>& raw,
 }
 
 // Pass 2 (radix 32 over n2, in place) -- thread (k1 = t>>5, m' = t&31).
+// KEEP < 32: only outputs k2 < KEEP are written back (pruned FFT: bins k2 >= KEEP unused).
+template <int KEEP = R2>
 __device__ __forceinline__ void fwd_pass2(cpx* lds) {
     const int t = opaque_tid();
     const int k1 = t >> 5, mp = t & 31;
@@ -231,7 +237,7 @@ __device__ __forceinline__ void fwd_pass2(cpx* lds) {
 #pragma unroll
     for (int n2 = 0; n2 < R2; ++n2) v[n2] = base[n2 * CHUNK];
     dft_dif<R2, -1>(v);
-    static_for<R2>([&](auto K) {
+    static_for<KEEP>([&](auto K) {
         constexpr int k2 = decltype(K)::value;
         cpx y = v[brev(k2, R2)];
         if constexpr (k2 != 0) y = cmul(y, tC[k2 * 32]);
@@ -413,6 +419,82 @@ __global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples
         if (t == 0) {
             st->sum_mag2 = (float)tot[0];
             st->sum_mag = WANT_STD ? (float)tot[1] : 0.f;
+            st->peak_mag = sqrtf(__uint_as_float(unsigned(best >> 32)));
+            st->peak_idx = peak_idx;
+            st->pad = 0;
+        }
+    }
+}
+
+// =========================================================================
+// K_A, pruned: carrier window (plus the 3-bin fit margin) inside bins [0, 128)
+// =========================================================================
+// The carrier stage only ever looks at the bins of the window, +-3 neighbours for the
+// fit, and at sum |X|^2.  With the window inside [0,128) the needed bins are
+// k = k1 + 16*k2 with k2 < 8 and k3 = 0: pass 2 keeps 8 of its 32 outputs, pass 3
+// degenerates to a 32-term sum in 128 threads, and sum |X|^2 = N * sum |x|^2 (Parseval)
+// comes from the samples pass 1 already holds.  (Not usable with a stddev threshold
+// term, which needs every |X|: the launcher then picks the full kernel.)
+constexpr int PRUNE_K2 = 8;
+constexpr int PRUNE_BINS = R1 * PRUNE_K2;  // 128
+
+template <int FMT>
+__global__ __launch_bounds__(NT) void k_carrier_pruned(const void* __restrict__ samples,
+                                                       int n_blocks, DevCfg cfg,
+                                                       const cpx* __restrict__ tables,
+                                                       CarStats* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cpx* lds = reinterpret_cast<cpx*>(smem_raw);
+    unsigned char* sc_red = reinterpret_cast<unsigned char*>(lds + OFF_S);
+    float* sc_bins = reinterpret_cast<float*>(sc_red + 2 * RED_SLOT_BYTES);  // [128] |X[k]|^2
+
+    load_tables(lds, tables);
+    __syncthreads();
+    const size_t blk_bytes = size_t(N) * (FMT == THR_IN_U8 ? 2 : 8);
+    int parity = 0;
+
+    RawSamples<FMT> cur;
+    if (int(blockIdx.x) < n_blocks)
+        cur.load(static_cast<const unsigned char*>(samples) + size_t(blockIdx.x) * blk_bytes,
+                 opaque_tid());
+    for (int b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+        RawSamples<FMT> nxt = cur;
+        if (b + int(gridDim.x) < n_blocks)
+            nxt.load(static_cast<const unsigned char*>(samples) + size_t(b + gridDim.x) * blk_bytes,
+                     opaque_tid());
+        float sums[1];
+        fwd_pass1<FMT, false>(lds, cur, nullptr, cpx{}, cpx{}, &sums[0]);
+        cur = nxt;
+        __syncthreads();
+        fwd_pass2<PRUNE_K2>(lds);
+        __builtin_amdgcn_sched_barrier(0);
+        // pass 3, output k3 = 0 only: the plain sum of the chunk; threads with k2 < 8
+        const int t = opaque_tid();
+        const int k2 = t & 31;
+        const int k = (t >> 5) + 16 * k2;  // bin index (valid when k2 < PRUNE_K2)
+        unsigned long long best = 0;
+        if (k2 < PRUNE_K2) {
+            const f4* src = reinterpret_cast<const f4*>(lds + (t >> 5) * ROW + k2 * CHUNK);
+            f4 acc = src[0];
+#pragma unroll
+            for (int j = 1; j < R3 / 2; ++j) acc += src[j];
+            const cpx x = cpx{acc.x + acc.z, acc.y + acc.w};
+            const float p = cnorm(x);
+            sc_bins[k] = p;
+            const unsigned wi = unsigned(k - cfg.win_lo) & unsigned(N - 1);
+            if (wi < unsigned(cfg.win_count))
+                best = ((unsigned long long)__float_as_uint(p) << 32) | (0xFFFFFFFFu - wi);
+        }
+        double tot[1];
+        block_reduce<1>(sums, tot, best, sc_red, parity);
+        parity ^= 1;
+        const unsigned wi = 0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu);
+        const int peak_idx = int(wi) + cfg.win_lo;  // < 128: the '> N' wrap cannot trigger
+        CarStats* st = stats + b;
+        if (t < 7) st->nb[t] = sqrtf(sc_bins[peak_idx - 3 + t]);
+        if (t == 0) {
+            st->sum_mag2 = (float)(tot[0] * double(N));  // Parseval
+            st->sum_mag = 0.f;
             st->peak_mag = sqrtf(__uint_as_float(unsigned(best >> 32)));
             st->peak_idx = peak_idx;
             st->pad = 0;
@@ -939,6 +1021,11 @@ correlate_fn correlate_variant(int fmt, bool want_std, bool multi, bool dump) {
 
 hipError_t prepare_16k() {
     // > 64 KiB of dynamic LDS must be opted into, per device and per kernel variant
+    for (const void* f : {reinterpret_cast<const void*>(&k_carrier_pruned<THR_IN_U8>),
+                          reinterpret_cast<const void*>(&k_carrier_pruned<THR_IN_C64>)}) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e != hipSuccess) return e;
+    }
     for (int fmt = 0; fmt < 2; ++fmt)
         for (int st = 0; st < 2; ++st)
             for (int d = 0; d < 2; ++d) {
@@ -959,6 +1046,15 @@ hipError_t prepare_16k() {
 hipError_t launch_carrier_16k(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,
                               const float2* tables, CarStats* stats, float2* dump_fft, int grid,
                               hipStream_t stream) {
+    if (cfg.car_prune && dump_fft == nullptr) {
+        if (fmt == THR_IN_U8)
+            hipLaunchKernelGGL(k_carrier_pruned<THR_IN_U8>, dim3(grid), dim3(NT), LDS_BYTES, stream,
+                               samples, n_blocks, cfg, reinterpret_cast<const cpx*>(tables), stats);
+        else
+            hipLaunchKernelGGL(k_carrier_pruned<THR_IN_C64>, dim3(grid), dim3(NT), LDS_BYTES, stream,
+                               samples, n_blocks, cfg, reinterpret_cast<const cpx*>(tables), stats);
+        return hipGetLastError();
+    }
     carrier_fn fn = carrier_variant(fmt, cfg.car_want_std != 0, dump_fft != nullptr);
     hipLaunchKernelGGL(fn, dim3(grid), dim3(NT), LDS_BYTES, stream, samples, n_blocks, cfg,
                        reinterpret_cast<const cpx*>(tables), stats, reinterpret_cast<cpx*>(dump_fft));

@@ -24,6 +24,7 @@ struct DevCfg {
     float car_thr[3];
     float cor_thr[3];
     float tmpl_energy[kMaxTemplates];  // sum t^2 (soa_estimator.py:65)
+    int car_prune;     // carrier window + fit margin inside bins [0,128): pruned FFT#1 (16384 path)
     int ablate;        // dev only (THR_ABLATE): stop each block after phase n; 0 = off
 };
 
