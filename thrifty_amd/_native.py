@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libthriftyhip.so")
+LIB_PATH = os.environ.get("THRIFTY_HIP_LIB") or os.path.join(HERE, "libthriftyhip.so")  # env: A/B builds
 
 THR_IN_U8 = 0
 THR_IN_C64 = 1

@@ -41,7 +41,8 @@ def build_native(force=False, verbose=False):
         # -fno-slp-vectorize: the kernels are hand-vectorised with ext-vector float2;
         # the SLP vectorizer only adds v_mov shuffles (see csrc/fft_regs.hpp)
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
-               "-fno-slp-vectorize", "-c", os.path.join(CSRC, src), "-o", obj]
+               "-fno-slp-vectorize"] + os.environ.get("THR_EXTRA_CFLAGS", "").split() + [
+               "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

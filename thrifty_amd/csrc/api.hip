@@ -399,6 +399,12 @@ int thr_create(const thr_settings* s, thr_handle** out) {
             d.car_thr[i] = float(s->carrier_thresh[i]);
             d.cor_thr[i] = float(s->corr_thresh[i]);
         }
+        d.timeline = nullptr;
+#ifdef THR_TIMELINE
+        if (hipMalloc(&d.timeline, 128 * sizeof(unsigned long long)) == hipSuccess)
+            hipMemset(d.timeline, 0, 128 * sizeof(unsigned long long));
+#endif
+        d.prio_mode = getenv("THR_PRIO") ? atoi(getenv("THR_PRIO")) : 1;
         d.ablate = getenv("THR_ABLATE") ? atoi(getenv("THR_ABLATE")) : 0;
         d.car_want_std = s->carrier_thresh[2] != 0.0;
         d.car_prune = !d.car_want_std && d.win_lo >= 3 && d.win_lo + d.win_count + 3 <= 128 &&
@@ -564,6 +570,15 @@ int thr_profile_read(thr_handle* h, double ms[THR_N_KERNEL_SLOTS],
     }
     return THR_OK;
 }
+
+#ifdef THR_TIMELINE
+int thr_debug_timeline(thr_handle* h, unsigned long long* out128) {
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    return hipMemcpy(out128, h->dev.timeline, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost) ==
+                   hipSuccess ? 0 : -2;
+}
+#endif
 
 int thr_debug_fft(thr_handle* h, const void* samples, int format, size_t n_blocks,
                   float* spectra_out) {

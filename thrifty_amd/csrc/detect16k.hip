@@ -50,6 +50,22 @@ __device__ __forceinline__ int opaque_tid() {
     return t;
 }
 
+// Dev-only cycle timeline (-DTHR_TIMELINE): workgroup 0 records s_memtime at phase
+// boundaries of its 4th block, one row of 16 stamps per wave, into cfg.timeline.
+#ifdef THR_TIMELINE
+#define THR_STAMP(slot)                                                                   \
+    do {                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        if (tl_on) {                                                                      \
+            const unsigned long long _t = __builtin_amdgcn_s_memtime();                   \
+            if ((threadIdx.x & 63) == 0) cfg.timeline[(threadIdx.x >> 6) * 16 + (slot)] = _t; \
+        }                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+    } while (0)
+#else
+#define THR_STAMP(slot) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------- reductions
 // Wave-level reductions on the VALU's DPP path (row_shr 1/2/4/8 inside each 16-lane
 // row, then row_bcast15 / row_bcast31 across rows): ~10 VALU ops instead of six
@@ -334,6 +350,10 @@ __global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples
 
     load_tables(lds, tables);
     __syncthreads();
+    // waves w and w+4 share a SIMD and the older one wins VALU arbitration: without this the
+    // younger half runs every phase ~35 % slower and the older half idles at the barriers
+    if (cfg.prio_mode == 1 && threadIdx.x >= NT / 2) __builtin_amdgcn_s_setprio(1);
+    if (cfg.prio_mode == 2 && threadIdx.x < NT / 2) __builtin_amdgcn_s_setprio(1);
     const size_t blk_bytes = size_t(N) * (FMT == THR_IN_U8 ? 2 : 8);
     int parity = 0;
 
@@ -371,8 +391,12 @@ __global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples
         const int t = opaque_tid();
         const int kbase = (t >> 5) + 16 * (t & 31);
         float sums[2] = {0.f, 0.f};
-        unsigned long long best = 0;
         float pw[R3];
+        // first-max inside the (wrapping) window: lowest window index wins ties, and this
+        // thread's bins are visited in increasing k, which is increasing window index except
+        // across the wrap -- so compare (p, wi) lexicographically via '>' / '==' + '<'
+        float bestp = -1.0f;
+        unsigned bestwi = 0;
         static_for<R3>([&](auto K) {
             constexpr int k3 = decltype(K)::value;
             const float p = cnorm(v[brev(k3, R3)]);
@@ -380,12 +404,14 @@ __global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples
             sums[0] += p;
             if constexpr (WANT_STD) sums[1] += __builtin_amdgcn_sqrtf(p);
             const unsigned wi = unsigned(kbase + 512 * k3 - cfg.win_lo) & unsigned(N - 1);
-            if (wi < unsigned(cfg.win_count)) {
-                const unsigned long long key =
-                    ((unsigned long long)__float_as_uint(p) << 32) | (0xFFFFFFFFu - wi);
-                best = key > best ? key : best;
-            }
+            const bool take = wi < unsigned(cfg.win_count) &&
+                              (p > bestp || (p == bestp && wi < bestwi));
+            bestp = take ? p : bestp;
+            bestwi = take ? wi : bestwi;
         });
+        unsigned long long best =
+            bestp < 0.f ? 0ull
+                        : ((unsigned long long)__float_as_uint(bestp) << 32) | (0xFFFFFFFFu - bestwi);
         double tot[2];
         block_reduce<WANT_STD ? 2 : 1>(reinterpret_cast<float(&)[WANT_STD ? 2 : 1]>(sums),
                                        reinterpret_cast<double(&)[WANT_STD ? 2 : 1]>(tot), best,
@@ -450,6 +476,10 @@ __global__ __launch_bounds__(NT) void k_carrier_pruned(const void* __restrict__ 
 
     load_tables(lds, tables);
     __syncthreads();
+    // waves w and w+4 share a SIMD and the older one wins VALU arbitration: without this the
+    // younger half runs every phase ~35 % slower and the older half idles at the barriers
+    if (cfg.prio_mode == 1 && threadIdx.x >= NT / 2) __builtin_amdgcn_s_setprio(1);
+    if (cfg.prio_mode == 2 && threadIdx.x < NT / 2) __builtin_amdgcn_s_setprio(1);
     const size_t blk_bytes = size_t(N) * (FMT == THR_IN_U8 ? 2 : 8);
     int parity = 0;
 
@@ -721,6 +751,10 @@ __global__ __launch_bounds__(NT) void k_correlate(
 
     load_tables(lds, tables);
     __syncthreads();
+    // waves w and w+4 share a SIMD and the older one wins VALU arbitration: without this the
+    // younger half runs every phase ~35 % slower and the older half idles at the barriers
+    if (cfg.prio_mode == 1 && threadIdx.x >= NT / 2) __builtin_amdgcn_s_setprio(1);
+    if (cfg.prio_mode == 2 && threadIdx.x < NT / 2) __builtin_amdgcn_s_setprio(1);
     const size_t blk_bytes = size_t(N) * (FMT == THR_IN_U8 ? 2 : 8);
     const int n_work = *work_count;
     int parity = 0;
@@ -728,12 +762,18 @@ __global__ __launch_bounds__(NT) void k_correlate(
     RawSamples<FMT> cur;
     cpx p[2] = {cpx{0.f, 0.f}, cpx{0.f, 0.f}};
     int b_next = int(blockIdx.x) < n_work ? work_list[blockIdx.x] : 0;
+    // work-list entry two iterations ahead, so the sample prefetch never waits on an index load
+    int b_next2 = int(blockIdx.x + gridDim.x) < n_work ? work_list[blockIdx.x + gridDim.x] : 0;
     if (int(blockIdx.x) < n_work) {
         cur.load(static_cast<const unsigned char*>(samples) + size_t(b_next) * blk_bytes,
                  opaque_tid());
         shift_phasor(shifts + b_next, twn, opaque_tid(), p);
     }
     for (int wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+#ifdef THR_TIMELINE
+        const bool tl_on = blockIdx.x == 0 && wi == 3 * int(gridDim.x) && cfg.timeline != nullptr;
+#endif
+        THR_STAMP(0);
         const int b = b_next;
         const int t = opaque_tid();
         const ShiftParams* sp = shifts + b;
@@ -741,24 +781,31 @@ __global__ __launch_bounds__(NT) void k_correlate(
         RawSamples<FMT> nxt = cur;
         const bool more = wi + int(gridDim.x) < n_work;
         if (more) {
-            b_next = work_list[wi + gridDim.x];
+            b_next = b_next2;
             nxt.load(static_cast<const unsigned char*>(samples) + size_t(b_next) * blk_bytes, t);
+            if (wi + 2 * int(gridDim.x) < n_work) b_next2 = work_list[wi + 2 * gridDim.x];
         }
 
+        THR_STAMP(1);
         // (the previous block's pass-C LDS reads all precede its reduction barrier)
         fwd_pass1<FMT, true>(lds, cur, sp->rpow, p[0], p[1]);
         cur = nxt;
+        THR_STAMP(2);
         // the next block's phasor (root-table gather + sincosf) overlaps this block's passes
         if (more) shift_phasor(shifts + b_next, twn, t, p);
+        THR_STAMP(3);
         __syncthreads();
-        if (cfg.ablate == 1) continue;
+        THR_STAMP(4);
+        if (cfg.ablate == 11) continue;
         // rows k1 = 2w, 2w+1 belong to wave w through passes 2, 3, A and B: no barriers
         fwd_pass2(lds);
         __builtin_amdgcn_sched_barrier(0);  // keep the passes' register working sets apart
-        if (cfg.ablate == 2) { __syncthreads(); continue; }
+        THR_STAMP(5);
+        if (cfg.ablate == 12) { __syncthreads(); continue; }
         cpx xh[R3];
         fwd_pass3(lds, xh);
-        if (cfg.ablate == 3) {
+        THR_STAMP(6);
+        if (cfg.ablate == 13) {
             float acc = 0;
 #pragma unroll
             for (int i = 0; i < R3; ++i) acc += xh[i].x + xh[i].y;
@@ -817,13 +864,17 @@ __global__ __launch_bounds__(NT) void k_correlate(
             // tpl > 0, rows whose pass-C readers are behind the previous reduction barrier)
             inv_passA(lds, z);
             __builtin_amdgcn_sched_barrier(0);
-            if (cfg.ablate == 4) { __syncthreads(); continue; }
+            THR_STAMP(7);
+            if (cfg.ablate == 14) { __syncthreads(); continue; }
             inv_passB(lds);
+            THR_STAMP(8);
             __syncthreads();
-            if (cfg.ablate == 5) continue;
+            THR_STAMP(9);
+            if (cfg.ablate == 15) continue;
             cpx c0[R1], c1[R1];
             inv_passC(lds, c0, c1);
-            if (cfg.ablate == 6) {
+            THR_STAMP(10);
+            if (cfg.ablate == 16) {
                 float acc = 0;
 #pragma unroll
                 for (int i = 0; i < R1; ++i) acc += c0[i].x + c0[i].y + c1[i].x + c1[i].y;
@@ -833,9 +884,13 @@ __global__ __launch_bounds__(NT) void k_correlate(
             }
 
             // ---- |corr|^2, windowed first-max, optional std sums
-            unsigned long long best = 0;
+            // per-thread first-max in float (lags visited in increasing n, strict '>'), one
+            // 64-bit key per thread only for the cross-lane reduction
             float sums[3] = {tpl == 0 ? e2 : 0.f, 0.f, 0.f};
             float pw0[R1], pw1[R1];
+            float bestp = -1.0f;
+            int bestn = 0;
+            const unsigned win_w = unsigned(cfg.corr_hi - cfg.corr_lo);
             static_for<R1>([&](auto K) {
                 constexpr int n1 = decltype(K)::value;
                 pw0[n1] = cnorm(c0[brev(n1, R1)]);
@@ -844,12 +899,9 @@ __global__ __launch_bounds__(NT) void k_correlate(
                 for (int e = 0; e < 2; ++e) {
                     const int n = n1 * S1 + 2 * t + e;
                     const float pw = e ? pw1[n1] : pw0[n1];
-                    if (n >= cfg.corr_lo && n < cfg.corr_hi) {
-                        const unsigned long long key =
-                            ((unsigned long long)__float_as_uint(pw) << 32) |
-                            (0xFFFFFFFFu - unsigned(n));
-                        best = key > best ? key : best;
-                    }
+                    const bool take = unsigned(n - cfg.corr_lo) < win_w && pw > bestp;
+                    bestp = take ? pw : bestp;
+                    bestn = take ? n : bestn;
                     if constexpr (WANT_STD) {
                         if (n < cfg.corr_len) {
                             sums[2] += pw;
@@ -858,10 +910,16 @@ __global__ __launch_bounds__(NT) void k_correlate(
                     }
                 }
             });
+            unsigned long long best =
+                bestp < 0.f ? 0ull
+                            : ((unsigned long long)__float_as_uint(bestp) << 32) |
+                                  (0xFFFFFFFFu - unsigned(bestn));
             constexpr int NS = WANT_STD ? 3 : 1;
             double tot[3] = {0, 0, 0};
+            THR_STAMP(11);
             block_reduce<NS>(reinterpret_cast<float(&)[NS]>(sums),
                              reinterpret_cast<double(&)[NS]>(tot), best, sc_red, parity);
+            THR_STAMP(12);
             parity ^= 1;
             const int pk = int(0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu));
             // |corr[pk-1..pk+1]|^2 for the log-parabola: lag n = n1*1024 + 2t + e, so this
@@ -898,6 +956,7 @@ __global__ __launch_bounds__(NT) void k_correlate(
                 cs->sum_mag = WANT_STD ? (float)tot[1] : 0.f;
                 cs->sum_mag2 = WANT_STD ? (float)tot[2] : 0.f;
             }
+            THR_STAMP(13);
         }
     }
 }

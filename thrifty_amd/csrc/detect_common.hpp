@@ -25,6 +25,8 @@ struct DevCfg {
     float cor_thr[3];
     float tmpl_energy[kMaxTemplates];  // sum t^2 (soa_estimator.py:65)
     int car_prune;     // carrier window + fit margin inside bins [0,128): pruned FFT#1 (16384 path)
+    unsigned long long* timeline;  // dev only (-DTHR_TIMELINE): [8 waves][16] s_memtime stamps
+    int prio_mode;     // 0: none, 1: s_setprio(1) for waves 4-7, 2: for waves 0-3 (THR_PRIO, default 1)
     int ablate;        // dev only (THR_ABLATE): stop each block after phase n; 0 = off
 };
 
