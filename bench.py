@@ -43,6 +43,8 @@ def parse_args():
     ap.add_argument("--mix", choices=["dense", "sparse"], default="dense",
                     help="dense: every block carries a signal; sparse: 10%% do")
     ap.add_argument("--templates", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=1,
+                    help="engine handles (each with its own HIP stream) the steps alternate over")
     ap.add_argument("--profile-kernels", type=int, default=8,
                     help="n > 0: HIP events around the kernels of every n-th step of the timed "
                          "region (roofline leg; 1 = every step, costs ~4%%); 0 = off")
@@ -136,9 +138,11 @@ def main():
     pad = HISTORY - wlen + 1
     window = (pad // 2, (N_BLOCK - wlen + 1) - (pad - pad // 2))
 
-    eng = F.Engine(N_BLOCK, HISTORY, tpls, (0, 15, 0), (7, 110), (0, 15, 0), device_id=local,
-                   max_batch=B)
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    engs = [F.Engine(N_BLOCK, HISTORY, tpls, (0, 15, 0), (7, 110), (0, 15, 0), device_id=local,
+                     max_batch=B) for _ in range(max(1, args.streams))]
+    eng = engs[0]
+    if len(engs) == 1:
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
 
     total = K * B
     gen = torch.Generator(device=dev)
@@ -156,20 +160,28 @@ def main():
 
     def step(i):
         s = (i % K) * B
-        eng.detect_device(data[s:s + B].data_ptr(), F.THR_IN_U8, B, rec[s * T:].data_ptr(),
-                          idx[s:].data_ptr())
+        engs[i % len(engs)].detect_device(data[s:s + B].data_ptr(), F.THR_IN_U8, B,
+                                          rec[s * T:].data_ptr(), idx[s:].data_ptr())
+
+    def sync_engines():
+        for e in engs:
+            e.sync()
 
     for i in range(W):
         step(i)
+    sync_engines()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    eng.profile_enable(args.profile_kernels)
-    eng.profile_read()  # reset accumulators
+    for e in engs:
+        e.profile_enable(args.profile_kernels)
+        e.profile_read()  # reset accumulators
     t0 = time.perf_counter()
     for i in range(K):
         step(i)
+    if len(engs) > 1:
+        sync_engines()
     # K7 + C1: compact detected records, gather them to rank 0 (the only collective)
     n_kept = eng.compact_device(rec.data_ptr(), total * T, kept.data_ptr())
     gathered = parallel.gather_records(kept[:n_kept], world, rank, dev) if world > 1 else kept[:n_kept]
@@ -178,8 +190,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    prof = eng.profile_read()
-    eng.profile_enable(0)
+    prof = {}
+    for e in engs:
+        for k, (ms, cnt) in e.profile_read().items():
+            prof[k] = (prof.get(k, (0.0, 0))[0] + ms, prof.get(k, (0.0, 0))[1] + cnt)
+        e.profile_enable(0)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

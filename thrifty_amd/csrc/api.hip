@@ -81,6 +81,7 @@ struct thr_handle {
     int device = 0;
     int n_cu = 0;
     bool fast = false;       // LDS-resident 16384 kernels; else the generic multi-pass path
+    bool w16 = false;        // fast path geometry: 16 waves x 16 elements (else 8 waves x 32)
     int gen_batch = 0;       // generic path: blocks per internal sub-batch
     float2* d_gen_scratch = nullptr;  // generic path: 3 * gen_batch * N complex
     float2* d_tspec_nat = nullptr;    // generic path: conj(FFT(template))/N, natural order
@@ -159,9 +160,18 @@ int window_indices(int start, int stop, int n, int* lo, int* count) {
 int build_constants(thr_handle* h) {
     const int n = h->cfg.block_len;
     // --- LDS twiddle tables (forward sign): C[32][32], A[16][32], Bt[16][32]  (fast path)
-    std::vector<float2> tab(2048);
-    for (int a = 0; a < 32; ++a)
-        for (int b = 0; b < 32; ++b) tab[a * 32 + b] = unit_root((long long)a * b, 1024);
+    std::vector<float2> tab(2048 + 64);
+    if (h->w16) {
+        // T2[k2][m2] = W_1024^(m2 k2), A[k1][mh] = W_512^(mh k1), B[k1][ml] = W_N^(ml k1),
+        // T3[k3][n4] = W_64^(n4 k3)
+        for (int k2 = 0; k2 < 16; ++k2)
+            for (int m2 = 0; m2 < 64; ++m2) tab[k2 * 64 + m2] = unit_root((long long)k2 * m2, 1024);
+        for (int k3 = 0; k3 < 4; ++k3)
+            for (int n4 = 0; n4 < 16; ++n4) tab[2048 + k3 * 16 + n4] = unit_root((long long)k3 * n4, 64);
+    } else {
+        for (int a = 0; a < 32; ++a)
+            for (int b = 0; b < 32; ++b) tab[a * 32 + b] = unit_root((long long)a * b, 1024);
+    }
     for (int k1 = 0; k1 < 16; ++k1)
         for (int n2 = 0; n2 < 32; ++n2) tab[1024 + k1 * 32 + n2] = unit_root((long long)k1 * n2, 512);
     for (int k1 = 0; k1 < 16; ++k1)
@@ -188,7 +198,17 @@ int build_constants(thr_handle* h) {
         h->dev.tmpl_energy[t] = float(energy);
         host_fft(buf);
         float2* out = spec.data() + size_t(t) * n;
-        if (h->fast) {
+        if (h->fast && h->w16) {
+            // thread t holds bins kb + 1024*k4, kb = (t>>6) + 16*((t>>2)&15) + 256*(t&3);
+            // float4 j of the thread = k4 in {2j, 2j+1}, stored [j][t] for coalescing
+            for (int tid = 0; tid < 1024; ++tid)
+                for (int k4 = 0; k4 < 16; ++k4) {
+                    const int k = (tid >> 6) + 16 * ((tid >> 2) & 15) + 256 * (tid & 3) + 1024 * k4;
+                    const std::complex<double> c = std::conj(buf[k]) / double(n);
+                    out[((k4 >> 1) * 1024 + tid) * 2 + (k4 & 1)] =
+                        float2{float(c.real()), float(c.imag())};
+                }
+        } else if (h->fast) {
             for (int tid = 0; tid < 512; ++tid)
                 for (int k3 = 0; k3 < 32; ++k3) {
                     const int k = (tid >> 5) + 16 * (tid & 31) + 512 * k3;
@@ -236,8 +256,8 @@ int run_batch_fast(thr_handle* h, const void* d_samples, int format,
     h->prof = h->prof_every > 0 && (h->batch_no++ % h->prof_every) == 0;
     {
         ProfScope p(h, 0);
-        HIP_TRY(thr::launch_carrier_16k(format, d_samples, n_blocks, h->dev, h->d_tables, h->d_stats,
-                                        dump_fft, grid, h->stream));
+        HIP_TRY((h->w16 ? thr::launch_carrier_16k_w16 : thr::launch_carrier_16k)(
+            format, d_samples, n_blocks, h->dev, h->d_tables, h->d_stats, dump_fft, grid, h->stream));
     }
     if (carrier_only) return THR_OK;
     {
@@ -247,10 +267,10 @@ int run_batch_fast(thr_handle* h, const void* d_samples, int format,
     }
     {
         ProfScope p(h, 2);
-        HIP_TRY(thr::launch_correlate_16k(format, d_samples, h->dev, h->d_tables, h->d_twn,
-                                          h->d_tspec, h->d_shifts, h->d_work_list, h->d_work_count,
-                                          h->d_corr_stats, d_out, h->d_xhat_scratch, dump_xhat,
-                                          dump_corr, dump_template, grid, h->stream));
+        HIP_TRY((h->w16 ? thr::launch_correlate_16k_w16 : thr::launch_correlate_16k)(
+            format, d_samples, h->dev, h->d_tables, h->d_twn, h->d_tspec, h->d_shifts, h->d_work_list,
+            h->d_work_count, h->d_corr_stats, d_out, h->d_xhat_scratch, dump_xhat, dump_corr,
+            dump_template, grid, h->stream));
     }
     {
         ProfScope p(h, 3);
@@ -360,6 +380,10 @@ int thr_create(const thr_settings* s, thr_handle** out) {
     h->cfg.templates = nullptr;  // not retained beyond this call (re-pointed below)
     h->device = s->device_id;
     h->fast = (n == 16384) && getenv("THR_FORCE_GENERIC") == nullptr;
+    {
+        const char* g = getenv("THR_GEOMETRY");  // "w8" | "w16": A/B of the two workgroup shapes
+        h->w16 = g != nullptr && std::string(g) == "w16";
+    }
     int rc = THR_OK;
     do {
         if (hipSetDevice(h->device) != hipSuccess) {
@@ -372,7 +396,8 @@ int thr_create(const thr_settings* s, thr_handle** out) {
             break;
         }
         h->n_cu = prop.multiProcessorCount;
-        if (h->fast && size_t(prop.maxSharedMemoryPerMultiProcessor) < thr::lds_bytes_16k()) {
+        if (h->fast && size_t(prop.maxSharedMemoryPerMultiProcessor) <
+                           std::max(thr::lds_bytes_16k(), thr::lds_bytes_16k_w16())) {
             rc = fail(THR_ERR_DEVICE, "device has %zu B LDS per CU, need %zu",
                       size_t(prop.maxSharedMemoryPerMultiProcessor), thr::lds_bytes_16k());
             break;
@@ -421,7 +446,7 @@ int thr_create(const thr_settings* s, thr_handle** out) {
         rc = fail(THR_ERR_DEVICE, "%s failed (%s)", #expr, hipGetErrorString(hipGetLastError())); \
         break;                                                                        \
     }
-        if (h->fast) CREATE_TRY(thr::prepare_16k());
+        if (h->fast) CREATE_TRY(h->w16 ? thr::prepare_16k_w16() : thr::prepare_16k());
         if (!h->fast) {
             // sub-batch so that the 3 ping-pong buffers stay near 256 MiB (Infinity-Cache sized)
             const size_t per_block = size_t(3) * n * sizeof(float2);

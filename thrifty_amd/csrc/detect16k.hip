@@ -19,6 +19,7 @@
 
 #include "detect_common.hpp"
 #include "fft_regs.hpp"
+#include "kernel_util.hpp"
 
 namespace thr {
 
@@ -40,108 +41,6 @@ constexpr size_t LDS_BYTES = size_t(LDS_CPX) * sizeof(cpx);  // 156,672 B
 }  // namespace k16
 
 using namespace k16;
-
-// Thread id the optimiser cannot see through: stops LICM from hoisting every
-// per-thread LDS address / window predicate out of the persistent block loop
-// (that cost ~220 SGPR + ~70 VGPR spills).
-__device__ __forceinline__ int opaque_tid() {
-    int t = threadIdx.x;
-    asm volatile("" : "+v"(t));
-    return t;
-}
-
-// Dev-only cycle timeline (-DTHR_TIMELINE): workgroup 0 records s_memtime at phase
-// boundaries of its 4th block, one row of 16 stamps per wave, into cfg.timeline.
-#ifdef THR_TIMELINE
-#define THR_STAMP(slot)                                                                   \
-    do {                                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                \
-        if (tl_on) {                                                                      \
-            const unsigned long long _t = __builtin_amdgcn_s_memtime();                   \
-            if ((threadIdx.x & 63) == 0) cfg.timeline[(threadIdx.x >> 6) * 16 + (slot)] = _t; \
-        }                                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                                \
-    } while (0)
-#else
-#define THR_STAMP(slot) do { } while (0)
-#endif
-
-// ---------------------------------------------------------------- reductions
-// Wave-level reductions on the VALU's DPP path (row_shr 1/2/4/8 inside each 16-lane
-// row, then row_bcast15 / row_bcast31 across rows): ~10 VALU ops instead of six
-// LDS-crossbar ds_bpermute round trips.  The result is valid in lane 63 and is
-// broadcast from there with v_readlane.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned dpp_u32(unsigned identity, unsigned v) {
-    return (unsigned)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xf, false);
-}
-constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114,
-              DPP_ROW_SHR8 = 0x118, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
-
-__device__ __forceinline__ float wave_sum(float v) {
-#define THR_STEP(CTRL, MASK) v += __uint_as_float(dpp_u32<CTRL, MASK>(0u, __float_as_uint(v)))
-    THR_STEP(DPP_ROW_SHR1, 0xf);
-    THR_STEP(DPP_ROW_SHR2, 0xf);
-    THR_STEP(DPP_ROW_SHR4, 0xf);
-    THR_STEP(DPP_ROW_SHR8, 0xf);
-    THR_STEP(DPP_ROW_BCAST15, 0xa);
-    THR_STEP(DPP_ROW_BCAST31, 0xc);
-#undef THR_STEP
-    return __uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
-}
-__device__ __forceinline__ unsigned long long wave_max(unsigned long long v) {
-#define THR_STEP(CTRL, MASK)                                                       \
-    {                                                                              \
-        const unsigned lo = dpp_u32<CTRL, MASK>(0u, (unsigned)v);                  \
-        const unsigned hi = dpp_u32<CTRL, MASK>(0u, (unsigned)(v >> 32));          \
-        const unsigned long long w = ((unsigned long long)hi << 32) | lo;          \
-        v = w > v ? w : v;                                                         \
-    }
-    THR_STEP(DPP_ROW_SHR1, 0xf)
-    THR_STEP(DPP_ROW_SHR2, 0xf)
-    THR_STEP(DPP_ROW_SHR4, 0xf)
-    THR_STEP(DPP_ROW_SHR8, 0xf)
-    THR_STEP(DPP_ROW_BCAST15, 0xa)
-    THR_STEP(DPP_ROW_BCAST31, 0xc)
-#undef THR_STEP
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
-    return ((unsigned long long)hi << 32) | lo;
-}
-
-// Combined block reduction: NS float sums (returned as double) + one u64 max,
-// ONE barrier.  `scratch` is double-buffered by `parity` (flip it on every call)
-// so a fast wave's next reduction cannot overwrite slots a slow wave still reads.
-constexpr int RED_SLOT_BYTES = 256;  // per parity: 8 waves x 3 doubles + 8 x u64
-template <int NS>
-__device__ __forceinline__ void block_reduce(float (&s)[NS], double (&out)[NS],
-                                             unsigned long long& m, unsigned char* scratch,
-                                             int parity) {
-    static_assert(NS <= 3, "scratch layout holds 3 sums");
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    double* sd = reinterpret_cast<double*>(scratch + parity * RED_SLOT_BYTES);
-    unsigned long long* su = reinterpret_cast<unsigned long long*>(sd + 24);
-#pragma unroll
-    for (int i = 0; i < NS; ++i) s[i] = wave_sum(s[i]);
-    m = wave_max(m);
-    if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < NS; ++i) sd[wv * 3 + i] = (double)s[i];
-        su[wv] = m;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        double t = 0;
-#pragma unroll
-        for (int w = 0; w < NT / 64; ++w) t += sd[w * 3 + i];
-        out[i] = t;
-    }
-    unsigned long long t = 0;
-#pragma unroll
-    for (int w = 0; w < NT / 64; ++w) t = su[w] > t ? su[w] : t;
-    m = t;
-}
 
 // ---------------------------------------------------------------- LDS tables
 __device__ __forceinline__ void load_tables(cpx* lds, const cpx* __restrict__ tables) {
@@ -413,7 +312,7 @@ __global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples
             bestp < 0.f ? 0ull
                         : ((unsigned long long)__float_as_uint(bestp) << 32) | (0xFFFFFFFFu - bestwi);
         double tot[2];
-        block_reduce<WANT_STD ? 2 : 1>(reinterpret_cast<float(&)[WANT_STD ? 2 : 1]>(sums),
+        block_reduce<WANT_STD ? 2 : 1, NT / 64>(reinterpret_cast<float(&)[WANT_STD ? 2 : 1]>(sums),
                                        reinterpret_cast<double(&)[WANT_STD ? 2 : 1]>(tot), best,
                                        sc_red, parity);
         parity ^= 1;
@@ -472,7 +371,7 @@ __global__ __launch_bounds__(NT) void k_carrier_pruned(const void* __restrict__ 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cpx* lds = reinterpret_cast<cpx*>(smem_raw);
     unsigned char* sc_red = reinterpret_cast<unsigned char*>(lds + OFF_S);
-    float* sc_bins = reinterpret_cast<float*>(sc_red + 2 * RED_SLOT_BYTES);  // [128] |X[k]|^2
+    float* sc_bins = reinterpret_cast<float*>(sc_red + 2 * red_slot_bytes<NT / 64>());  // [128] |X[k]|^2
 
     load_tables(lds, tables);
     __syncthreads();
@@ -516,7 +415,7 @@ __global__ __launch_bounds__(NT) void k_carrier_pruned(const void* __restrict__ 
                 best = ((unsigned long long)__float_as_uint(p) << 32) | (0xFFFFFFFFu - wi);
         }
         double tot[1];
-        block_reduce<1>(sums, tot, best, sc_red, parity);
+        block_reduce<1, NT / 64>(sums, tot, best, sc_red, parity);
         parity ^= 1;
         const unsigned wi = 0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu);
         const int peak_idx = int(wi) + cfg.win_lo;  // < 128: the '> N' wrap cannot trigger
@@ -551,18 +450,28 @@ __device__ __forceinline__ void dirichlet_eval(double u, double n, double w, dou
     dd = (pi * w / n * cw * s1 - sw * pi / n * c1) / (w * s1 * s1);
 }
 
-// Sum over the 8-lane group, bitwise identical in all 8 lanes.  The xor butterfly alone
-// is NOT enough: with HIP's default -ffp-contract=fast the caller's `x*x` gets fused
-// into the first add as fma(x, x, partner) on one side and fma(y, y, ...) on the other,
-// partner lanes then differ by an ulp, and an accept/reject decision in the LM loop
-// eventually flips in some lanes only.  So: contraction off here, and every lane takes
-// the group leader's value.
+// Sum over the 8-lane group, bitwise identical in all 8 lanes, on the DPP path
+// (quad_perm xor 1, xor 2, then row_half_mirror: i <-> 7-i) -- three VALU-speed steps
+// instead of ds_bpermute round trips (the fit is a chain of ~50 dependent group sums).
+// Each step adds the same two operands in both partners, so all lanes agree bit for
+// bit PROVIDED nothing gets contracted into the adds: with HIP's default
+// -ffp-contract=fast the caller's `x*x` is fused into the first add as fma(x, x, partner)
+// on one side and fma(y, y, ...) on the other, partner lanes then differ by an ulp, and
+// an accept/reject decision in the LM loop eventually flips in some lanes only.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = dpp_u32<CTRL, 0xf>(0u, (unsigned)u);
+    const unsigned hi = dpp_u32<CTRL, 0xf>(0u, (unsigned)(u >> 32));
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ double group8_sum(double v) {
 #pragma clang fp contract(off)
-    v = v + __shfl_xor(v, 1, 64);
-    v = v + __shfl_xor(v, 2, 64);
-    v = v + __shfl_xor(v, 4, 64);
-    return __shfl(v, (threadIdx.x & 63) & ~7, 64);
+    asm volatile("" : "+v"(v));  // materialise the operand: nothing upstream may fuse into the adds
+    v = v + dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = v + dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = v + dpp_f64<0x141>(v);  // row_half_mirror
+    return v;
 }
 
 // Levenberg-Marquardt on f_j(A, o) = A * |D(x_j - o)|, x_j = j - 3, from
@@ -917,7 +826,7 @@ __global__ __launch_bounds__(NT) void k_correlate(
             constexpr int NS = WANT_STD ? 3 : 1;
             double tot[3] = {0, 0, 0};
             THR_STAMP(11);
-            block_reduce<NS>(reinterpret_cast<float(&)[NS]>(sums),
+            block_reduce<NS, NT / 64>(reinterpret_cast<float(&)[NS]>(sums),
                              reinterpret_cast<double(&)[NS]>(tot), best, sc_red, parity);
             THR_STAMP(12);
             parity ^= 1;

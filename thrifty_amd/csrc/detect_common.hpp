@@ -79,6 +79,21 @@ hipError_t launch_finish(int n_records, const DevCfg& cfg, const CorrStats* corr
 hipError_t launch_compact(const thr_record* in, int n, thr_record* out, int* n_out,
                           hipStream_t stream);
 
+// detect16k_w16.hip (same contract, 1024-thread / 16-wave geometry)
+hipError_t prepare_16k_w16();
+size_t lds_bytes_16k_w16();
+int table_cpx_16k_w16();
+hipError_t launch_carrier_16k_w16(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,
+                                  const float2* tables, CarStats* stats, float2* dump_fft, int grid,
+                                  hipStream_t stream);
+hipError_t launch_correlate_16k_w16(int fmt, const void* samples, const DevCfg& cfg,
+                                    const float2* tables, const float2* twn, const float4* tspec,
+                                    const ShiftParams* shifts, const int* work_list,
+                                    const int* work_count, CorrStats* corr_stats,
+                                    thr_record* records, float4* xhat_scratch, float2* dump_xhat,
+                                    float2* dump_corr, int dump_template, int grid,
+                                    hipStream_t stream);
+
 // generic.hip (any power-of-two block length; multi-pass through HBM)
 size_t generic_scratch_bytes(int n, int n_blocks);
 hipError_t generic_carrier(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,

@@ -1,0 +1,111 @@
+// Helpers shared by the LDS-resident kernels (both workgroup geometries).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace thr {
+
+// Thread id the optimiser cannot see through: stops LICM from hoisting every
+// per-thread LDS address / window predicate out of the persistent block loop
+// (that cost ~220 SGPR + ~70 VGPR spills).
+__device__ __forceinline__ int opaque_tid() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
+// Dev-only cycle timeline (-DTHR_TIMELINE): workgroup 0 records s_memtime at phase
+// boundaries of its 4th block, one row of 16 stamps per wave, into cfg.timeline.
+#ifdef THR_TIMELINE
+#define THR_STAMP(slot)                                                                   \
+    do {                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        if (tl_on) {                                                                      \
+            const unsigned long long _t = __builtin_amdgcn_s_memtime();                   \
+            if ((threadIdx.x & 63) == 0) cfg.timeline[(threadIdx.x >> 6) * 16 + (slot)] = _t; \
+        }                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+    } while (0)
+#else
+#define THR_STAMP(slot) do { } while (0)
+#endif
+
+// ---------------------------------------------------------------- reductions
+// Wave-level reductions on the VALU's DPP path (row_shr 1/2/4/8 inside each 16-lane
+// row, then row_bcast15 / row_bcast31 across rows): ~10 VALU ops instead of six
+// LDS-crossbar ds_bpermute round trips.  The result is valid in lane 63 and is
+// broadcast from there with v_readlane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_u32(unsigned identity, unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114,
+              DPP_ROW_SHR8 = 0x118, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#define THR_STEP(CTRL, MASK) v += __uint_as_float(dpp_u32<CTRL, MASK>(0u, __float_as_uint(v)))
+    THR_STEP(DPP_ROW_SHR1, 0xf);
+    THR_STEP(DPP_ROW_SHR2, 0xf);
+    THR_STEP(DPP_ROW_SHR4, 0xf);
+    THR_STEP(DPP_ROW_SHR8, 0xf);
+    THR_STEP(DPP_ROW_BCAST15, 0xa);
+    THR_STEP(DPP_ROW_BCAST31, 0xc);
+#undef THR_STEP
+    return __uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
+}
+__device__ __forceinline__ unsigned long long wave_max(unsigned long long v) {
+#define THR_STEP(CTRL, MASK)                                                       \
+    {                                                                              \
+        const unsigned lo = dpp_u32<CTRL, MASK>(0u, (unsigned)v);                  \
+        const unsigned hi = dpp_u32<CTRL, MASK>(0u, (unsigned)(v >> 32));          \
+        const unsigned long long w = ((unsigned long long)hi << 32) | lo;          \
+        v = w > v ? w : v;                                                         \
+    }
+    THR_STEP(DPP_ROW_SHR1, 0xf)
+    THR_STEP(DPP_ROW_SHR2, 0xf)
+    THR_STEP(DPP_ROW_SHR4, 0xf)
+    THR_STEP(DPP_ROW_SHR8, 0xf)
+    THR_STEP(DPP_ROW_BCAST15, 0xa)
+    THR_STEP(DPP_ROW_BCAST31, 0xc)
+#undef THR_STEP
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// Combined block reduction: NS float sums (returned as double) + one u64 max,
+// ONE barrier.  `scratch` is double-buffered by `parity` (flip it on every call)
+// so a fast wave's next reduction cannot overwrite slots a slow wave still reads.
+template <int NW>
+constexpr int red_slot_bytes() { return NW * 32; }  // per parity: NW waves x (3 doubles + u64)
+template <int NS, int NW>
+__device__ __forceinline__ void block_reduce(float (&s)[NS], double (&out)[NS],
+                                             unsigned long long& m, unsigned char* scratch,
+                                             int parity) {
+    static_assert(NS <= 3, "scratch layout holds 3 sums");
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double* sd = reinterpret_cast<double*>(scratch + parity * red_slot_bytes<NW>());
+    unsigned long long* su = reinterpret_cast<unsigned long long*>(sd + 3 * NW);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) s[i] = wave_sum(s[i]);
+    m = wave_max(m);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) sd[wv * 3 + i] = (double)s[i];
+        su[wv] = m;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        double t = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += sd[w * 3 + i];
+        out[i] = t;
+    }
+    unsigned long long t = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t = su[w] > t ? su[w] : t;
+    m = t;
+}
+
+
+}  // namespace thr
