@@ -128,7 +128,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # under torchrun (RANK set) always bring RCCL up, even for one rank: the record gather
+    # then runs through the same collectives as the multi-GPU case
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
     B, K, W = args.batch, args.steps, args.warmup
@@ -171,7 +174,7 @@ def main():
         step(i)
     sync_engines()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     for e in engs:
@@ -184,9 +187,10 @@ def main():
         sync_engines()
     # K7 + C1: compact detected records, gather them to rank 0 (the only collective)
     n_kept = eng.compact_device(rec.data_ptr(), total * T, kept.data_ptr())
-    gathered = parallel.gather_records(kept[:n_kept], world, rank, dev) if world > 1 else kept[:n_kept]
+    gathered = (parallel.gather_records(kept[:n_kept], world, rank, dev, force=use_dist)
+                if use_dist else kept[:n_kept])
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -195,7 +199,7 @@ def main():
         for k, (ms, cnt) in e.profile_read().items():
             prof[k] = (prof.get(k, (0.0, 0))[0] + ms, prof.get(k, (0.0, 0))[1] + cnt)
         e.profile_enable(0)
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -243,7 +247,7 @@ def main():
                 data[:ns].cpu().numpy(), np.arange(first, first + ns), tpls[0], args.cpu_seconds,
                 rec.view(total, T, 64)[:ns, 0].cpu().numpy().view(F.RECORD_DTYPE).reshape(-1), T)
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

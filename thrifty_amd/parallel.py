@@ -20,7 +20,7 @@ def shard_range(n_blocks, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_records(local, world, rank, device=None, group=None):
+def gather_records(local, world, rank, device=None, group=None, force=False):
     """Gather variable-length uint8 [n_i, 64] record tensors to rank 0, in rank order.
 
     Returns the concatenation on rank 0 and an empty [0, 64] tensor elsewhere.
@@ -30,7 +30,7 @@ def gather_records(local, world, rank, device=None, group=None):
     import torch
     import torch.distributed as dist
 
-    if world == 1:
+    if world == 1 and not force:
         return local
     dev = local.device if device is None else device
     n = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
