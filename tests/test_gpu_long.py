@@ -1,0 +1,94 @@
+"""GPU parity of the long-block path (csrc/detect_long.hip): block_len = 4 x 16384
+(BASELINE config C3) and 2 x 16384, against the reference goldens, the oracle, and
+the generic multi-pass pipeline."""
+import numpy as np
+import pytest
+
+from oracle import thrifty_np as onp
+from thrifty_amd import _native as F
+from thrifty_amd import block_data, synth
+
+from test_gpu_parity import check_against_golden, engine_for
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c3_long_path_and_generic_path_both_match_golden(golden, monkeypatch):
+    g = golden("c3")
+    rec_long = engine_for(g, max_batch=8).detect(g["blocks"], g["block_idx"])[:, 0]
+    check_against_golden(rec_long, g)
+    monkeypatch.setenv("THR_FORCE_GENERIC", "1")
+    eng_gen = engine_for(g, max_batch=8)
+    monkeypatch.delenv("THR_FORCE_GENERIC")
+    rec_gen = eng_gen.detect(g["blocks"], g["block_idx"])[:, 0]
+    check_against_golden(rec_gen, g)
+    assert np.array_equal(rec_long["corr_sample"], rec_gen["corr_sample"])
+    np.testing.assert_allclose(rec_long["corr_energy"], rec_gen["corr_energy"], rtol=2e-5)
+
+
+def test_c3_stage_dumps(golden):
+    g = golden("c3")
+    eng = engine_for(g, max_batch=4)
+    spec = eng.debug_fft(g["blocks"][:2])
+    for i in range(2):
+        ref = np.fft.fft(block_data.raw_to_complex(g["blocks"][i]).astype(np.complex128))
+        assert np.linalg.norm(spec[i] - ref) / np.linalg.norm(ref) < 2e-6
+    orc = onp.OracleDetector(65536, 4096, g["template"], (0, 15, 0), (7, 110), (0, 15, 0))
+    xhat, corr = eng.debug_stage(g["blocks"][:2])
+    for i in range(2):
+        (res,), ((xh, co),) = orc.detect_u8(0, g["blocks"][i], want_data=True)
+        assert np.linalg.norm(xhat[i] - xh) / np.linalg.norm(xh) < 5e-6
+        assert np.linalg.norm(corr[i][:len(co)] - co) / np.linalg.norm(co) < 5e-6
+
+
+@pytest.mark.parametrize("n,bits,sps,cwin,cthr", [
+    (32768, 11, 1.0, (7, 110), (0, 15, 0)),          # R0 = 2
+    (65536, 11, 2.0, (-300, -20), (0, 15, 0)),       # negative-bin window
+    (65536, 11, 2.0, (0, -1), (100.0, 5.0, 2.0)),    # full window + stddev terms
+])
+def test_long_blocks_match_oracle(n, bits, sps, cwin, cthr):
+    h = 4096
+    tpl = synth.gold_template(bits, 3, sps)
+    win = onp.unique_window(n, h, len(tpl))
+    rng = np.random.default_rng(n + len(tpl))
+    lo, hi = (-250.0, -30.0) if cwin[0] < 0 and cwin[1] < 0 else (10.0, 100.0)
+    blocks, _ = synth.synth_blocks(rng, 5, n, tpl, win, signal_frac=0.8, carrier_bins=(lo, hi))
+    eng = F.Engine(n, h, tpl, cthr, cwin, (50.0, 8.0, 3.0) if cthr[2] else (0, 15, 0), max_batch=3)
+    orc = onp.OracleDetector(n, h, tpl, cthr, cwin, (50.0, 8.0, 3.0) if cthr[2] else (0, 15, 0))
+    idx = np.arange(5) * 3 + 1
+    rec = eng.detect(blocks, idx)[:, 0]
+    for i in range(5):
+        (res,) = orc.detect_u8(int(idx[i]), blocks[i])
+        r = rec[i]
+        assert r["carrier_bin"] == res.carrier.bin
+        assert bool(r["flags"] & F.FLAG_CARRIER) == res.carrier.detected
+        np.testing.assert_allclose(r["carrier_energy"], res.carrier.energy, rtol=1e-4)
+        np.testing.assert_allclose(r["carrier_noise"], res.carrier.noise, rtol=1e-4)
+        if res.carrier.detected:
+            assert r["corr_sample"] == res.corr.sample
+            assert bool(r["flags"] & F.FLAG_CORR) == res.corr.detected
+            np.testing.assert_allclose(r["corr_energy"], res.corr.energy, rtol=1e-4)
+            np.testing.assert_allclose(r["corr_noise"], res.corr.noise, rtol=1e-4)
+            np.testing.assert_allclose(r["corr_offset"], res.corr.offset, atol=1e-4)
+            np.testing.assert_allclose(r["carrier_offset"], res.carrier.offset, atol=1e-3)
+
+
+def test_long_multi_template_and_c64_input():
+    n, h = 65536, 4096
+    tpls = np.stack([synth.gold_template(11, i, 2.0) for i in (2, 3, 4)]).astype(np.float64)
+    win = onp.unique_window(n, h, tpls.shape[1])
+    rng = np.random.default_rng(77)
+    parts = [synth.synth_blocks(rng, 2, n, t, win)[0] for t in tpls]
+    blocks = np.concatenate(parts)
+    eng = F.Engine(n, h, tpls, (0, 15, 0), (7, 110), (0, 15, 0), max_batch=4)
+    rec = eng.detect(blocks)
+    rec_c64 = eng.detect(np.stack([block_data.raw_to_complex(b) for b in blocks]))
+    for t in range(3):
+        orc = onp.OracleDetector(n, h, tpls[t], (0, 15, 0), (7, 110), (0, 15, 0))
+        for i in range(6):
+            (res,) = orc.detect_u8(i, blocks[i])
+            for r in (rec[i, t], rec_c64[i, t]):
+                assert r["corr_sample"] == res.corr.sample
+                assert bool(r["flags"] & F.FLAG_CORR) == res.corr.detected
+                np.testing.assert_allclose(r["corr_energy"], res.corr.energy, rtol=1e-4)
+                np.testing.assert_allclose(r["corr_offset"], res.corr.offset, atol=1e-4)

@@ -12,8 +12,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libthriftyhip.so")
-SOURCES = ["api.hip", "detect16k.hip", "detect16k_w16.hip", "generic.hip"]
-HEADERS = ["detect_common.hpp", "fft_regs.hpp", "kernel_util.hpp", os.path.join("..", "..", "include", "thrifty_hip.h")]
+SOURCES = ["api.hip", "detect16k.hip", "detect16k_w16.hip", "detect_long.hip", "generic.hip"]
+HEADERS = ["detect_common.hpp", "fft_regs.hpp", "kernel_util.hpp", "passes_w8.hpp", os.path.join("..", "..", "include", "thrifty_hip.h")]
 
 
 def _hipcc():

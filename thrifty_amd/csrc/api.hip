@@ -82,6 +82,12 @@ struct thr_handle {
     int n_cu = 0;
     bool fast = false;       // LDS-resident 16384 kernels; else the generic multi-pass path
     bool w16 = false;        // fast path geometry: 16 waves x 16 elements (else 8 waves x 32)
+    bool lng = false;        // block_len = 2 or 4 x 16384: R0 LDS sub-transforms per block
+    int long_batch = 0;      // long path: blocks per internal sub-batch
+    float* d_win_pow = nullptr;     // long: [long_batch][win_w] |X|^2 of the window bins (+-3)
+    float* d_partial = nullptr;     // long: [long_batch][R0][2] partial sums of FFT#1
+    float* d_partial_x2 = nullptr;  // long: [long_batch][R0] partial sum |X^|^2
+    float2* d_dsub = nullptr;       // long: [long_batch][T][R0][16384] sub-transform outputs
     int gen_batch = 0;       // generic path: blocks per internal sub-batch
     float2* d_gen_scratch = nullptr;  // generic path: 3 * gen_batch * N complex
     float2* d_tspec_nat = nullptr;    // generic path: conj(FFT(template))/N, natural order
@@ -175,7 +181,8 @@ int build_constants(thr_handle* h) {
     for (int k1 = 0; k1 < 16; ++k1)
         for (int n2 = 0; n2 < 32; ++n2) tab[1024 + k1 * 32 + n2] = unit_root((long long)k1 * n2, 512);
     for (int k1 = 0; k1 < 16; ++k1)
-        for (int mp = 0; mp < 32; ++mp) tab[1536 + k1 * 32 + mp] = unit_root((long long)k1 * mp, n);
+        for (int mp = 0; mp < 32; ++mp)
+            tab[1536 + k1 * 32 + mp] = unit_root((long long)k1 * mp, h->lng ? 16384 : n);
     HIP_TRY(hipMalloc(&h->d_tables, tab.size() * sizeof(float2)));
     HIP_TRY(hipMemcpy(h->d_tables, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice));
     // --- full-length root table for the shift phasor
@@ -198,7 +205,18 @@ int build_constants(thr_handle* h) {
         h->dev.tmpl_energy[t] = float(energy);
         host_fft(buf);
         float2* out = spec.data() + size_t(t) * n;
-        if (h->fast && h->w16) {
+        if (h->lng) {
+            // sub-transform k0 holds bins k0 + R0*q; within it the 16384 kernels' permutation
+            const int r0 = n / 16384;
+            for (int k0 = 0; k0 < r0; ++k0)
+                for (int tid = 0; tid < 512; ++tid)
+                    for (int k3 = 0; k3 < 32; ++k3) {
+                        const int q = (tid >> 5) + 16 * (tid & 31) + 512 * k3;
+                        const std::complex<double> c = std::conj(buf[k0 + r0 * q]) / double(n);
+                        out[size_t(k0) * 16384 + ((k3 >> 1) * 512 + tid) * 2 + (k3 & 1)] =
+                            float2{float(c.real()), float(c.imag())};
+                    }
+        } else if (h->fast && h->w16) {
             // thread t holds bins kb + 1024*k4, kb = (t>>6) + 16*((t>>2)&15) + 256*(t&3);
             // float4 j of the thread = k4 in {2j, 2j+1}, stored [j][t] for coalescing
             for (int tid = 0; tid < 1024; ++tid)
@@ -226,7 +244,7 @@ int build_constants(thr_handle* h) {
     float2* d_spec = nullptr;
     HIP_TRY(hipMalloc(&d_spec, spec.size() * sizeof(float2)));
     HIP_TRY(hipMemcpy(d_spec, spec.data(), spec.size() * sizeof(float2), hipMemcpyHostToDevice));
-    if (h->fast)
+    if (h->fast || h->lng)
         h->d_tspec = reinterpret_cast<float4*>(d_spec);
     else
         h->d_tspec_nat = d_spec;
@@ -331,12 +349,55 @@ int run_batch_generic(thr_handle* h, const void* d_samples, int format,
     return THR_OK;
 }
 
+// Long blocks (2 or 4 x 16384): R0 LDS-resident sub-transforms per block, sub-batched.
+int run_batch_long(thr_handle* h, const void* d_samples, int format,
+                   const long long* d_block_idx, int n_blocks, thr_record* d_out, float2* dump_fft,
+                   float2* dump_xhat, float2* dump_corr, int dump_template, bool carrier_only) {
+    const size_t n = size_t(h->cfg.block_len), T = size_t(h->cfg.n_templates);
+    const size_t blk_bytes = n * (format == THR_IN_U8 ? 2 : 8);
+    const int r0 = int(n / 16384);
+    h->prof = h->prof_every > 0 && (h->batch_no++ % h->prof_every) == 0;
+    for (int off = 0; off < n_blocks; off += h->long_batch) {
+        const int nb = std::min(h->long_batch, n_blocks - off);
+        const void* in = static_cast<const unsigned char*>(d_samples) + size_t(off) * blk_bytes;
+        thr_record* out = d_out + size_t(off) * T;
+        {
+            ProfScope p(h, 0);
+            HIP_TRY(thr::launch_carrier_long(format, in, nb, h->dev, h->d_tables, h->d_twn,
+                                             h->d_win_pow, h->d_partial, h->d_stats,
+                                             dump_fft ? dump_fft + size_t(off) * n : nullptr,
+                                             std::min(nb * r0, h->n_cu), h->stream));
+        }
+        if (carrier_only) continue;
+        {
+            ProfScope p(h, 1);
+            HIP_TRY(thr::launch_fit(nb, h->dev, h->d_stats, d_block_idx ? d_block_idx + off : nullptr,
+                                    h->d_shifts, h->d_work_list, h->d_work_count, out, h->stream));
+        }
+        {
+            ProfScope p(h, 2);
+            HIP_TRY(thr::launch_correlate_long(
+                format, in, nb, h->dev, h->d_tables, h->d_twn, h->d_tspec, h->d_shifts, h->d_work_list,
+                h->d_work_count, h->d_dsub, h->d_partial_x2, h->d_xhat_scratch, h->d_corr_stats,
+                dump_xhat ? dump_xhat + size_t(off) * n : nullptr,
+                dump_corr ? dump_corr + size_t(off) * n : nullptr, dump_template,
+                std::min(nb * r0, h->n_cu), h->stream));
+        }
+        {
+            ProfScope p(h, 3);
+            HIP_TRY(thr::launch_finish(nb * int(T), h->dev, h->d_corr_stats, out, h->d_work_count,
+                                       h->stream));
+        }
+    }
+    return THR_OK;
+}
+
 int run_batch(thr_handle* h, const void* d_samples, int format, const long long* d_block_idx,
               int n_blocks, thr_record* d_out, float2* dump_fft, float2* dump_xhat,
               float2* dump_corr, int dump_template, bool carrier_only) {
-    return (h->fast ? run_batch_fast : run_batch_generic)(h, d_samples, format, d_block_idx, n_blocks,
-                                                          d_out, dump_fft, dump_xhat, dump_corr,
-                                                          dump_template, carrier_only);
+    return (h->fast ? run_batch_fast : h->lng ? run_batch_long : run_batch_generic)(
+        h, d_samples, format, d_block_idx, n_blocks, d_out, dump_fft, dump_xhat, dump_corr,
+        dump_template, carrier_only);
 }
 
 }  // namespace
@@ -380,6 +441,7 @@ int thr_create(const thr_settings* s, thr_handle** out) {
     h->cfg.templates = nullptr;  // not retained beyond this call (re-pointed below)
     h->device = s->device_id;
     h->fast = (n == 16384) && getenv("THR_FORCE_GENERIC") == nullptr;
+    h->lng = thr::long_supported(n) && getenv("THR_FORCE_GENERIC") == nullptr;
     {
         const char* g = getenv("THR_GEOMETRY");  // "w8" | "w16": A/B of the two workgroup shapes
         h->w16 = g != nullptr && std::string(g) == "w16";
@@ -396,7 +458,7 @@ int thr_create(const thr_settings* s, thr_handle** out) {
             break;
         }
         h->n_cu = prop.multiProcessorCount;
-        if (h->fast && size_t(prop.maxSharedMemoryPerMultiProcessor) <
+        if ((h->fast || h->lng) && size_t(prop.maxSharedMemoryPerMultiProcessor) <
                            std::max(thr::lds_bytes_16k(), thr::lds_bytes_16k_w16())) {
             rc = fail(THR_ERR_DEVICE, "device has %zu B LDS per CU, need %zu",
                       size_t(prop.maxSharedMemoryPerMultiProcessor), thr::lds_bytes_16k());
@@ -447,7 +509,19 @@ int thr_create(const thr_settings* s, thr_handle** out) {
         break;                                                                        \
     }
         if (h->fast) CREATE_TRY(h->w16 ? thr::prepare_16k_w16() : thr::prepare_16k());
-        if (!h->fast) {
+        if (h->lng) {
+            CREATE_TRY(thr::prepare_long(n));
+            const int r0 = n / 16384;
+            h->long_batch = std::min(s->max_batch, 128);
+            const size_t lb = size_t(h->long_batch);
+            const size_t win_w = size_t(std::min(h->dev.win_count + 6, n));
+            CREATE_TRY(hipMalloc(&h->d_win_pow, lb * win_w * sizeof(float)));
+            CREATE_TRY(hipMalloc(&h->d_partial, lb * r0 * 2 * sizeof(float)));
+            CREATE_TRY(hipMalloc(&h->d_partial_x2, lb * r0 * sizeof(float)));
+            CREATE_TRY(hipMalloc(&h->d_dsub, lb * s->n_templates * size_t(n) * sizeof(float2)));
+            CREATE_TRY(hipMalloc(&h->d_xhat_scratch, size_t(h->n_cu) * 16384 * sizeof(float2)));
+        }
+        if (!h->fast && !h->lng) {
             // sub-batch so that the 3 ping-pong buffers stay near 256 MiB (Infinity-Cache sized)
             const size_t per_block = size_t(3) * n * sizeof(float2);
             h->gen_batch = int(std::max<size_t>(1, std::min<size_t>(size_t(s->max_batch),
@@ -486,7 +560,7 @@ void thr_destroy(thr_handle* h) {
         hipEventDestroy(e.a);
         hipEventDestroy(e.b);
     }
-    void* bufs[] = {h->d_tables, h->d_twn, h->d_tspec, h->d_stats, h->d_shifts, h->d_corr_stats, h->d_gen_scratch, h->d_tspec_nat, h->d_work_list,
+    void* bufs[] = {h->d_tables, h->d_twn, h->d_tspec, h->d_stats, h->d_shifts, h->d_corr_stats, h->d_gen_scratch, h->d_tspec_nat, h->d_win_pow, h->d_partial, h->d_partial_x2, h->d_dsub, h->d_work_list,
                     h->d_work_count, h->d_xhat_scratch, h->d_ncompact, h->d_in, h->d_idx, h->d_rec};
     for (void* b : bufs)
         if (b) hipFree(b);

@@ -53,6 +53,7 @@ struct CorrStats {
 // K_fit -> K_B: the frequency-shift phasor exp(2 pi i s (n/N - 1/2)), factored
 struct ShiftParams {
     float2 rpow[16];  // exp(2 pi i s j / R1), j = sub-sequence index of pass 1
+    float2 r0pow[4];  // long blocks only: exp(2 pi i s j / R0), j = leading sub-sequence index
     float2 c0;        // exp(-pi i s)
     int si_mod;       // round(s) mod N
     float sf_over_n;  // (s - round(s)) / N
@@ -93,6 +94,21 @@ hipError_t launch_correlate_16k_w16(int fmt, const void* samples, const DevCfg& 
                                     thr_record* records, float4* xhat_scratch, float2* dump_xhat,
                                     float2* dump_corr, int dump_template, int grid,
                                     hipStream_t stream);
+
+// detect_long.hip (block_len = 2 or 4 x 16384: R0 LDS-resident sub-transforms per block)
+bool long_supported(int block_len);
+hipError_t prepare_long(int block_len);
+hipError_t launch_carrier_long(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,
+                               const float2* tables, const float2* twn, float* win_pow,
+                               float* partial, CarStats* stats, float2* dump_fft, int grid,
+                               hipStream_t stream);
+hipError_t launch_correlate_long(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,
+                                 const float2* tables, const float2* twn, const float4* tspec,
+                                 const ShiftParams* shifts, const int* work_list,
+                                 const int* work_count, float2* dsub, float* partial_x2,
+                                 float4* xhat_scratch, CorrStats* corr_stats, float2* dump_xhat,
+                                 float2* dump_corr, int dump_template, int grid,
+                                 hipStream_t stream);
 
 // generic.hip (any power-of-two block length; multi-pass through HBM)
 size_t generic_scratch_bytes(int n, int n_blocks);

@@ -1,0 +1,504 @@
+// Long blocks: block_len NL = R0 * 16384 (R0 = 2, 4; BASELINE config C3 is 65536).
+//
+// A block no longer fits the CU's 160 KiB LDS, so the transform is split by one
+// decimation-in-frequency stage in front of the LDS-resident 16384-point kernels
+// (passes_w8.hpp):
+//     n = n0*M + m,  k = k0 + R0*q        (M = 16384)
+//     X[k0 + R0 q] = FFT_M{ W_NL^(m k0) * sum_n0 x[n0 M + m] W_R0^(n0 k0) }[q]
+// i.e. R0 independent 16384-point sub-transforms per block whose inputs are formed on
+// the fly by the sample loader (R0 coalesced loads per element, a radix-R0 butterfly,
+// one twiddle) -- the sub-transform itself, the template product and the mirrored
+// inverse run exactly as for N = 16384, with the digit-reversed spectrum staying in
+// registers.  What crosses sub-transforms goes through small global arrays:
+//   k_carrier_sub  -> |X|^2 of the window bins (+-3) and partial sums -> k_select -> k_fit
+//   k_correlate_sub-> d_k0[m] = IFFT_M{...} per (block, template, k0)  -> k_combine:
+//                     corr[n0 M + m] = sum_k0 W_R0^(-n0 k0) conj(W_NL^(m k0)) d_k0[m]
+// Reference lines as in detect16k.hip.
+#include <hip/hip_runtime.h>
+
+#include "detect_common.hpp"
+#include "fft_regs.hpp"
+#include "kernel_util.hpp"
+#include "passes_w8.hpp"
+
+namespace thr {
+
+using namespace k16;  // N == M == 16384 here; NL = R0 * N is the block length
+
+namespace {
+
+constexpr int M = N;
+
+// z * exp(-i*pi/2 * q), q in 0..3 (wave-uniform q)
+__device__ __forceinline__ cpx rot_quarter_neg(cpx z, int q) {
+    switch (q & 3) {
+        case 1: return cpx{z.y, -z.x};
+        case 2: return -z;
+        case 3: return cpx{-z.y, z.x};
+        default: return z;
+    }
+}
+
+// Sample source of sub-transform k0: the radix-R0 combination of the R0 samples that
+// alias onto m.  g[n0] (LDS, wave-uniform) = [shift phasor step r0^n0] * W_R0^(n0 k0);
+// GEN = false means g is a pure quarter-turn (carrier stage): adds only.
+template <int FMT, int R0, bool GEN>
+struct RawLong {
+    const void* blk;
+    const float2* g;  // [R0]
+    int t, k0;
+    __device__ __forceinline__ void pair(int n0, int n1, cpx& a, cpx& b) const {
+        const size_t idx = size_t(n0) * (M / 2) + size_t(n1) * (S1 / 2) + t;
+        if constexpr (FMT == THR_IN_U8) {
+            const unsigned w = reinterpret_cast<const unsigned*>(blk)[idx];
+            constexpr float sc = 1.0f / 128.0f, of = -127.4f / 128.0f;
+            a = cpx{fmaf(float(w & 0xffu), sc, of), fmaf(float((w >> 8) & 0xffu), sc, of)};
+            b = cpx{fmaf(float((w >> 16) & 0xffu), sc, of), fmaf(float(w >> 24), sc, of)};
+        } else {
+            const f4 w = reinterpret_cast<const f4*>(blk)[idx];
+            a = cpx{w.x, w.y};
+            b = cpx{w.z, w.w};
+        }
+    }
+    __device__ __forceinline__ void get(int n1, cpx& a, cpx& b) const {
+        pair(0, n1, a, b);
+#pragma unroll
+        for (int n0 = 1; n0 < R0; ++n0) {
+            cpx x, y;
+            pair(n0, n1, x, y);
+            if constexpr (GEN) {
+                const cpx w = cpx{g[n0].x, g[n0].y};
+                a += cmul(x, w);
+                b += cmul(y, w);
+            } else {
+                const int q = (n0 * k0 * (4 / R0)) & 3;  // W_R0^(n0 k0) as quarter turns
+                a += rot_quarter_neg(x, q);
+                b += rot_quarter_neg(y, q);
+            }
+        }
+        // complex64 input: R0 x 16 float4 loads would all be hoisted (256 VGPRs) -- fence per n1
+        if constexpr (FMT == THR_IN_C64) __builtin_amdgcn_sched_barrier(0);
+    }
+};
+
+// Per-item uniform factors into LDS scratch: rp[n1] = rpow[n1] * W_NL^(1024 n1 k0) and
+// g[n0] (see RawLong); `sp` == nullptr for the carrier stage (no frequency shift).
+template <int R0>
+__device__ __forceinline__ void item_factors(float2* rp, float2* g, const ShiftParams* sp,
+                                             const cpx* __restrict__ twn, int k0, int nl_mask) {
+    const int i = threadIdx.x;
+    if (i < 16) {
+        const cpx u = twn[(1024 * i * k0) & nl_mask];
+        const cpx r = sp ? cmul(cpx{sp->rpow[i].x, sp->rpow[i].y}, u) : u;
+        rp[i] = float2{r.x, r.y};
+    } else if (i >= 64 && i < 64 + R0) {
+        const int n0 = i - 64;
+        const cpx w = rot_quarter_neg(cpx{1.f, 0.f}, n0 * k0 * (4 / R0));
+        const cpx r = sp ? cmul(cpx{sp->r0pow[n0].x, sp->r0pow[n0].y}, w) : w;
+        g[n0] = float2{r.x, r.y};
+    }
+}
+
+// =========================================================================
+// carrier stage of one sub-transform
+// =========================================================================
+template <int FMT, int R0, bool WANT_STD, bool DUMP>
+__global__ __launch_bounds__(NT) void k_carrier_sub(const void* __restrict__ samples, int n_blocks,
+                                                    DevCfg cfg, const cpx* __restrict__ tables,
+                                                    const cpx* __restrict__ twn,
+                                                    float* __restrict__ win_pow,   // [b][win_w]
+                                                    float* __restrict__ partial,   // [b][R0][2]
+                                                    cpx* __restrict__ dump_fft) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cpx* lds = reinterpret_cast<cpx*>(smem_raw);
+    unsigned char* sc_red = reinterpret_cast<unsigned char*>(lds + OFF_S);
+    float2* sc_rp = reinterpret_cast<float2*>(sc_red + 2 * red_slot_bytes<NT / 64>());  // [16]
+    float2* sc_g = sc_rp + 16;                                                            // [R0]
+
+    load_tables(lds, tables);
+    __syncthreads();
+    const int NL = R0 * M, nl_mask = NL - 1;
+    const size_t blk_bytes = size_t(NL) * (FMT == THR_IN_U8 ? 2 : 8);
+    const int win_w = min(cfg.win_count + 6, NL);
+    const int win_base = cfg.win_lo - 3;
+    int parity = 0;
+
+    for (int item = blockIdx.x; item < n_blocks * R0; item += gridDim.x) {
+        const int b = item / R0, k0 = item % R0;
+        const int t = opaque_tid();
+        __syncthreads();  // scratch factors of the previous item are no longer read
+        item_factors<R0>(sc_rp, sc_g, nullptr, twn, k0, nl_mask);
+        cpx p[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) p[e] = twn[((2 * t + e) * k0) & nl_mask];  // W_NL^(m' k0)
+        __syncthreads();
+        // (complex64 input takes the branch-free multiply form: the quarter-turn switch plus
+        // R0 x 16 hoisted float4 loads spills ~150 VGPRs)
+        RawLong<FMT, R0, FMT == THR_IN_C64> raw{
+            static_cast<const unsigned char*>(samples) + size_t(b) * blk_bytes, sc_g, t, k0};
+        fwd_pass1<true>(lds, raw, sc_rp, p[0], p[1]);
+        __syncthreads();
+        fwd_pass2(lds);
+        __builtin_amdgcn_sched_barrier(0);
+        cpx v[R3];
+        fwd_pass3(lds, v);
+
+        const int kbase = (t >> 5) + 16 * (t & 31);
+        float sums[2] = {0.f, 0.f};
+        float* wp = win_pow + size_t(b) * win_w;
+        static_for<R3>([&](auto K) {
+            constexpr int k3 = decltype(K)::value;
+            const float pw = cnorm(v[brev(k3, R3)]);
+            sums[0] += pw;
+            if constexpr (WANT_STD) sums[1] += __builtin_amdgcn_sqrtf(pw);
+            const int k = k0 + R0 * (kbase + 512 * k3);
+            const unsigned wi = unsigned(k - win_base) & unsigned(nl_mask);
+            if (wi < unsigned(win_w)) wp[wi] = pw;
+            if constexpr (DUMP) dump_fft[size_t(b) * NL + k] = v[brev(k3, R3)];
+        });
+        double tot[2] = {0, 0};
+        unsigned long long dummy = 0;
+        block_reduce<WANT_STD ? 2 : 1, NT / 64>(reinterpret_cast<float(&)[WANT_STD ? 2 : 1]>(sums),
+                                                reinterpret_cast<double(&)[WANT_STD ? 2 : 1]>(tot),
+                                                dummy, sc_red, parity);
+        parity ^= 1;
+        if (t == 0) {
+            partial[(size_t(b) * R0 + k0) * 2 + 0] = (float)tot[0];
+            partial[(size_t(b) * R0 + k0) * 2 + 1] = WANT_STD ? (float)tot[1] : 0.f;
+        }
+    }
+}
+
+// window first-max + neighbourhood + totals, one workgroup per block
+__global__ __launch_bounds__(256) void k_select(int r0, DevCfg cfg, const float* __restrict__ win_pow,
+                                                const float* __restrict__ partial,
+                                                CarStats* __restrict__ stats) {
+    __shared__ unsigned long long sh[4];
+    const int b = blockIdx.x, nl = cfg.block_len;
+    const int win_w = min(cfg.win_count + 6, nl);
+    const float* wp = win_pow + size_t(b) * win_w;
+    unsigned long long best = 0;
+    for (int wi = threadIdx.x; wi < cfg.win_count; wi += blockDim.x) {
+        // with a full-length window the +-3 margin cannot be stored: index modulo the array
+        const float pw = wp[(wi + 3) % win_w];
+        const unsigned long long key =
+            ((unsigned long long)__float_as_uint(pw) << 32) | (0xFFFFFFFFu - unsigned(wi));
+        best = key > best ? key : best;
+    }
+    best = wave_max(best);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; ++i) best = sh[i] > best ? sh[i] : best;
+        const int wi = int(0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu));
+        int peak_idx = wi + cfg.win_lo;
+        if (peak_idx > nl) peak_idx -= nl;  // sic (carrier_detect.py:151)
+        CarStats st;
+        float s2 = 0.f, s1 = 0.f;
+        for (int k0 = 0; k0 < r0; ++k0) {
+            s2 += partial[(size_t(b) * r0 + k0) * 2 + 0];
+            s1 += partial[(size_t(b) * r0 + k0) * 2 + 1];
+        }
+        st.sum_mag2 = s2;
+        st.sum_mag = s1;
+        st.peak_mag = sqrtf(__uint_as_float(unsigned(best >> 32)));
+        st.peak_idx = peak_idx;
+        for (int d = 0; d < 7; ++d) st.nb[d] = sqrtf(wp[(wi + d) % win_w]);
+        st.pad = 0;
+        stats[b] = st;
+    }
+}
+
+// =========================================================================
+// correlation stage of one sub-transform: shift, FFT, x template, inverse -> d_k0[m]
+// =========================================================================
+template <int FMT, int R0, bool DUMP>
+__global__ __launch_bounds__(NT) void k_correlate_sub(
+    const void* __restrict__ samples, DevCfg cfg, const cpx* __restrict__ tables,
+    const cpx* __restrict__ twn, const f4* __restrict__ tspec,
+    const ShiftParams* __restrict__ shifts, const int* __restrict__ work_list,
+    const int* __restrict__ work_count, f4* __restrict__ dsub,   // [slot][tpl][k0][M/2] float4
+    float* __restrict__ partial_x2,                               // [slot][R0]
+    f4* __restrict__ xhat_scratch, cpx* __restrict__ dump_xhat) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cpx* lds = reinterpret_cast<cpx*>(smem_raw);
+    unsigned char* sc_red = reinterpret_cast<unsigned char*>(lds + OFF_S);
+    float2* sc_rp = reinterpret_cast<float2*>(sc_red + 2 * red_slot_bytes<NT / 64>());
+    float2* sc_g = sc_rp + 16;
+
+    load_tables(lds, tables);
+    __syncthreads();
+    const int NL = R0 * M, nl_mask = NL - 1;
+    const size_t blk_bytes = size_t(NL) * (FMT == THR_IN_U8 ? 2 : 8);
+    const int n_work = *work_count;
+    const int T = cfg.n_templates;
+    int parity = 0;
+
+    for (int item = blockIdx.x; item < n_work * R0; item += gridDim.x) {
+        const int slot = item / R0, k0 = item % R0;
+        const int b = work_list[slot];
+        const int t = opaque_tid();
+        const ShiftParams* sp = shifts + b;
+        __syncthreads();
+        item_factors<R0>(sc_rp, sc_g, sp, twn, k0, nl_mask);
+        // per-thread phasor for m' = 2t, 2t+1: c0 * exp(2 pi i s m'/NL) * W_NL^(m' k0)
+        cpx p[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int m = 2 * t + e;
+            const int q = int(((long long)sp->si_mod * m) & nl_mask);
+            float sn, cs;
+            sincosf(6.283185307179586f * (sp->sf_over_n * float(m)), &sn, &cs);
+            const cpx ph = cmul(cmul(cconj(twn[q]), cpx{cs, sn}), cpx{sp->c0.x, sp->c0.y});
+            p[e] = cmul(ph, twn[(m * k0) & nl_mask]);
+        }
+        __syncthreads();
+        RawLong<FMT, R0, true> raw{static_cast<const unsigned char*>(samples) + size_t(b) * blk_bytes,
+                                   sc_g, t, k0};
+        fwd_pass1<true>(lds, raw, sc_rp, p[0], p[1]);
+        __syncthreads();
+        fwd_pass2(lds);
+        __builtin_amdgcn_sched_barrier(0);
+        cpx xh[R3];
+        fwd_pass3(lds, xh);
+
+        const int kbase = (t >> 5) + 16 * (t & 31);
+        float sums[1] = {0.f};
+#pragma unroll
+        for (int i = 0; i < R3; ++i) sums[0] += cnorm(xh[i]);
+        if constexpr (DUMP) {
+            if (dump_xhat != nullptr)
+                static_for<R3>([&](auto K) {
+                    constexpr int k3 = decltype(K)::value;
+                    dump_xhat[size_t(b) * NL + k0 + R0 * (kbase + 512 * k3)] = xh[brev(k3, R3)];
+                });
+        }
+        double tot[1];
+        unsigned long long dummy = 0;
+        block_reduce<1, NT / 64>(sums, tot, dummy, sc_red, parity);
+        parity ^= 1;
+        if (t == 0) partial_x2[size_t(slot) * R0 + k0] = (float)tot[0];
+        // park the spectrum (L2-resident scratch row of this workgroup): every template reuses it
+        f4* park = xhat_scratch + size_t(blockIdx.x) * (M / 2) + t;
+        static_for<R3 / 2>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            park[j * NT] = f4{xh[brev(2 * j, R3)].x, xh[brev(2 * j, R3)].y,
+                              xh[brev(2 * j + 1, R3)].x, xh[brev(2 * j + 1, R3)].y};
+        });
+        for (int tpl = 0; tpl < T; ++tpl) {
+            const int t = opaque_tid();
+            park = xhat_scratch + size_t(blockIdx.x) * (M / 2) + t;
+            const f4* ts = tspec + (size_t(tpl) * R0 + k0) * (M / 2) + t;
+            cpx z[R3];
+            static_for<R3 / 2>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                const f4 q = ts[j * NT];
+                const f4 xx = park[j * NT];
+                z[brev(2 * j, R3)] = cmul(cpx{xx.x, xx.y}, cpx{q.x, q.y});
+                z[brev(2 * j + 1, R3)] = cmul(cpx{xx.z, xx.w}, cpx{q.z, q.w});
+            });
+            __syncthreads();  // tpl > 0: the previous pass-C reads of other waves are done
+            inv_passA(lds, z);
+            __builtin_amdgcn_sched_barrier(0);
+            inv_passB(lds);
+            __syncthreads();
+            cpx c0[R1], c1[R1];
+            inv_passC(lds, c0, c1);
+            f4* out = dsub + ((size_t(slot) * T + tpl) * R0 + k0) * (M / 2) + t;
+            static_for<R1>([&](auto K) {
+                constexpr int n1 = decltype(K)::value;
+                out[n1 * (S1 / 2)] = f4{c0[brev(n1, R1)].x, c0[brev(n1, R1)].y, c1[brev(n1, R1)].x,
+                                        c1[brev(n1, R1)].y};
+            });
+        }
+    }
+}
+
+// corr[n0 M + m] = sum_k0 W_R0^(-n0 k0) conj(W_NL^(m k0)) d_k0[m]; windowed first-max, sums
+template <int R0>
+__device__ __forceinline__ void combine_at(const cpx* __restrict__ d, const cpx* __restrict__ twn,
+                                           int m, int nl_mask, cpx (&out)[R0]) {
+    cpx u[R0];
+    u[0] = d[m];
+#pragma unroll
+    for (int k0 = 1; k0 < R0; ++k0) u[k0] = cmulc(d[size_t(k0) * M + m], twn[(m * k0) & nl_mask]);
+    dft_dif<R0, +1>(u);
+#pragma unroll
+    for (int n0 = 0; n0 < R0; ++n0) out[n0] = u[brev(n0, R0)];
+}
+
+template <int R0>
+__global__ __launch_bounds__(1024) void k_combine(DevCfg cfg, const cpx* __restrict__ twn,
+                                                  const cpx* __restrict__ dsub,
+                                                  const float* __restrict__ partial_x2,
+                                                  const int* __restrict__ work_list,
+                                                  const int* __restrict__ work_count,
+                                                  CorrStats* __restrict__ corr_stats,
+                                                  cpx* __restrict__ dump_corr, int dump_template) {
+    __shared__ __attribute__((aligned(16))) unsigned char scratch[2 * 16 * 32];
+    const int T = cfg.n_templates;
+    const int slot = blockIdx.x / T, tpl = blockIdx.x % T;
+    if (slot >= *work_count) return;
+    const int b = work_list[slot];
+    const int NL = R0 * M, nl_mask = NL - 1;
+    const cpx* d = dsub + (size_t(slot) * T + tpl) * NL;
+    float sums[2] = {0.f, 0.f};
+    float bestp = -1.f;
+    int bestn = 0;
+    const unsigned win_w = unsigned(cfg.corr_hi - cfg.corr_lo);
+    // n0-major order would visit lags out of order; ties are resolved through the key instead
+    unsigned long long best = 0;
+    for (int m = threadIdx.x; m < M; m += blockDim.x) {
+        cpx c[R0];
+        combine_at<R0>(d, twn, m, nl_mask, c);
+#pragma unroll
+        for (int n0 = 0; n0 < R0; ++n0) {
+            const int n = n0 * M + m;
+            const float pw = cnorm(c[n0]);
+            if (unsigned(n - cfg.corr_lo) < win_w) {
+                const unsigned long long key =
+                    ((unsigned long long)__float_as_uint(pw) << 32) | (0xFFFFFFFFu - unsigned(n));
+                best = key > best ? key : best;
+            }
+            if (cfg.cor_want_std && n < cfg.corr_len) {
+                sums[1] += pw;
+                sums[0] += __builtin_amdgcn_sqrtf(pw);
+            }
+            if (dump_corr != nullptr && tpl == dump_template) dump_corr[size_t(b) * NL + n] = c[n0];
+        }
+    }
+    (void)bestp;
+    (void)bestn;
+    double tot[2];
+    block_reduce<2, 16>(sums, tot, best, scratch, 0);
+    if (threadIdx.x == 0) {
+        CorrStats* cs = corr_stats + size_t(b) * T + tpl;
+        const int pk = int(0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu));
+        cs->pm2 = __uint_as_float(unsigned(best >> 32));
+        cs->pk = pk;
+        for (int dd = 0; dd < 3; ++dd) {
+            const int n = pk - 1 + dd;
+            float v = 0.f;
+            if (n >= 0 && n < NL) {
+                cpx c[R0];
+                combine_at<R0>(d, twn, n % M, nl_mask, c);
+                cpx sel = c[0];
+#pragma unroll
+                for (int n0 = 1; n0 < R0; ++n0) sel = (n / M == n0) ? c[n0] : sel;
+                v = cnorm(sel);
+            }
+            cs->m2[dd] = v;
+        }
+        if (tpl == 0) {
+            float s = 0.f;
+            for (int k0 = 0; k0 < R0; ++k0) s += partial_x2[size_t(slot) * R0 + k0];
+            cs->sum_x2 = s;
+        }
+        cs->sum_mag = (float)tot[0];
+        cs->sum_mag2 = (float)tot[1];
+    }
+}
+
+template <int R0>
+hipError_t prepare_r0() {
+    const void* fns[] = {
+        reinterpret_cast<const void*>(&k_carrier_sub<THR_IN_U8, R0, false, false>),
+        reinterpret_cast<const void*>(&k_carrier_sub<THR_IN_U8, R0, true, false>),
+        reinterpret_cast<const void*>(&k_carrier_sub<THR_IN_U8, R0, false, true>),
+        reinterpret_cast<const void*>(&k_carrier_sub<THR_IN_U8, R0, true, true>),
+        reinterpret_cast<const void*>(&k_carrier_sub<THR_IN_C64, R0, false, false>),
+        reinterpret_cast<const void*>(&k_carrier_sub<THR_IN_C64, R0, true, false>),
+        reinterpret_cast<const void*>(&k_carrier_sub<THR_IN_C64, R0, false, true>),
+        reinterpret_cast<const void*>(&k_carrier_sub<THR_IN_C64, R0, true, true>),
+        reinterpret_cast<const void*>(&k_correlate_sub<THR_IN_U8, R0, false>),
+        reinterpret_cast<const void*>(&k_correlate_sub<THR_IN_U8, R0, true>),
+        reinterpret_cast<const void*>(&k_correlate_sub<THR_IN_C64, R0, false>),
+        reinterpret_cast<const void*>(&k_correlate_sub<THR_IN_C64, R0, true>)};
+    for (const void* f : fns) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+template <int R0>
+hipError_t carrier_r0(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,
+                      const float2* tables, const float2* twn, float* win_pow, float* partial,
+                      CarStats* stats, float2* dump_fft, int grid, hipStream_t stream) {
+    typedef void (*fn_t)(const void*, int, DevCfg, const cpx*, const cpx*, float*, float*, cpx*);
+    const bool st = cfg.car_want_std != 0, dump = dump_fft != nullptr;
+    fn_t fn;
+    if (fmt == THR_IN_U8)
+        fn = st ? (dump ? &k_carrier_sub<THR_IN_U8, R0, true, true> : &k_carrier_sub<THR_IN_U8, R0, true, false>)
+                : (dump ? &k_carrier_sub<THR_IN_U8, R0, false, true> : &k_carrier_sub<THR_IN_U8, R0, false, false>);
+    else
+        fn = st ? (dump ? &k_carrier_sub<THR_IN_C64, R0, true, true> : &k_carrier_sub<THR_IN_C64, R0, true, false>)
+                : (dump ? &k_carrier_sub<THR_IN_C64, R0, false, true> : &k_carrier_sub<THR_IN_C64, R0, false, false>);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(NT), LDS_BYTES, stream, samples, n_blocks, cfg,
+                       reinterpret_cast<const cpx*>(tables), reinterpret_cast<const cpx*>(twn), win_pow,
+                       partial, reinterpret_cast<cpx*>(dump_fft));
+    hipLaunchKernelGGL(k_select, dim3(n_blocks), dim3(256), 0, stream, R0, cfg, win_pow, partial, stats);
+    return hipGetLastError();
+}
+
+template <int R0>
+hipError_t correlate_r0(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,
+                        const float2* tables, const float2* twn, const float4* tspec,
+                        const ShiftParams* shifts, const int* work_list, const int* work_count,
+                        float2* dsub, float* partial_x2, float4* xhat_scratch,
+                        CorrStats* corr_stats, float2* dump_xhat, float2* dump_corr,
+                        int dump_template, int grid, hipStream_t stream) {
+    typedef void (*fn_t)(const void*, DevCfg, const cpx*, const cpx*, const f4*, const ShiftParams*,
+                         const int*, const int*, f4*, float*, f4*, cpx*);
+    const bool dump = dump_xhat != nullptr;
+    fn_t fn = fmt == THR_IN_U8
+                  ? (dump ? &k_correlate_sub<THR_IN_U8, R0, true> : &k_correlate_sub<THR_IN_U8, R0, false>)
+                  : (dump ? &k_correlate_sub<THR_IN_C64, R0, true> : &k_correlate_sub<THR_IN_C64, R0, false>);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(NT), LDS_BYTES, stream, samples, cfg,
+                       reinterpret_cast<const cpx*>(tables), reinterpret_cast<const cpx*>(twn),
+                       reinterpret_cast<const f4*>(tspec), shifts, work_list, work_count,
+                       reinterpret_cast<f4*>(dsub), partial_x2, reinterpret_cast<f4*>(xhat_scratch),
+                       reinterpret_cast<cpx*>(dump_xhat));
+    hipLaunchKernelGGL(k_combine<R0>, dim3(n_blocks * cfg.n_templates), dim3(1024), 0, stream, cfg,
+                       reinterpret_cast<const cpx*>(twn), reinterpret_cast<const cpx*>(dsub),
+                       partial_x2, work_list, work_count, corr_stats,
+                       reinterpret_cast<cpx*>(dump_corr), dump_template);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool long_supported(int block_len) { return block_len == 2 * M || block_len == 4 * M; }
+
+hipError_t prepare_long(int block_len) {
+    return block_len == 2 * M ? prepare_r0<2>() : prepare_r0<4>();
+}
+
+hipError_t launch_carrier_long(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,
+                               const float2* tables, const float2* twn, float* win_pow,
+                               float* partial, CarStats* stats, float2* dump_fft, int grid,
+                               hipStream_t stream) {
+    return cfg.block_len == 2 * M
+               ? carrier_r0<2>(fmt, samples, n_blocks, cfg, tables, twn, win_pow, partial, stats,
+                               dump_fft, grid, stream)
+               : carrier_r0<4>(fmt, samples, n_blocks, cfg, tables, twn, win_pow, partial, stats,
+                               dump_fft, grid, stream);
+}
+
+hipError_t launch_correlate_long(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,
+                                 const float2* tables, const float2* twn, const float4* tspec,
+                                 const ShiftParams* shifts, const int* work_list,
+                                 const int* work_count, float2* dsub, float* partial_x2,
+                                 float4* xhat_scratch, CorrStats* corr_stats, float2* dump_xhat,
+                                 float2* dump_corr, int dump_template, int grid,
+                                 hipStream_t stream) {
+    return cfg.block_len == 2 * M
+               ? correlate_r0<2>(fmt, samples, n_blocks, cfg, tables, twn, tspec, shifts, work_list,
+                                 work_count, dsub, partial_x2, xhat_scratch, corr_stats, dump_xhat,
+                                 dump_corr, dump_template, grid, stream)
+               : correlate_r0<4>(fmt, samples, n_blocks, cfg, tables, twn, tspec, shifts, work_list,
+                                 work_count, dsub, partial_x2, xhat_scratch, corr_stats, dump_xhat,
+                                 dump_corr, dump_template, grid, stream);
+}
+
+}  // namespace thr

@@ -1,0 +1,226 @@
+// Register passes of the 16 x 32 x 32 LDS-resident FFT (512 threads, 8 waves) and their
+// mirrored inverse -- shared by detect16k.hip (block_len 16384) and detect_long.hip
+// (block_len R0 * 16384, which runs R0 of these sub-transforms per block).
+// Index algebra, LDS layout and bank-conflict reasoning: DESIGN.md section 2.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "detect_common.hpp"
+#include "fft_regs.hpp"
+#include "kernel_util.hpp"
+
+namespace thr {
+
+namespace k16 {
+constexpr int N = 16384;
+constexpr int R1 = 16, R2 = 32, R3 = 32;
+constexpr int S1 = R2 * R3;       // 1024
+constexpr int CHUNK = 34;         // 32 complex + 2 pad (16 B) -> conflict-free strided b128
+constexpr int ROW = R2 * CHUNK;   // 1088
+constexpr int NT = 512;           // threads per workgroup
+constexpr int DATA = R1 * ROW;    // 17408 complex
+// LDS carve (complex units)
+constexpr int OFF_C = DATA;             // C[32][32]  = W_1024^(a*b)
+constexpr int OFF_A = OFF_C + 1024;     // A[16][32]  = W_512^(n2*k1)   [k1][n2]
+constexpr int OFF_B = OFF_A + 512;      // Bt[16][32] = W_N^(m'*k1)     [k1][m']
+constexpr int OFF_S = OFF_B + 512;      // 128 complex (1 KiB) reduction scratch
+constexpr int LDS_CPX = OFF_S + 128;
+constexpr size_t LDS_BYTES = size_t(LDS_CPX) * sizeof(cpx);  // 156,672 B
+}  // namespace k16
+
+using namespace k16;
+
+// ---------------------------------------------------------------- LDS tables
+__device__ __forceinline__ void load_tables(cpx* lds, const cpx* __restrict__ tables) {
+    // 2048 complex = 16 KiB: 512 threads x 2 x float4
+    const f4* src = reinterpret_cast<const f4*>(tables);
+    f4* dst = reinterpret_cast<f4*>(lds + OFF_C);
+    dst[threadIdx.x] = src[threadIdx.x];
+    dst[threadIdx.x + NT] = src[threadIdx.x + NT];
+}
+
+// ---------------------------------------------------------------- sample load
+// Per-thread raw samples of one block: for each sub-sequence n1 the two adjacent
+// samples m = 2t, 2t+1 (n = n1*1024 + m).  The u8 flavour holds them in 16 VGPRs so
+// the NEXT block's HBM loads can be in flight while the current block is computed;
+// the c64 flavour (64 VGPRs if held) just remembers the address and loads at use.
+template <int FMT>
+struct RawSamples;
+
+template <>
+struct RawSamples<THR_IN_U8> {
+    unsigned q[R1];
+    __device__ __forceinline__ void load(const void* __restrict__ blk, int t) {
+        const unsigned* p = reinterpret_cast<const unsigned*>(blk) + t;
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) q[n1] = p[n1 * (S1 / 2)];
+    }
+    __device__ __forceinline__ void get(int n1, cpx& a, cpx& b) const {
+        const unsigned w = q[n1];
+        constexpr float sc = 1.0f / 128.0f, of = -127.4f / 128.0f;  // == (v - 127.4f) / 128 exactly
+        a = cpx{fmaf(float(w & 0xffu), sc, of), fmaf(float((w >> 8) & 0xffu), sc, of)};
+        b = cpx{fmaf(float((w >> 16) & 0xffu), sc, of), fmaf(float(w >> 24), sc, of)};
+    }
+};
+
+template <>
+struct RawSamples<THR_IN_C64> {
+    const f4* p;
+    __device__ __forceinline__ void load(const void* __restrict__ blk, int t) {
+        p = reinterpret_cast<const f4*>(blk) + t;
+    }
+    __device__ __forceinline__ void get(int n1, cpx& a, cpx& b) const {
+        const f4 w = p[n1 * (S1 / 2)];
+        a = cpx{w.x, w.y};
+        b = cpx{w.z, w.w};
+    }
+};
+
+// ------------------------------------------------------------ forward passes
+// Pass 1 (radix 16 over n1, two adjacent m per thread) -> LDS.
+// If PH: pre-rotate x[n1] by rpow[n1] and fold the per-m phasor p0/p1 into the twiddle.
+template <bool PH, class RAW>
+__device__ __forceinline__ void fwd_pass1(cpx* lds, const RAW& raw,
+                                          const float2* __restrict__ rpow, cpx p0, cpx p1,
+                                          float* energy = nullptr) {
+    const int t = opaque_tid();
+    cpx v0[R1], v1[R1];
+    float e = 0.f;
+#pragma unroll
+    for (int n1 = 0; n1 < R1; ++n1) {
+        raw.get(n1, v0[n1], v1[n1]);
+        if (energy != nullptr) e += cnorm(v0[n1]) + cnorm(v1[n1]);  // time-domain sum |x|^2
+        if constexpr (PH) {
+            const cpx r = cpx{rpow[n1].x, rpow[n1].y};
+            v0[n1] = cmul(v0[n1], r);
+            v1[n1] = cmul(v1[n1], r);
+        }
+    }
+    if (energy != nullptr) *energy = e;
+    dft_dif<R1, -1>(v0);
+    dft_dif<R1, -1>(v1);
+    const int n2 = t >> 4, mp = 2 * (t & 15);
+    const cpx* tA = lds + OFF_A;
+    const cpx* tB = lds + OFF_B;
+    f4* out = reinterpret_cast<f4*>(lds + n2 * CHUNK + mp);
+    static_for<R1>([&](auto K) {
+        constexpr int k1 = decltype(K)::value;
+        constexpr int src = brev(k1, R1);
+        cpx y0 = v0[src], y1 = v1[src];
+        if constexpr (k1 == 0) {
+            if constexpr (PH) {
+                y0 = cmul(y0, p0);
+                y1 = cmul(y1, p1);
+            }
+        } else {
+            const cpx a = tA[k1 * 32 + n2];
+            const f4 bb = *reinterpret_cast<const f4*>(tB + k1 * 32 + mp);
+            cpx w0 = cmul(a, cpx{bb.x, bb.y});
+            cpx w1 = cmul(a, cpx{bb.z, bb.w});
+            if constexpr (PH) {
+                w0 = cmul(w0, p0);
+                w1 = cmul(w1, p1);
+            }
+            y0 = cmul(y0, w0);
+            y1 = cmul(y1, w1);
+        }
+        out[k1 * (ROW / 2)] = f4{y0.x, y0.y, y1.x, y1.y};
+    });
+}
+
+// Pass 2 (radix 32 over n2, in place) -- thread (k1 = t>>5, m' = t&31).
+// KEEP < 32: only outputs k2 < KEEP are written back (pruned FFT: bins k2 >= KEEP unused).
+template <int KEEP = R2>
+__device__ __forceinline__ void fwd_pass2(cpx* lds) {
+    const int t = opaque_tid();
+    const int k1 = t >> 5, mp = t & 31;
+    cpx* base = lds + k1 * ROW + mp;
+    const cpx* tC = lds + OFF_C + mp;
+    cpx v[R2];
+#pragma unroll
+    for (int n2 = 0; n2 < R2; ++n2) v[n2] = base[n2 * CHUNK];
+    dft_dif<R2, -1>(v);
+    static_for<KEEP>([&](auto K) {
+        constexpr int k2 = decltype(K)::value;
+        cpx y = v[brev(k2, R2)];
+        if constexpr (k2 != 0) y = cmul(y, tC[k2 * 32]);
+        base[k2 * CHUNK] = y;
+    });
+}
+
+// Pass 3 (radix 32 over m', registers only) -- thread (k1 = t>>5, k2 = t&31).
+// On return bin k = k1 + 16*k2 + 512*k3 is in v[brev(k3, 32)].
+__device__ __forceinline__ void fwd_pass3(const cpx* lds, cpx* v) {
+    const int t = opaque_tid();
+    const f4* src = reinterpret_cast<const f4*>(lds + (t >> 5) * ROW + (t & 31) * CHUNK);
+#pragma unroll
+    for (int j = 0; j < R3 / 2; ++j) {
+        const f4 q = src[j];
+        v[2 * j] = cpx{q.x, q.y};
+        v[2 * j + 1] = cpx{q.z, q.w};
+    }
+    dft_dif<R3, -1>(v);
+}
+
+// ------------------------------------------------------------ inverse passes
+// Pass A (radix 32 over k3, registers) then twiddle conj(W_1024^(n3*k2)) -> LDS.
+// Input: z[brev(k3)] = Z[k1,k2,k3] (same placement fwd_pass3 produces).
+__device__ __forceinline__ void inv_passA(cpx* lds, cpx* z) {
+    const int t = opaque_tid();
+    const int k2 = t & 31;
+    // z is indexed by brev(k3); a DIF butterfly wants natural order input. Re-label:
+    cpx v[R3];
+    static_for<R3>([&](auto K) {
+        constexpr int k3 = decltype(K)::value;
+        v[k3] = z[brev(k3, R3)];
+    });
+    dft_dif<R3, +1>(v);
+    const cpx* tC = lds + OFF_C + k2;
+    f4* dst = reinterpret_cast<f4*>(lds + (t >> 5) * ROW + k2 * CHUNK);
+    static_for<R3 / 2>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        cpx y0 = v[brev(2 * j, R3)], y1 = v[brev(2 * j + 1, R3)];
+        if constexpr (j != 0) y0 = cmulc(y0, tC[(2 * j) * 32]);
+        y1 = cmulc(y1, tC[(2 * j + 1) * 32]);
+        dst[j] = f4{y0.x, y0.y, y1.x, y1.y};
+    });
+}
+
+// Pass B (radix 32 over k2, in place) -- thread (k1 = t>>5, n3 = t&31);
+// twiddle conj(W_N^(k1*(32*n2 + n3))) = conj(A[k1][n2] * Bt[k1][n3]).
+__device__ __forceinline__ void inv_passB(cpx* lds) {
+    const int t = opaque_tid();
+    const int k1 = t >> 5, n3 = t & 31;
+    cpx* base = lds + k1 * ROW + n3;
+    cpx v[R2];
+#pragma unroll
+    for (int k2 = 0; k2 < R2; ++k2) v[k2] = base[k2 * CHUNK];
+    dft_dif<R2, +1>(v);
+    const cpx b = lds[OFF_B + k1 * 32 + n3];
+    const cpx* tA = lds + OFF_A + k1 * 32;
+    static_for<R2>([&](auto K) {
+        constexpr int n2 = decltype(K)::value;
+        cpx y = v[brev(n2, R2)];
+        cpx w = b;
+        if constexpr (n2 != 0) w = cmul(tA[n2], b);
+        base[n2 * CHUNK] = cmulc(y, w);
+    });
+}
+
+// Pass C (radix 16 over k1, two adjacent m per thread), registers out:
+// c0[brev(n1)] = corr[n1*1024 + 2t], c1[...] = corr[n1*1024 + 2t + 1].
+__device__ __forceinline__ void inv_passC(const cpx* lds, cpx* c0, cpx* c1) {
+    const int t = opaque_tid();
+    const int n2 = t >> 4, mp = 2 * (t & 15);
+    const f4* src = reinterpret_cast<const f4*>(lds + n2 * CHUNK + mp);
+#pragma unroll
+    for (int k1 = 0; k1 < R1; ++k1) {
+        const f4 q = src[k1 * (ROW / 2)];
+        c0[k1] = cpx{q.x, q.y};
+        c1[k1] = cpx{q.z, q.w};
+    }
+    dft_dif<R1, +1>(c0);
+    dft_dif<R1, +1>(c1);
+}
+
+}  // namespace thr
