@@ -114,6 +114,18 @@ int thr_detect(thr_handle* h, const void* samples, int format, const int64_t* bl
                size_t n_blocks, thr_record* out);
 
 /*
+ * .card form (ingest on the device).  `text` holds .card records
+ * "<timestamp> <block_idx> <base64 of 2*block_len bytes>" (block_data.py:120-131;
+ * fastcard_cli.c:187-192); `payload_off[i]` is the byte offset of the i-th block's base64
+ * payload inside `text` (the host only splits lines).  The text crosses PCIe once and is
+ * decoded on the device (replaces base64.b64decode + np.fromstring, block_data.py:129, and
+ * fastcard/lib/base64.c), then processed exactly like thr_detect().  Host pointers,
+ * synchronous.  Invalid base64 -> THR_ERR_ARG.
+ */
+int thr_detect_card(thr_handle* h, const char* text, size_t text_len, const int64_t* payload_off,
+                    const int64_t* block_idx, size_t n_blocks, thr_record* out);
+
+/*
  * Device-resident form (what bench.py times): `d_samples`, `d_block_idx`
  * (may be NULL) and `d_out` are device pointers on the handle's device.  The
  * work is enqueued on the handle's stream and NOT synchronised; call

@@ -220,3 +220,37 @@ def test_bad_settings_rejected():
     _lib_or_skip()
     with pytest.raises(_native.NativeError):
         _native.Engine(16000, 4096, np.ones(1023), (0, 15, 0), (7, 110), (0, 15, 0))  # not 2^k
+
+
+# ---------------------------------------------------------------- CardStream framing (host part of f1)
+def test_card_stream_framing_matches_card_reader(golden):
+    g = golden("small")
+    text = str(g["card_text"])
+    ref = list(block_data.card_reader(io.StringIO(text)))
+    for chunk in (1, 20000, 1 << 20):                     # refills in the middle of lines too
+        cs = block_data.CardStream(io.BytesIO(text.encode()), 4096, chunk_bytes=chunk)
+        got = []
+        while True:
+            batch = cs.next_batch(5)
+            if batch is None:
+                break
+            stamps, idxs, buf, offs = batch
+            assert len(stamps) <= 5 and idxs.dtype == np.int64
+            for ts, idx, off in zip(stamps, idxs, offs):
+                import base64
+                raw = np.frombuffer(base64.b64decode(bytes(buf[off:off + cs.payload_chars])), np.uint8)
+                got.append((ts, int(idx), raw))
+        assert [(a, b) for a, b, _ in got] == [(r[0], r[1]) for r in ref]
+        assert all(np.array_equal(x[2], r[2].raw) for x, r in zip(got, ref))
+    # iterable like card_reader, text-mode streams and CRLF line ends included
+    crlf = text.replace("\n", "\r\n")
+    it = list(block_data.CardStream(io.StringIO(crlf), 4096))
+    assert len(it) == len(ref) and all(np.array_equal(a[2], b[2]) for a, b in zip(it, ref))
+
+
+def test_card_stream_rejects_malformed_lines():
+    with pytest.raises(ValueError):
+        block_data.CardStream(io.BytesIO(b"1000.5 7 QUJD\n"), 4096).next_batch(1)     # short payload
+    with pytest.raises(ValueError):
+        block_data.CardStream(io.BytesIO(b"garbage-without-fields\n"), 4096).next_batch(1)
+    assert block_data.CardStream(io.BytesIO(b"# only comments\n\n"), 4096).next_batch(1) is None

@@ -22,7 +22,7 @@ N_KERNEL_SLOTS = 4
 
 EXPORTS = [
     "thr_abi_version", "thr_last_error", "thr_create", "thr_destroy", "thr_detect",
-    "thr_detect_device", "thr_sync", "thr_set_stream", "thr_compact_device",
+    "thr_detect_card", "thr_detect_device", "thr_sync", "thr_set_stream", "thr_compact_device",
     "thr_profile_enable", "thr_profile_read", "thr_kernel_name", "thr_debug_fft",
     "thr_debug_stage",
 ]
@@ -104,6 +104,7 @@ def load_library():
     lib.thr_destroy.argtypes = [vp]
     lib.thr_destroy.restype = None
     lib.thr_detect.argtypes = [vp, vp, C.c_int, vp, C.c_size_t, vp]
+    lib.thr_detect_card.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_size_t, vp]
     lib.thr_detect_device.argtypes = [vp, vp, C.c_int, vp, C.c_size_t, vp]
     lib.thr_sync.argtypes = [vp]
     lib.thr_set_stream.argtypes = [vp, vp]
@@ -179,6 +180,22 @@ class Engine(object):
             idx_p = idx.ctypes.data
         _check(self._lib, self._lib.thr_detect(self._h, a.ctypes.data, fmt, idx_p, nb,
                                                out.ctypes.data))
+        return out
+
+    def detect_card(self, text, payload_off, block_idx=None):
+        """text: bytes-like holding .card records; payload_off: int64 offsets of each block's
+        base64 payload.  Decoding happens on the device.  -> records [B, n_templates]."""
+        buf = np.frombuffer(text, dtype=np.uint8)
+        off = np.ascontiguousarray(np.asarray(payload_off, dtype=np.int64))
+        nb = off.shape[0]
+        out = np.zeros((nb, self.n_templates), dtype=RECORD_DTYPE)
+        idx_p = None
+        if block_idx is not None:
+            idx = np.ascontiguousarray(np.asarray(block_idx, dtype=np.int64))
+            assert idx.shape == (nb,)
+            idx_p = idx.ctypes.data
+        _check(self._lib, self._lib.thr_detect_card(self._h, buf.ctypes.data, buf.size,
+                                                    off.ctypes.data, idx_p, nb, out.ctypes.data))
         return out
 
     # ---- device-resident path (pointers are plain integers) ---------------

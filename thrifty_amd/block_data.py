@@ -102,6 +102,102 @@ def card_reader(stream):
         yield float(timestamp), int(idx), IQBlock(raw_to_complex(raw), raw)
 
 
+class CardStream(object):
+    """Batch-oriented .card reader for the GPU engine.
+
+    The host only *finds* the records -- line ends, the two header fields, the offset of
+    the base64 payload -- in large binary chunks; the payload text itself is handed to
+    the device untouched (`Engine.detect_card`) and decoded there.  Skips the same lines
+    as `card_reader` (comments, blanks, fastcard banners).  Also iterable as a plain
+    `(timestamp, block_idx, IQBlock)` reader (host decode) for drop-in use.
+    """
+
+    def __init__(self, stream, block_len, chunk_bytes=64 << 20):
+        self.stream = stream
+        self.block_len = int(block_len)
+        self.payload_chars = ((2 * self.block_len + 2) // 3) * 4
+        line_max = self.payload_chars + 128
+        self.chunk_bytes = max(int(chunk_bytes), 2 * line_max)
+        # ONE reusable buffer: refills move the unconsumed tail (< one line) to the front and
+        # read the next chunk in place -- no per-chunk reallocation / concatenation copies
+        self._buf = bytearray(self.chunk_bytes)
+        self._pos = 0   # first unconsumed byte
+        self._end = 0   # one past the last valid byte
+        self._eof = False
+
+    def _fill(self):
+        """Compact the unconsumed tail to the front and read more; returns bytes added."""
+        if self._eof:
+            return 0
+        tail = self._end - self._pos
+        if self._pos:
+            self._buf[:tail] = self._buf[self._pos:self._end]
+            self._pos, self._end = 0, tail
+        room = len(self._buf) - self._end
+        if room == 0:  # a single line longer than the buffer: grow (malformed input ends up here)
+            self._buf.extend(bytes(len(self._buf)))
+            room = len(self._buf) - self._end
+        view = memoryview(self._buf)[self._end:self._end + room]
+        if hasattr(self.stream, "readinto"):
+            got = self.stream.readinto(view) or 0
+        else:
+            more = self.stream.read(room)
+            if isinstance(more, str):
+                more = more.encode("ascii")
+            got = len(more)
+            view[:got] = more
+        if got == 0:
+            self._eof = True
+        self._end += got
+        return got
+
+    def next_batch(self, max_blocks):
+        """-> (timestamps, block_idx int64[n], text bytearray, payload_off int64[n]) or None at EOF.
+        `text` is this reader's buffer: valid until the next call."""
+        stamps, idxs, offs = [], [], []
+        buf = self._buf
+        while len(offs) < max_blocks:
+            end = buf.find(b"\n", self._pos, self._end)
+            if end < 0:
+                if offs:
+                    break          # never let a batch straddle a refill: offsets index ONE buffer state
+                if self._fill():
+                    buf = self._buf
+                    continue
+                if self._pos >= self._end:
+                    break
+                end = self._end    # last line without newline
+            start, self._pos = self._pos, min(end + 1, self._end)
+            stop = end - 1 if end > start and buf[end - 1] == 0x0D else end
+            if stop <= start or buf[start] == 0x23:      # blank or '#'
+                continue
+            if buf.startswith(b"Using Volk machine:", start) or buf.startswith(b"linux;", start):
+                continue
+            sp1 = buf.find(b" ", start, stop)
+            sp2 = buf.find(b" ", sp1 + 1, stop)
+            if sp1 < 0 or sp2 < 0:
+                raise ValueError("malformed .card line: %r" % bytes(buf[start:min(stop, start + 60)]))
+            if stop - (sp2 + 1) != self.payload_chars:
+                raise ValueError("block %s: payload of %d base64 characters, expected %d (block_len %d)" % (
+                    bytes(buf[sp1 + 1:sp2]).decode(), stop - (sp2 + 1), self.payload_chars, self.block_len))
+            stamps.append(float(buf[start:sp1]))
+            idxs.append(int(buf[sp1 + 1:sp2]))
+            offs.append(sp2 + 1)
+        if not offs:
+            return None
+        return stamps, np.asarray(idxs, dtype=np.int64), buf, np.asarray(offs, dtype=np.int64)
+
+    def __iter__(self):
+        while True:
+            batch = self.next_batch(64)
+            if batch is None:
+                return
+            stamps, idxs, text, offs = batch
+            for ts, idx, off in zip(stamps, idxs, offs):
+                raw = np.frombuffer(base64.b64decode(bytes(text[off:off + self.payload_chars])), dtype=np.uint8)
+                yield ts, int(idx), IQBlock(raw_to_complex(raw), raw)
+
+
 def card_line(timestamp, block_idx, raw):
     """Format one .card line (fastcard_cli.c:187-192: "%ld.%06ld %PRId64 %s\\n")."""
     sec = int(timestamp)

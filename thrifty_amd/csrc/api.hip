@@ -105,6 +105,11 @@ struct thr_handle {
     int* d_work_count = nullptr;
     float4* d_xhat_scratch = nullptr;
     int* d_ncompact = nullptr;
+    // .card ingest staging (lazy)
+    unsigned char* d_text = nullptr;
+    size_t d_text_bytes = 0;
+    long long* d_payload_off = nullptr;
+    int* d_bad = nullptr;
     // host-path staging (lazy)
     void* d_in = nullptr;
     size_t d_in_bytes = 0;
@@ -560,7 +565,7 @@ void thr_destroy(thr_handle* h) {
         hipEventDestroy(e.a);
         hipEventDestroy(e.b);
     }
-    void* bufs[] = {h->d_tables, h->d_twn, h->d_tspec, h->d_stats, h->d_shifts, h->d_corr_stats, h->d_gen_scratch, h->d_tspec_nat, h->d_win_pow, h->d_partial, h->d_partial_x2, h->d_dsub, h->d_work_list,
+    void* bufs[] = {h->d_tables, h->d_twn, h->d_tspec, h->d_stats, h->d_shifts, h->d_corr_stats, h->d_text, h->d_payload_off, h->d_bad, h->d_gen_scratch, h->d_tspec_nat, h->d_win_pow, h->d_partial, h->d_partial_x2, h->d_dsub, h->d_work_list,
                     h->d_work_count, h->d_xhat_scratch, h->d_ncompact, h->d_in, h->d_idx, h->d_rec};
     for (void* b : bufs)
         if (b) hipFree(b);
@@ -622,6 +627,67 @@ int thr_detect(thr_handle* h, const void* samples, int format, const int64_t* bl
         HIP_TRY(hipMemcpyAsync(out + done * nt, h->d_rec, nb * nt * sizeof(thr_record),
                                hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
+        done += nb;
+    }
+    return THR_OK;
+}
+
+int thr_detect_card(thr_handle* h, const char* text, size_t text_len, const int64_t* payload_off,
+                    const int64_t* block_idx, size_t n_blocks, thr_record* out) {
+    if (!h || !text || !payload_off || !out) return fail(THR_ERR_ARG, "thr_detect_card: null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = ensure_staging(h, THR_IN_U8);
+    if (rc != THR_OK) return rc;
+    const size_t out_bytes = size_t(h->cfg.block_len) * 2;
+    const size_t chars = ((out_bytes + 2) / 3) * 4;  // base64 payload length of one block
+    const size_t nt = size_t(h->cfg.n_templates);
+    if (!h->d_payload_off)
+        HIP_TRY(hipMalloc(&h->d_payload_off, size_t(h->cfg.max_batch) * sizeof(long long)));
+    if (!h->d_bad) HIP_TRY(hipMalloc(&h->d_bad, sizeof(int)));
+    std::vector<long long> rel;
+    for (size_t done = 0; done < n_blocks;) {
+        const size_t nb = std::min(n_blocks - done, size_t(h->cfg.max_batch));
+        // contiguous span of text covering this chunk's payloads
+        long long lo = payload_off[done], hi = payload_off[done];
+        for (size_t i = 0; i < nb; ++i) {
+            const long long o = payload_off[done + i];
+            if (o < 0 || size_t(o) + chars > text_len)
+                return fail(THR_ERR_ARG, "payload %zu (offset %lld, %zu chars) lies outside the text",
+                            done + i, o, chars);
+            lo = std::min(lo, o);
+            hi = std::max(hi, o);
+        }
+        const size_t span = size_t(hi - lo) + chars;
+        if (h->d_text_bytes < span) {
+            if (h->d_text) hipFree(h->d_text);
+            h->d_text = nullptr;
+            h->d_text_bytes = 0;
+            HIP_TRY(hipMalloc(&h->d_text, span + (span >> 2)));
+            h->d_text_bytes = span + (span >> 2);
+        }
+        rel.resize(nb);
+        for (size_t i = 0; i < nb; ++i) rel[i] = payload_off[done + i] - lo;
+        HIP_TRY(hipMemcpyAsync(h->d_text, text + lo, span, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->d_payload_off, rel.data(), nb * sizeof(long long),
+                               hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemsetAsync(h->d_bad, 0, sizeof(int), h->stream));
+        std::vector<long long> idx(nb);
+        for (size_t i = 0; i < nb; ++i) idx[i] = block_idx ? block_idx[done + i] : (long long)(done + i);
+        HIP_TRY(hipMemcpyAsync(h->d_idx, idx.data(), nb * sizeof(long long), hipMemcpyHostToDevice,
+                               h->stream));
+        HIP_TRY(thr::launch_b64_decode(h->d_text, h->d_payload_off, int(nb), int(out_bytes),
+                                       static_cast<unsigned char*>(h->d_in), h->d_bad, h->stream));
+        rc = run_batch(h, h->d_in, THR_IN_U8, h->d_idx, int(nb), h->d_rec, nullptr, nullptr, nullptr, 0,
+                       false);
+        if (rc != THR_OK) return rc;
+        int bad = 0;
+        HIP_TRY(hipMemcpyAsync(&bad, h->d_bad, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(out + done * nt, h->d_rec, nb * nt * sizeof(thr_record),
+                               hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));  // also keeps rel/idx alive until copied
+        if (bad != 0)
+            return fail(THR_ERR_ARG, "%d .card payload(s) in blocks [%zu, %zu) are not valid base64",
+                        bad, done, done + nb);
         done += nb;
     }
     return THR_OK;

@@ -110,6 +110,10 @@ hipError_t launch_correlate_long(int fmt, const void* samples, int n_blocks, con
                                  float2* dump_corr, int dump_template, int grid,
                                  hipStream_t stream);
 
+// card_ingest.hip (.card base64 payloads -> u8 IQ on the device)
+hipError_t launch_b64_decode(const unsigned char* d_text, const long long* d_payload_off, int n_lines,
+                             int out_bytes, unsigned char* d_out, int* d_bad, hipStream_t stream);
+
 // generic.hip (any power-of-two block length; multi-pass through HBM)
 size_t generic_scratch_bytes(int n, int n_blocks);
 hipError_t generic_carrier(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,

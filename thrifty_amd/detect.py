@@ -18,7 +18,7 @@ from types import SimpleNamespace
 import numpy as np
 
 from thrifty_amd import _native, toads_data, util
-from thrifty_amd.block_data import block_reader, card_reader
+from thrifty_amd.block_data import CardStream, block_reader, card_reader
 from thrifty_amd.setting_parsers import normalize_freq_range
 from thrifty_amd.settings import load_args
 
@@ -47,6 +47,8 @@ class Detector(object):
     def __init__(self, settings, blocks=None, rxid=-1, yield_data=False, batch_size=256,
                  device_id=0):
         self.settings = settings
+        # a CardStream is consumed in whole batches with the base64 payloads decoded on the GPU
+        self._card = blocks if isinstance(blocks, CardStream) and not yield_data else None
         self.blocks = iter(blocks) if blocks is not None else None
         self.rxid = rxid
         self.yield_data = yield_data
@@ -104,6 +106,33 @@ class Detector(object):
         return detected, toads_data.DetectionResult(timestamp, block_idx, soa, carrier, corr,
                                                     self.rxid)
 
+    def _results(self, stamps, idxs, recs):
+        """Vectorised re-hydration of a batch of records (one .tolist() per column instead of
+        ten numpy-scalar look-ups per block)."""
+        flags = recs["flags"]
+        if np.any(flags & _native.FLAG_INDEX_ERROR) :
+            return [self._result(stamps[i], int(idxs[i]), recs[i]) for i in range(len(recs))]
+        fl = flags.tolist()
+        cbin = recs["carrier_bin"].tolist()
+        coff = recs["carrier_offset"].tolist()
+        cen, cno = recs["carrier_energy"], recs["carrier_noise"]     # stay np.float32
+        samp = recs["corr_sample"].tolist()
+        soff = recs["corr_offset"].tolist()
+        en = recs["corr_energy"].astype(np.float64).tolist()
+        no = recs["corr_noise"].astype(np.float64).tolist()
+        out = []
+        Car, Cor, Res = toads_data.CarrierSyncInfo, toads_data.CorrDetectionInfo, toads_data.DetectionResult
+        for i in range(len(fl)):
+            f, bi = fl[i], int(idxs[i])
+            if not f & _native.FLAG_CARRIER:
+                out.append((False, Res(stamps[i], bi, None, Car(cbin[i], 0, cen[i], cno[i]), None, self.rxid)))
+                continue
+            det = bool(f & _native.FLAG_CORR)
+            cor = Cor(samp[i], soff[i] if det else 0, en[i], no[i])
+            out.append((det, Res(stamps[i], bi, self.new_len * bi + cor.sample + cor.offset,
+                                 Car(cbin[i], coff[i], cen[i], cno[i]), cor, self.rxid)))
+        return out
+
     def detect_batch(self, items):
         """[(timestamp, block_idx, block), ...] -> [(detected, DetectionResult), ...]."""
         if not items:
@@ -111,7 +140,7 @@ class Detector(object):
         arr = self._stack([it[2] for it in items])
         idx = np.array([int(it[1]) for it in items], dtype=np.int64)
         recs = self._engine.detect(arr, idx)[:, 0]
-        return [self._result(it[0], int(it[1]), recs[i]) for i, it in enumerate(items)]
+        return self._results([it[0] for it in items], idx, recs)
 
     def detect(self, timestamp, block_idx, block):
         """Process one block (reference detect.py:60-78)."""
@@ -128,6 +157,15 @@ class Detector(object):
 
     # -------------------------------------------------------------- iterator
     def _refill(self):
+        if self._card is not None:
+            batch = self._card.next_batch(self.batch_size)
+            if batch is None:
+                self._exhausted = True
+                return
+            stamps, idxs, text, offs = batch
+            recs = self._engine.detect_card(text, offs, idxs)[:, 0]
+            self._ready.extend(self._results(stamps, idxs, recs))
+            return
         items = []
         while len(items) < self.batch_size and not self._exhausted:
             try:
@@ -180,6 +218,33 @@ class MultiTemplateDetector(object):
         self._single = Detector.__new__(Detector)  # reuse record re-hydration
         self._single.settings, self._single.rxid, self._single.new_len = settings, rxid, self.new_len
         self._ready = deque()
+
+    def _results(self, stamps, idxs, recs):
+        """Vectorised re-hydration of a batch of records (one .tolist() per column instead of
+        ten numpy-scalar look-ups per block)."""
+        flags = recs["flags"]
+        if np.any(flags & _native.FLAG_INDEX_ERROR) :
+            return [self._result(stamps[i], int(idxs[i]), recs[i]) for i in range(len(recs))]
+        fl = flags.tolist()
+        cbin = recs["carrier_bin"].tolist()
+        coff = recs["carrier_offset"].tolist()
+        cen, cno = recs["carrier_energy"], recs["carrier_noise"]     # stay np.float32
+        samp = recs["corr_sample"].tolist()
+        soff = recs["corr_offset"].tolist()
+        en = recs["corr_energy"].astype(np.float64).tolist()
+        no = recs["corr_noise"].astype(np.float64).tolist()
+        out = []
+        Car, Cor, Res = toads_data.CarrierSyncInfo, toads_data.CorrDetectionInfo, toads_data.DetectionResult
+        for i in range(len(fl)):
+            f, bi = fl[i], int(idxs[i])
+            if not f & _native.FLAG_CARRIER:
+                out.append((False, Res(stamps[i], bi, None, Car(cbin[i], 0, cen[i], cno[i]), None, self.rxid)))
+                continue
+            det = bool(f & _native.FLAG_CORR)
+            cor = Cor(samp[i], soff[i] if det else 0, en[i], no[i])
+            out.append((det, Res(stamps[i], bi, self.new_len * bi + cor.sample + cor.offset,
+                                 Car(cbin[i], coff[i], cen[i], cno[i]), cor, self.rxid)))
+        return out
 
     def detect_batch(self, items):
         if not items:
@@ -272,7 +337,9 @@ def detector_cli(detector_class, parser=None, extra_args=None, argv=None):
     if args.raw:
         blocks = block_reader(args.input, config.block_size, config.block_history)
     else:
-        blocks = card_reader(args.input)
+        # binary stream -> batches with on-device base64 decode (card_reader-compatible tuples
+        # if the detector class iterates it the classic way)
+        blocks = CardStream(args.input, config.block_size)
     template = np.load(config.template)
     settings = DetectorSettings(block_len=config.block_size, history_len=config.block_history,
                                 carrier_len=len(template), carrier_thresh=config.carrier_threshold,
