@@ -61,13 +61,14 @@ __global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples
         fwd_pass1<false>(lds, cur, nullptr, cpx{}, cpx{});
         cur = nxt;
         __syncthreads();
-        if (cfg.ablate == 1) continue;
+        THR_ABLATE_AT(1, continue);
         // passes 2 and 3 of row k1 are done by the same half-wave: no barrier between them
         fwd_pass2(lds);
         __builtin_amdgcn_sched_barrier(0);  // keep the passes' register working sets apart
-        if (cfg.ablate == 2) { __syncthreads(); continue; }
+        THR_ABLATE_AT(2, { __syncthreads(); continue; });
         cpx v[R3];
         fwd_pass3(lds, v);
+#ifdef THR_DEV_ABLATE
         if (cfg.ablate == 3) {
             float acc = 0;
 #pragma unroll
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples
             __syncthreads();
             continue;
         }
+#endif
 
         // ---- statistics over the spectrum held in registers
         const int t = opaque_tid();
@@ -503,15 +505,16 @@ __global__ __launch_bounds__(NT) void k_correlate(
         THR_STAMP(3);
         __syncthreads();
         THR_STAMP(4);
-        if (cfg.ablate == 11) continue;
+        THR_ABLATE_AT(11, continue);
         // rows k1 = 2w, 2w+1 belong to wave w through passes 2, 3, A and B: no barriers
         fwd_pass2(lds);
         __builtin_amdgcn_sched_barrier(0);  // keep the passes' register working sets apart
         THR_STAMP(5);
-        if (cfg.ablate == 12) { __syncthreads(); continue; }
+        THR_ABLATE_AT(12, { __syncthreads(); continue; });
         cpx xh[R3];
         fwd_pass3(lds, xh);
         THR_STAMP(6);
+#ifdef THR_DEV_ABLATE
         if (cfg.ablate == 13) {
             float acc = 0;
 #pragma unroll
@@ -520,6 +523,7 @@ __global__ __launch_bounds__(NT) void k_correlate(
             __syncthreads();
             continue;
         }
+#endif
 
         const int kbase = (t >> 5) + 16 * (t & 31);
         float e2 = 0.f;
@@ -572,15 +576,16 @@ __global__ __launch_bounds__(NT) void k_correlate(
             inv_passA(lds, z);
             __builtin_amdgcn_sched_barrier(0);
             THR_STAMP(7);
-            if (cfg.ablate == 14) { __syncthreads(); continue; }
+            THR_ABLATE_AT(14, { __syncthreads(); continue; });
             inv_passB(lds);
             THR_STAMP(8);
             __syncthreads();
             THR_STAMP(9);
-            if (cfg.ablate == 15) continue;
+            THR_ABLATE_AT(15, continue);
             cpx c0[R1], c1[R1];
             inv_passC(lds, c0, c1);
             THR_STAMP(10);
+#ifdef THR_DEV_ABLATE
             if (cfg.ablate == 16) {
                 float acc = 0;
 #pragma unroll
@@ -589,6 +594,7 @@ __global__ __launch_bounds__(NT) void k_correlate(
                 __syncthreads();
                 continue;
             }
+#endif
 
             // ---- |corr|^2, windowed first-max, optional std sums
             // per-thread first-max in float (lags visited in increasing n, strict '>'), one

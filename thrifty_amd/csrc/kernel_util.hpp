@@ -13,6 +13,15 @@ __device__ __forceinline__ int opaque_tid() {
     return t;
 }
 
+// Dev-only phase ablation (-DTHR_DEV_ABLATE, env THR_ABLATE=n): leave each block after phase n
+// so that cumulative phase costs can be read off the kernel time (results are garbage).
+#ifdef THR_DEV_ABLATE
+#define THR_ABLATE_AT(code, stmt) \
+    if (cfg.ablate == (code)) stmt
+#else
+#define THR_ABLATE_AT(code, stmt) do { } while (0)
+#endif
+
 // Dev-only cycle timeline (-DTHR_TIMELINE): workgroup 0 records s_memtime at phase
 // boundaries of its 4th block, one row of 16 stamps per wave, into cfg.timeline.
 #ifdef THR_TIMELINE
