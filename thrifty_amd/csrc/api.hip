@@ -517,7 +517,9 @@ int thr_create(const thr_settings* s, thr_handle** out) {
         if (h->lng) {
             CREATE_TRY(thr::prepare_long(n));
             const int r0 = n / 16384;
-            h->long_batch = std::min(s->max_batch, 128);
+            // sub-batch: large enough to amortise the small kernels' launch latency, small enough
+            // that the per-(block, template) sub-transform outputs stay around 0.5 GiB
+            h->long_batch = std::min(s->max_batch, std::max(64, 1024 / s->n_templates));
             const size_t lb = size_t(h->long_batch);
             const size_t win_w = size_t(std::min(h->dev.win_count + 6, n));
             CREATE_TRY(hipMalloc(&h->d_win_pow, lb * win_w * sizeof(float)));

@@ -123,7 +123,14 @@ __global__ __launch_bounds__(NT) void k_carrier_sub(const void* __restrict__ sam
     const int win_base = cfg.win_lo - 3;
     int parity = 0;
 
-    for (int item = blockIdx.x; item < n_blocks * R0; item += gridDim.x) {
+    // With enough blocks a workgroup runs the R0 sub-transforms of ONE block back to back:
+    // each of them reads all of the block's samples, so k0 >= 1 finds them in L2.
+    const bool per_block = n_blocks >= int(gridDim.x);
+    const int n_iter = per_block ? ((n_blocks - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x)) * R0
+                                 : (n_blocks * R0 - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x);
+    for (int it = 0; it < n_iter; ++it) {
+        const int item = per_block ? (int(blockIdx.x) + (it / R0) * int(gridDim.x)) * R0 + it % R0
+                                   : int(blockIdx.x) + it * int(gridDim.x);
         const int b = item / R0, k0 = item % R0;
         const int t = opaque_tid();
         __syncthreads();  // scratch factors of the previous item are no longer read
@@ -234,7 +241,12 @@ __global__ __launch_bounds__(NT) void k_correlate_sub(
     const int T = cfg.n_templates;
     int parity = 0;
 
-    for (int item = blockIdx.x; item < n_work * R0; item += gridDim.x) {
+    const bool per_block = n_work >= int(gridDim.x);
+    const int n_iter = per_block ? ((n_work - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x)) * R0
+                                 : (n_work * R0 - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x);
+    for (int it = 0; it < n_iter; ++it) {
+        const int item = per_block ? (int(blockIdx.x) + (it / R0) * int(gridDim.x)) * R0 + it % R0
+                                   : int(blockIdx.x) + it * int(gridDim.x);
         const int slot = item / R0, k0 = item % R0;
         const int b = work_list[slot];
         const int t = opaque_tid();
