@@ -35,17 +35,21 @@ def build_native(force=False, verbose=False):
     """Compile every HIP source for gfx950 and link libthriftyhip.so."""
     if not force and not needs_build():
         return LIB
-    objs = []
+    # -fno-slp-vectorize: the kernels are hand-vectorised with ext-vector float2;
+    # the SLP vectorizer only adds v_mov shuffles (see csrc/fft_regs.hpp)
+    extra = os.environ.get("THR_EXTRA_CFLAGS", "").split()
+    jobs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        # -fno-slp-vectorize: the kernels are hand-vectorised with ext-vector float2;
-        # the SLP vectorizer only adds v_mov shuffles (see csrc/fft_regs.hpp)
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
-               "-fno-slp-vectorize"] + os.environ.get("THR_EXTRA_CFLAGS", "").split() + [
-               "-c", os.path.join(CSRC, src), "-o", obj]
+               "-fno-slp-vectorize"] + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        jobs.append((subprocess.Popen(cmd), cmd, obj))   # the translation units build in parallel
+    objs = []
+    for proc, cmd, obj in jobs:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
         objs.append(obj)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:

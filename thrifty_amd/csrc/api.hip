@@ -280,7 +280,8 @@ int run_batch_fast(thr_handle* h, const void* d_samples, int format,
     {
         ProfScope p(h, 0);
         HIP_TRY((h->w16 ? thr::launch_carrier_16k_w16 : thr::launch_carrier_16k)(
-            format, d_samples, n_blocks, h->dev, h->d_tables, h->d_stats, dump_fft, grid, h->stream));
+            format, d_samples, n_blocks, h->dev, h->d_tables, h->d_twn, h->d_stats, dump_fft, grid,
+            h->stream));
     }
     if (carrier_only) return THR_OK;
     {
@@ -496,11 +497,16 @@ int thr_create(const thr_settings* s, thr_handle** out) {
         if (hipMalloc(&d.timeline, 128 * sizeof(unsigned long long)) == hipSuccess)
             hipMemset(d.timeline, 0, 128 * sizeof(unsigned long long));
 #endif
-        d.prio_mode = getenv("THR_PRIO") ? atoi(getenv("THR_PRIO")) : 1;
+        d.prio_mode = getenv("THR_PRIO") ? atoi(getenv("THR_PRIO")) : 0;
         d.ablate = getenv("THR_ABLATE") ? atoi(getenv("THR_ABLATE")) : 0;
         d.car_want_std = s->carrier_thresh[2] != 0.0;
-        d.car_prune = !d.car_want_std && d.win_lo >= 3 && d.win_lo + d.win_count + 3 <= 128 &&
-                      getenv("THR_NO_PRUNE") == nullptr;
+        d.car_prune = 0;
+        if (!d.car_want_std && getenv("THR_NO_PRUNE") == nullptr) {
+            if (d.win_lo >= 3 && d.win_lo + d.win_count + 3 <= 128)
+                d.car_prune = 1;  // window and fit margin already inside bins [0,128)
+            else if (d.win_count + 6 <= 128)
+                d.car_prune = 2;  // any narrow window: pre-shift by win_lo - 3
+        }
         d.cor_want_std = s->corr_thresh[2] != 0.0;
 
         h->cfg.templates = s->templates;

@@ -40,8 +40,8 @@ __global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples
 
     load_tables(lds, tables);
     __syncthreads();
-    // waves w and w+4 share a SIMD and the older one wins VALU arbitration: without this the
-    // younger half runs every phase ~35 % slower and the older half idles at the barriers
+    // dev knob (THR_PRIO): waves w and w+4 share a SIMD and the older one finishes every phase
+    // ~35 % earlier; raising either half's priority was measured to change nothing here
     if (cfg.prio_mode == 1 && threadIdx.x >= NT / 2) __builtin_amdgcn_s_setprio(1);
     if (cfg.prio_mode == 2 && threadIdx.x < NT / 2) __builtin_amdgcn_s_setprio(1);
     const size_t blk_bytes = size_t(N) * (FMT == THR_IN_U8 ? 2 : 8);
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples
 }
 
 // =========================================================================
-// K_A, pruned: carrier window (plus the 3-bin fit margin) inside bins [0, 128)
+// K_A, pruned: carrier window (plus the 3-bin fit margin) of at most 128 bins
 // =========================================================================
 // The carrier stage only ever looks at the bins of the window, +-3 neighbours for the
 // fit, and at sum |X|^2.  With the window inside [0,128) the needed bins are
@@ -156,20 +156,38 @@ __global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples
 constexpr int PRUNE_K2 = 8;
 constexpr int PRUNE_BINS = R1 * PRUNE_K2;  // 128
 
-template <int FMT>
+// SHIFTED: the window does not start near bin 0 -- multiply the samples by
+// exp(-2 pi i base n / N), base = win_lo - 3 (exact: an integer shift through the root
+// table), which moves spectrum bin `base + k'` to k'; the window then occupies
+// k' = 3 .. 3 + count - 1 and the same pruned transform applies to ANY window of at most
+// 122 bins (negative bins, wrap-around windows included).
+template <int FMT, bool SHIFTED>
 __global__ __launch_bounds__(NT) void k_carrier_pruned(const void* __restrict__ samples,
                                                        int n_blocks, DevCfg cfg,
                                                        const cpx* __restrict__ tables,
+                                                       const cpx* __restrict__ twn,
                                                        CarStats* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cpx* lds = reinterpret_cast<cpx*>(smem_raw);
     unsigned char* sc_red = reinterpret_cast<unsigned char*>(lds + OFF_S);
-    float* sc_bins = reinterpret_cast<float*>(sc_red + 2 * red_slot_bytes<NT / 64>());  // [128] |X[k]|^2
+    float* sc_bins = reinterpret_cast<float*>(sc_red + 2 * red_slot_bytes<NT / 64>());  // [128] |X[k']|^2
+    float2* sc_rp = reinterpret_cast<float2*>(sc_bins + PRUNE_BINS);                     // [16]
 
     load_tables(lds, tables);
+    // block-invariant shift factors: per sub-sequence n1 (LDS) and per thread (registers)
+    const int base = SHIFTED ? ((cfg.win_lo - 3) & (N - 1)) : 0;
+    const int win_off = SHIFTED ? 3 : cfg.win_lo;  // window start in the pruned bin domain
+    cpx ph[2] = {cpx{1.f, 0.f}, cpx{1.f, 0.f}};
+    if constexpr (SHIFTED) {
+        if (threadIdx.x < 16) {
+            const cpx r = twn[(threadIdx.x * 1024 * base) & (N - 1)];
+            sc_rp[threadIdx.x] = float2{r.x, r.y};
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) ph[e] = twn[((2 * int(threadIdx.x) + e) * base) & (N - 1)];
+    }
     __syncthreads();
-    // waves w and w+4 share a SIMD and the older one wins VALU arbitration: without this the
-    // younger half runs every phase ~35 % slower and the older half idles at the barriers
+    // dev knob (THR_PRIO): see k_carrier
     if (cfg.prio_mode == 1 && threadIdx.x >= NT / 2) __builtin_amdgcn_s_setprio(1);
     if (cfg.prio_mode == 2 && threadIdx.x < NT / 2) __builtin_amdgcn_s_setprio(1);
     const size_t blk_bytes = size_t(N) * (FMT == THR_IN_U8 ? 2 : 8);
@@ -185,7 +203,13 @@ __global__ __launch_bounds__(NT) void k_carrier_pruned(const void* __restrict__ 
             nxt.load(static_cast<const unsigned char*>(samples) + size_t(b + gridDim.x) * blk_bytes,
                      opaque_tid());
         float sums[1];
-        fwd_pass1<false>(lds, cur, nullptr, cpx{}, cpx{}, &sums[0]);
+        if constexpr (SHIFTED) {
+            cpx p0 = ph[0], p1 = ph[1];
+            asm volatile("" : "+v"(p0), "+v"(p1));  // keep the loop body free of hoisted products
+            fwd_pass1<true>(lds, cur, sc_rp, p0, p1, &sums[0]);
+        } else {
+            fwd_pass1<false>(lds, cur, nullptr, cpx{}, cpx{}, &sums[0]);
+        }
         cur = nxt;
         __syncthreads();
         fwd_pass2<PRUNE_K2>(lds);
@@ -193,7 +217,7 @@ __global__ __launch_bounds__(NT) void k_carrier_pruned(const void* __restrict__ 
         // pass 3, output k3 = 0 only: the plain sum of the chunk; threads with k2 < 8
         const int t = opaque_tid();
         const int k2 = t & 31;
-        const int k = (t >> 5) + 16 * k2;  // bin index (valid when k2 < PRUNE_K2)
+        const int k = (t >> 5) + 16 * k2;  // pruned-domain bin (valid when k2 < PRUNE_K2)
         unsigned long long best = 0;
         if (k2 < PRUNE_K2) {
             const f4* src = reinterpret_cast<const f4*>(lds + (t >> 5) * ROW + k2 * CHUNK);
@@ -203,17 +227,18 @@ __global__ __launch_bounds__(NT) void k_carrier_pruned(const void* __restrict__ 
             const cpx x = cpx{acc.x + acc.z, acc.y + acc.w};
             const float p = cnorm(x);
             sc_bins[k] = p;
-            const unsigned wi = unsigned(k - cfg.win_lo) & unsigned(N - 1);
+            const unsigned wi = unsigned(k - win_off) & unsigned(N - 1);
             if (wi < unsigned(cfg.win_count))
                 best = ((unsigned long long)__float_as_uint(p) << 32) | (0xFFFFFFFFu - wi);
         }
         double tot[1];
         block_reduce<1, NT / 64>(sums, tot, best, sc_red, parity);
         parity ^= 1;
-        const unsigned wi = 0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu);
-        const int peak_idx = int(wi) + cfg.win_lo;  // < 128: the '> N' wrap cannot trigger
+        const int wi = int(0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu));
+        int peak_idx = wi + cfg.win_lo;
+        if (peak_idx > N) peak_idx -= N;  // sic: '>' (carrier_detect.py:151)
         CarStats* st = stats + b;
-        if (t < 7) st->nb[t] = sqrtf(sc_bins[peak_idx - 3 + t]);
+        if (t < 7) st->nb[t] = sqrtf(sc_bins[wi + win_off - 3 + t]);
         if (t == 0) {
             st->sum_mag2 = (float)(tot[0] * double(N));  // Parseval
             st->sum_mag = 0.f;
@@ -460,8 +485,8 @@ __global__ __launch_bounds__(NT) void k_correlate(
 
     load_tables(lds, tables);
     __syncthreads();
-    // waves w and w+4 share a SIMD and the older one wins VALU arbitration: without this the
-    // younger half runs every phase ~35 % slower and the older half idles at the barriers
+    // dev knob (THR_PRIO): waves w and w+4 share a SIMD and the older one finishes every phase
+    // ~35 % earlier; raising either half's priority was measured to change nothing here
     if (cfg.prio_mode == 1 && threadIdx.x >= NT / 2) __builtin_amdgcn_s_setprio(1);
     if (cfg.prio_mode == 2 && threadIdx.x < NT / 2) __builtin_amdgcn_s_setprio(1);
     const size_t blk_bytes = size_t(N) * (FMT == THR_IN_U8 ? 2 : 8);
@@ -793,8 +818,10 @@ correlate_fn correlate_variant(int fmt, bool want_std, bool multi, bool dump) {
 
 hipError_t prepare_16k() {
     // > 64 KiB of dynamic LDS must be opted into, per device and per kernel variant
-    for (const void* f : {reinterpret_cast<const void*>(&k_carrier_pruned<THR_IN_U8>),
-                          reinterpret_cast<const void*>(&k_carrier_pruned<THR_IN_C64>)}) {
+    for (const void* f : {reinterpret_cast<const void*>(&k_carrier_pruned<THR_IN_U8, false>),
+                          reinterpret_cast<const void*>(&k_carrier_pruned<THR_IN_U8, true>),
+                          reinterpret_cast<const void*>(&k_carrier_pruned<THR_IN_C64, false>),
+                          reinterpret_cast<const void*>(&k_carrier_pruned<THR_IN_C64, true>)}) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return e;
     }
@@ -816,15 +843,16 @@ hipError_t prepare_16k() {
 }
 
 hipError_t launch_carrier_16k(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,
-                              const float2* tables, CarStats* stats, float2* dump_fft, int grid,
-                              hipStream_t stream) {
+                              const float2* tables, const float2* twn, CarStats* stats,
+                              float2* dump_fft, int grid, hipStream_t stream) {
     if (cfg.car_prune && dump_fft == nullptr) {
-        if (fmt == THR_IN_U8)
-            hipLaunchKernelGGL(k_carrier_pruned<THR_IN_U8>, dim3(grid), dim3(NT), LDS_BYTES, stream,
-                               samples, n_blocks, cfg, reinterpret_cast<const cpx*>(tables), stats);
-        else
-            hipLaunchKernelGGL(k_carrier_pruned<THR_IN_C64>, dim3(grid), dim3(NT), LDS_BYTES, stream,
-                               samples, n_blocks, cfg, reinterpret_cast<const cpx*>(tables), stats);
+        typedef void (*pruned_fn)(const void*, int, DevCfg, const cpx*, const cpx*, CarStats*);
+        const bool shifted = cfg.car_prune == 2;
+        pruned_fn fn = fmt == THR_IN_U8
+                           ? (shifted ? &k_carrier_pruned<THR_IN_U8, true> : &k_carrier_pruned<THR_IN_U8, false>)
+                           : (shifted ? &k_carrier_pruned<THR_IN_C64, true> : &k_carrier_pruned<THR_IN_C64, false>);
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(NT), LDS_BYTES, stream, samples, n_blocks, cfg,
+                           reinterpret_cast<const cpx*>(tables), reinterpret_cast<const cpx*>(twn), stats);
         return hipGetLastError();
     }
     carrier_fn fn = carrier_variant(fmt, cfg.car_want_std != 0, dump_fft != nullptr);

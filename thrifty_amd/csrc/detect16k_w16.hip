@@ -657,9 +657,9 @@ hipError_t prepare_16k_w16() {
 }
 
 hipError_t launch_carrier_16k_w16(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,
-                                  const float2* tables, CarStats* stats, float2* dump_fft, int grid,
-                                  hipStream_t stream) {
-    if (cfg.car_prune && dump_fft == nullptr) {
+                                  const float2* tables, const float2* /*twn*/, CarStats* stats,
+                                  float2* dump_fft, int grid, hipStream_t stream) {
+    if (cfg.car_prune == 1 && dump_fft == nullptr) {
         if (fmt == THR_IN_U8)
             hipLaunchKernelGGL(k_carrier_pruned_w16<THR_IN_U8>, dim3(grid), dim3(NT), LDS_BYTES, stream,
                                samples, n_blocks, cfg, reinterpret_cast<const cpx*>(tables), stats);

@@ -24,9 +24,10 @@ struct DevCfg {
     float car_thr[3];
     float cor_thr[3];
     float tmpl_energy[kMaxTemplates];  // sum t^2 (soa_estimator.py:65)
-    int car_prune;     // carrier window + fit margin inside bins [0,128): pruned FFT#1 (16384 path)
+    int car_prune;     // pruned FFT#1 (16384 path): 0 off, 1 window+margin inside bins [0,128),
+                       // 2 any window of <= 122 bins (samples pre-shifted by win_lo - 3)
     unsigned long long* timeline;  // dev only (-DTHR_TIMELINE): [8 waves][16] s_memtime stamps
-    int prio_mode;     // 0: none, 1: s_setprio(1) for waves 4-7, 2: for waves 0-3 (THR_PRIO, default 1)
+    int prio_mode;     // dev knob THR_PRIO: 0 none (default), 1: s_setprio(1) for waves 4-7, 2: waves 0-3
     int ablate;        // dev only (THR_ABLATE): stop each block after phase n; 0 = off
 };
 
@@ -63,8 +64,8 @@ struct ShiftParams {
 hipError_t prepare_16k();
 size_t lds_bytes_16k();
 hipError_t launch_carrier_16k(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,
-                              const float2* tables, CarStats* stats, float2* dump_fft, int grid,
-                              hipStream_t stream);
+                              const float2* tables, const float2* twn, CarStats* stats,
+                              float2* dump_fft, int grid, hipStream_t stream);
 hipError_t launch_fit(int n_blocks, const DevCfg& cfg, const CarStats* stats,
                       const long long* block_idx, ShiftParams* shifts, int* work_list,
                       int* work_count, thr_record* records, hipStream_t stream);
@@ -85,8 +86,8 @@ hipError_t prepare_16k_w16();
 size_t lds_bytes_16k_w16();
 int table_cpx_16k_w16();
 hipError_t launch_carrier_16k_w16(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,
-                                  const float2* tables, CarStats* stats, float2* dump_fft, int grid,
-                                  hipStream_t stream);
+                                  const float2* tables, const float2* twn, CarStats* stats,
+                                  float2* dump_fft, int grid, hipStream_t stream);
 hipError_t launch_correlate_16k_w16(int fmt, const void* samples, const DevCfg& cfg,
                                     const float2* tables, const float2* twn, const float4* tspec,
                                     const ShiftParams* shifts, const int* work_list,
