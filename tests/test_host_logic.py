@@ -254,3 +254,18 @@ def test_card_stream_rejects_malformed_lines():
     with pytest.raises(ValueError):
         block_data.CardStream(io.BytesIO(b"garbage-without-fields\n"), 4096).next_batch(1)
     assert block_data.CardStream(io.BytesIO(b"# only comments\n\n"), 4096).next_batch(1) is None
+
+
+# ---------------------------------------------------------------- the product never touches the oracle
+def test_product_package_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "thrifty_amd")
+    offenders = []
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f), encoding="utf-8", errors="replace").read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", text, re.M) or "oracle/" in text:
+                    offenders.append(os.path.join(dirpath, f))
+    assert offenders == []
+    header = open(os.path.join(ROOT, "oracle", "thrifty_np.py")).read()
+    assert "TEST INFRASTRUCTURE ONLY" in header and "PINNED" in header
