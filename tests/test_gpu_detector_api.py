@@ -116,3 +116,46 @@ def test_multi_template_detector(golden):
         for ln in lines:
             assert ln.split()[1] == str(t)                          # txid column
         assert_toad_close([" ".join(ln.split()[:1] + ln.split()[2:]) for ln in lines], g["toad"])
+
+
+def test_raw_stream_mode_matches_oracle(golden, tmp_path):
+    """`thrifty detect --raw`: overlapping blocks cut from a raw u8 stream (block_reader,
+    reference block_data.py:70-98), first history = 0.0, through the CLI."""
+    from oracle import thrifty_np as onp
+    from thrifty_amd import synth
+    g = golden("c2")
+    n, h = 16384, 4096
+    new = n - h
+    tpl = g["template"]
+    rng = np.random.default_rng(31)
+    # a continuous stream: noise with three bursts at known stream positions
+    nblk = 6
+    stream = (rng.normal(0, 0.02, new * nblk) + 1j * rng.normal(0, 0.02, new * nblk))
+    ook = 0.3 * (np.asarray(tpl, float) + 1) / 2
+    for start, car in ((9000, 33.3), (30000, 71.8), (52000, 55.1)):
+        k = np.arange(len(tpl))
+        stream[start:start + len(tpl)] += ook * np.exp(2j * np.pi * car * (k + start) / n)
+    raw = synth.quantise_iq(stream)
+    np.save(tmp_path / "template.npy", tpl)
+    (tmp_path / "detector.cfg").write_text(
+        "rxid: 9\nsample_rate: 2.4M\nblock_size: %d\nblock_history: %d\ncarrier_window: 7 - 110\n"
+        "carrier_threshold: 15 * snr\ncorr_threshold: 15*snr\ntemplate: %s\n" % (n, h, tmp_path / "template.npy"))
+    (tmp_path / "rx.raw").write_bytes(raw.tobytes())
+    detector_cli(Detector, argv=[str(tmp_path / "rx.raw"), "--raw", "--quiet", "-o", str(tmp_path / "rx.toad"),
+                                 "-c", str(tmp_path / "detector.cfg")])
+    got = [ln.split() for ln in (tmp_path / "rx.toad").read_text().strip().split("\n")]
+    # oracle over the same framing
+    orc = onp.OracleDetector(n, h, tpl, (0, 15, 0), (7, 110), (0, 15, 0))
+    want = []
+    for ts, idx, blk in block_data.block_reader(io.BytesIO(raw.tobytes()), n, h):
+        (res,) = orc.detect_block(idx, np.asarray(blk))
+        if res.detected:
+            want.append((idx, res))
+    assert len(got) == len(want) == 3
+    for a, (idx, res) in zip(got, want):
+        assert int(a[0]) == 9 and int(a[2]) == idx and int(a[4]) == res.corr.sample
+        np.testing.assert_allclose(float(a[3]), res.soa, atol=2e-4)
+        np.testing.assert_allclose(float(a[6]), res.corr.energy, rtol=1e-4)
+    # each burst is reported exactly once although blocks overlap by `history` samples
+    soas = sorted(float(a[3]) for a in got)
+    np.testing.assert_allclose(soas, [9000 + h, 30000 + h, 52000 + h], atol=1.0)

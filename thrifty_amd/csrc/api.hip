@@ -497,6 +497,7 @@ int thr_create(const thr_settings* s, thr_handle** out) {
         if (hipMalloc(&d.timeline, 128 * sizeof(unsigned long long)) == hipSuccess)
             hipMemset(d.timeline, 0, 128 * sizeof(unsigned long long));
 #endif
+        d.stagger = getenv("THR_STAGGER") ? atoi(getenv("THR_STAGGER")) : 1;
         d.prio_mode = getenv("THR_PRIO") ? atoi(getenv("THR_PRIO")) : 0;
         d.ablate = getenv("THR_ABLATE") ? atoi(getenv("THR_ABLATE")) : 0;
         d.car_want_std = s->carrier_thresh[2] != 0.0;

@@ -525,10 +525,22 @@ __global__ __launch_bounds__(NT) void k_correlate(
         fwd_pass1<true>(lds, cur, sp->rpow, p[0], p[1]);
         cur = nxt;
         THR_STAMP(2);
-        // the next block's phasor (root-table gather + sincosf) overlaps this block's passes
-        if (more) shift_phasor(shifts + b_next, twn, t, p);
+        // The next block's phasor (root-table gather + sincosf, ~1 k cycles).  The older half of
+        // the waves reaches the barrier first and would idle there: it computes the phasor
+        // before the barrier; the younger half does it after -- which also staggers the two
+        // halves by about one LDS phase through the barrier-free passes that follow.
+        const bool early_half = cfg.stagger == 0 || threadIdx.x < NT / 2;
+        if (more && early_half) shift_phasor(shifts + b_next, twn, t, p);
         THR_STAMP(3);
         __syncthreads();
+        if (more && !early_half) shift_phasor(shifts + b_next, twn, t, p);
+#ifdef THR_DEV_ABLATE
+        if (cfg.stagger >= 2 && threadIdx.x >= NT / 2) {
+            if (cfg.stagger == 2) __builtin_amdgcn_s_sleep(16);
+            if (cfg.stagger == 3) __builtin_amdgcn_s_sleep(32);
+            if (cfg.stagger == 4) __builtin_amdgcn_s_sleep(64);
+        }
+#endif
         THR_STAMP(4);
         THR_ABLATE_AT(11, continue);
         // rows k1 = 2w, 2w+1 belong to wave w through passes 2, 3, A and B: no barriers
