@@ -3,7 +3,7 @@
 // Correctness-first companion of detect16k.hip for block lengths that do not have an
 // LDS-resident kernel yet (BASELINE config C3: N = 65536, and the small blocks the
 // reference's unit tests use).  Every stage is its own launch and round-trips complex64
-// through HBM/L2 (Stockham radix-2 autosort passes), i.e. this path IS the "unfused
+// through HBM/L2 (Stockham radix-4 autosort passes), i.e. this path IS the "unfused
 // pipeline" of SURVEY.md 8(d) and is HBM-bound by construction.  Same record semantics,
 // same k_fit / k_finish kernels, same twiddle sources (exactly rounded root table) as the
 // fast path.  Reference lines as in detect16k.hip.
@@ -76,6 +76,43 @@ __global__ __launch_bounds__(256) void g_fft_pass(const cpx2* __restrict__ in,
     const int j0 = ((j >> log2ns) << (log2ns + 1)) + k;
     dst[j0] = a + bb;
     dst[j0 + ns] = a - bb;
+}
+
+// ---- one Stockham radix-4 pass (two radix-2 levels at once: half the HBM round trips)
+template <bool INVERSE>
+__global__ __launch_bounds__(256) void g_fft_pass4(const cpx2* __restrict__ in,
+                                                   cpx2* __restrict__ out, int n, int log2n,
+                                                   int log2ns, int n_blocks,
+                                                   const cpx2* __restrict__ twn,
+                                                   const thr_record* __restrict__ records,
+                                                   int n_tpl) {
+    const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int quarter = n >> 2;
+    const int b = int(gid >> (log2n - 2)), j = int(gid & size_t(quarter - 1));
+    if (b >= n_blocks) return;
+    if (records != nullptr && !(records[size_t(b) * n_tpl].flags & THR_FLAG_CARRIER)) return;
+    const int ns = 1 << log2ns;
+    const int k = j & (ns - 1);
+    // w = exp(-2 pi i k / (4 ns)) and its square / cube, each read exactly rounded from the table
+    const size_t step = size_t(1) << (log2n - log2ns - 2);
+    cpx2 w1 = twn[size_t(k) * step], w2 = twn[size_t(2 * k) * step], w3 = twn[size_t(3 * k) * step];
+    if (INVERSE) {
+        w1.y = -w1.y;
+        w2.y = -w2.y;
+        w3.y = -w3.y;
+    }
+    const cpx2* src = in + size_t(b) * n;
+    const cpx2 u0 = src[j], u1 = gmul(w1, src[j + quarter]), u2 = gmul(w2, src[j + 2 * quarter]),
+               u3 = gmul(w3, src[j + 3 * quarter]);
+    const cpx2 t0 = u0 + u2, t1 = u0 - u2, t2 = u1 + u3, t3 = u1 - u3;
+    // forward: -i * t3 = (t3.y, -t3.x); inverse: +i * t3
+    const cpx2 r = INVERSE ? cpx2{-t3.y, t3.x} : cpx2{t3.y, -t3.x};
+    cpx2* dst = out + size_t(b) * n;
+    const int j0 = ((j >> log2ns) << (log2ns + 2)) + k;
+    dst[j0] = t0 + t2;
+    dst[j0 + ns] = t1 + r;
+    dst[j0 + 2 * ns] = t0 - t2;
+    dst[j0 + 3 * ns] = t1 - r;
 }
 
 // ---- block-wide helpers (256 threads)
@@ -207,20 +244,36 @@ inline int ilog2(int n) {
     return l;
 }
 
-// log2 N Stockham passes, ping-ponging a <-> b; returns the buffer holding the result
+// Stockham passes (radix 4, plus one radix-2 pass when log2 N is odd), ping-ponging a <-> b;
+// returns the buffer holding the natural-order result
 cpx2* run_fft(cpx2* a, cpx2* b, int n, int n_blocks, bool inverse, const cpx2* twn,
               const thr_record* records, int n_tpl, hipStream_t stream, hipError_t* err) {
     const int log2n = ilog2(n);
-    const size_t work = size_t(n_blocks) * (n / 2);
-    const dim3 grid((unsigned)((work + 255) / 256)), blk(256);
+    const dim3 blk(256);
     cpx2 *src = a, *dst = b;
-    for (int s = 0; s < log2n; ++s) {
-        if (inverse)
-            hipLaunchKernelGGL(g_fft_pass<true>, grid, blk, 0, stream, src, dst, n, log2n, s, n_blocks,
-                               twn, records, n_tpl);
-        else
-            hipLaunchKernelGGL(g_fft_pass<false>, grid, blk, 0, stream, src, dst, n, log2n, s, n_blocks,
-                               twn, records, n_tpl);
+    int s = 0;
+    while (s < log2n) {
+        if (log2n - s >= 2) {
+            const size_t work = size_t(n_blocks) * (n / 4);
+            const dim3 grid((unsigned)((work + 255) / 256));
+            if (inverse)
+                hipLaunchKernelGGL(g_fft_pass4<true>, grid, blk, 0, stream, src, dst, n, log2n, s,
+                                   n_blocks, twn, records, n_tpl);
+            else
+                hipLaunchKernelGGL(g_fft_pass4<false>, grid, blk, 0, stream, src, dst, n, log2n, s,
+                                   n_blocks, twn, records, n_tpl);
+            s += 2;
+        } else {
+            const size_t work = size_t(n_blocks) * (n / 2);
+            const dim3 grid((unsigned)((work + 255) / 256));
+            if (inverse)
+                hipLaunchKernelGGL(g_fft_pass<true>, grid, blk, 0, stream, src, dst, n, log2n, s,
+                                   n_blocks, twn, records, n_tpl);
+            else
+                hipLaunchKernelGGL(g_fft_pass<false>, grid, blk, 0, stream, src, dst, n, log2n, s,
+                                   n_blocks, twn, records, n_tpl);
+            s += 1;
+        }
         cpx2* t = src;
         src = dst;
         dst = t;
