@@ -126,6 +126,33 @@ int thr_detect_card(thr_handle* h, const char* text, size_t text_len, const int6
                     const int64_t* block_idx, size_t n_blocks, thr_record* out);
 
 /*
+ * Raw-stream framing on the device.  Replaces the overlap bookkeeping of
+ * `block_reader` (thrifty/block_data.py:70-98: block = previous block's last
+ * `history_len` samples + `block_len - history_len` new ones) and of fastcard's
+ * raw_reader_next (fastcard/lib/raw_reader.c:15-46): `stream` is the receiver's
+ * interleaved u8 I/Q byte stream and block i is the 2*block_len bytes starting
+ * 2*(block_len - history_len)*i bytes into it -- the kernels read overlapping
+ * windows in place, nothing is copied or re-framed.  Needs an even
+ * block_len - history_len (4-byte aligned block starts), else THR_ERR_ARG.
+ * The reference's very first block has an all-zero (0.0, not quantiser-zero)
+ * history and therefore no u8 form: callers send that one block through
+ * thr_detect(..., THR_IN_C64, ...) (thrifty_amd/block_data.py:RawStream does).
+ *
+ * thr_detect_stream: host pointer, synchronous; processes the
+ *   (n_bytes - 2*block_len) / (2*(block_len - history_len)) + 1 whole blocks the
+ *   stream holds (0 if shorter than one block), numbers them first_block_idx,
+ *   first_block_idx+1, ..., writes [n_blocks][n_templates] records and stores
+ *   the block count in *n_blocks_out.  `out_capacity` is in blocks.
+ * thr_detect_stream_device: device pointers, asynchronous like
+ *   thr_detect_device; n_blocks <= max_batch; d_stream must hold
+ *   (n_blocks-1)*2*(block_len-history_len) + 2*block_len bytes.
+ */
+int thr_detect_stream(thr_handle* h, const uint8_t* stream, size_t n_bytes, int64_t first_block_idx,
+                      thr_record* out, size_t out_capacity, size_t* n_blocks_out);
+int thr_detect_stream_device(thr_handle* h, const uint8_t* d_stream, const int64_t* d_block_idx,
+                             size_t n_blocks, thr_record* d_out);
+
+/*
  * Device-resident form (what bench.py times): `d_samples`, `d_block_idx`
  * (may be NULL) and `d_out` are device pointers on the handle's device.  The
  * work is enqueued on the handle's stream and NOT synchronised; call

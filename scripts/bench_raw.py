@@ -1,0 +1,29 @@
+"""Dev/aux: end-to-end `raw u8 stream -> records` rate: host framing (block_reader) vs
+device framing (RawStream -> thr_detect_stream)."""
+import io, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from thrifty_amd import block_data, synth
+from thrifty_amd.detect import Detector, DetectorSettings
+
+n, h = 16384, 4096
+new = n - h
+tpl = synth.gold_template(10, 2)
+rng = np.random.default_rng(0)
+nb = 8192
+x = (rng.normal(0, 0.02, new * 64) + 1j * rng.normal(0, 0.02, new * 64))
+ook = 0.3 * (np.asarray(tpl, float) + 1) / 2
+for j in range(64):
+    s = j * new + 3000 + 97 * j
+    k = np.arange(len(tpl))
+    x[s:s + len(tpl)] += ook * np.exp(2j * np.pi * (20 + j) * (k + s) / n)
+raw = np.tile(synth.quantise_iq(x), nb // 64).tobytes()
+st = DetectorSettings(n, h, len(tpl), (0, 15, 0), (7, 110), tpl, (0, 15, 0))
+for name, mk in (("host framing (block_reader)", lambda: block_data.block_reader(io.BytesIO(raw), n, h)),
+                 ("device framing (RawStream)", lambda: block_data.RawStream(io.BytesIO(raw), n, h))):
+    det = Detector(st, mk(), batch_size=1024)
+    t0 = time.perf_counter()
+    cnt = sum(1 for d, r in det if d)
+    dt = time.perf_counter() - t0
+    print("%-30s %8.0f blocks/s (%d detections, %.1f MB stream, %.1f MS/s)" % (
+        name, nb / dt, cnt, len(raw) / 1e6, nb * new / dt / 1e6))

@@ -269,3 +269,41 @@ def test_product_package_does_not_import_the_oracle():
     assert offenders == []
     header = open(os.path.join(ROOT, "oracle", "thrifty_np.py")).read()
     assert "TEST INFRASTRUCTURE ONLY" in header and "PINNED" in header
+
+
+@pytest.mark.parametrize("n,h", [(64, 16), (64, 40), (64, 48), (64, 0), (64, 62)])
+def test_rawstream_batches_frame_like_block_reader(n, h):
+    """RawStream's (lead-in c64 blocks, then contiguous u8 stream with 2H carry) describes
+    exactly block_reader's blocks (reference block_data.py:70-98)."""
+    import io
+    rng = np.random.default_rng(n * 100 + h)
+    step = 2 * (n - h)
+    data = rng.integers(0, 256, size=step * 23 + 3, dtype=np.uint8).tobytes()
+    ref = list(block_data.block_reader(io.BytesIO(data), n, h))
+    rs = block_data.RawStream(io.BytesIO(data), n, h)
+    got, kinds = [], []
+    while True:
+        batch = rs.next_batch(5)
+        if batch is None:
+            break
+        kind, stamps, idx, payload = batch
+        kinds.append(kind)
+        assert len(stamps) == len(idx)
+        if kind == "c64":
+            got += [(int(i), np.array(b)) for i, b in zip(idx, payload)]
+        else:
+            a = np.frombuffer(payload, dtype=np.uint8)
+            assert a.size == 2 * h + len(idx) * step
+            got += [(int(i), block_data.raw_to_complex(a[j * step: j * step + 2 * n]))
+                    for j, i in enumerate(idx)]
+            del a
+    assert len(got) == len(ref)
+    assert kinds == sorted(kinds)                      # all lead-in batches come first
+    n_lead = min(-(-h // (n - h)), len(ref))           # blocks that still see the zero history
+    assert kinds.count("c64") == -(-n_lead // 5)
+    for (i, blk), (_, ri, rb) in zip(got, ref):
+        assert i == ri
+        assert np.array_equal(blk.astype(np.complex128), np.asarray(rb).astype(np.complex128))
+    # plain iteration is block_reader
+    again = list(block_data.RawStream(io.BytesIO(data), n, h))
+    assert len(again) == len(ref) and all(np.array_equal(a[2], b[2]) for a, b in zip(again, ref))

@@ -22,7 +22,7 @@ N_KERNEL_SLOTS = 4
 
 EXPORTS = [
     "thr_abi_version", "thr_last_error", "thr_create", "thr_destroy", "thr_detect",
-    "thr_detect_card", "thr_detect_device", "thr_sync", "thr_set_stream", "thr_compact_device",
+    "thr_detect_card", "thr_detect_stream", "thr_detect_stream_device", "thr_detect_device", "thr_sync", "thr_set_stream", "thr_compact_device",
     "thr_profile_enable", "thr_profile_read", "thr_kernel_name", "thr_debug_fft",
     "thr_debug_stage",
 ]
@@ -106,6 +106,9 @@ def load_library():
     lib.thr_detect.argtypes = [vp, vp, C.c_int, vp, C.c_size_t, vp]
     lib.thr_detect_card.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_size_t, vp]
     lib.thr_detect_device.argtypes = [vp, vp, C.c_int, vp, C.c_size_t, vp]
+    lib.thr_detect_stream.argtypes = [vp, vp, C.c_size_t, C.c_int64, vp, C.c_size_t,
+                                      C.POINTER(C.c_size_t)]
+    lib.thr_detect_stream_device.argtypes = [vp, vp, vp, C.c_size_t, vp]
     lib.thr_sync.argtypes = [vp]
     lib.thr_set_stream.argtypes = [vp, vp]
     lib.thr_compact_device.argtypes = [vp, vp, C.c_size_t, vp, C.POINTER(C.c_size_t)]
@@ -146,6 +149,7 @@ class Engine(object):
         _check(lib, lib.thr_create(C.byref(st), C.byref(handle)))
         self._lib, self._h = lib, handle
         self.block_len, self.n_templates = int(block_len), int(tpl.shape[0])
+        self.history_len = int(history_len)
         self.max_batch = int(max_batch)
 
     def close(self):
@@ -198,7 +202,26 @@ class Engine(object):
                                                     off.ctypes.data, idx_p, nb, out.ctypes.data))
         return out
 
+    def detect_stream(self, stream, first_block_idx=0):
+        """stream: bytes-like raw interleaved u8 I/Q; the overlapping blocks
+        (block_reader framing, stride block_len - history_len samples) are framed on the
+        device.  -> records [n_whole_blocks, n_templates]."""
+        buf = np.frombuffer(stream, dtype=np.uint8)
+        stride = 2 * (self.block_len - self.history_len)
+        nb = 0 if buf.size < 2 * self.block_len else (buf.size - 2 * self.block_len) // stride + 1
+        out = np.zeros((nb, self.n_templates), dtype=RECORD_DTYPE)
+        got = C.c_size_t(0)
+        _check(self._lib, self._lib.thr_detect_stream(self._h, buf.ctypes.data, buf.size,
+                                                      int(first_block_idx), out.ctypes.data, nb,
+                                                      C.byref(got)))
+        assert got.value == nb
+        return out
+
     # ---- device-resident path (pointers are plain integers) ---------------
+    def detect_stream_device(self, d_stream, n_blocks, d_out, d_block_idx=None):
+        _check(self._lib, self._lib.thr_detect_stream_device(self._h, d_stream, d_block_idx,
+                                                             n_blocks, d_out))
+
     def detect_device(self, d_samples, fmt, n_blocks, d_out, d_block_idx=None):
         _check(self._lib, self._lib.thr_detect_device(self._h, d_samples, fmt, d_block_idx,
                                                       n_blocks, d_out))

@@ -198,6 +198,93 @@ class CardStream(object):
                 yield ts, int(idx), IQBlock(raw_to_complex(raw), raw)
 
 
+class RawStream(object):
+    """Batch-oriented raw u8 I/Q reader with the overlap framing done on the GPU
+    (reference block_data.py:70-98, fastcard raw_reader.c:15-46).
+
+    `block_reader` re-copies every block's history on the host; here the host keeps the
+    byte stream contiguous (the last 2*history bytes are carried over between batches) and
+    the engine reads overlapping windows straight out of it (`Engine.detect_stream`).  The
+    first ceil(history / (size - history)) blocks still contain part of the reference's
+    all-zero initial history, which has no u8 form: those come back as complex64 blocks.
+    Iterating a RawStream yields `block_reader`'s tuples (drop-in use, host framing).
+    """
+
+    def __init__(self, stream, size, history):
+        self.stream = stream
+        self.size, self.history = int(size), int(history)
+        self.new = self.size - self.history
+        if self.new <= 0:
+            raise ValueError("history must be shorter than the block")
+        self.device_framing = self.new % 2 == 0     # 4-byte aligned block starts
+        self._next_idx = 0
+        self._n_lead = -(-self.history // self.new)          # blocks that still see zero history
+        self._lead = np.zeros(self.size, dtype=np.complex64)  # rolling block of the lead-in
+        # _buf = [carry: last 2*history stream bytes][unconsumed new bytes]; _have = valid bytes
+        self._buf = bytearray(2 * self.history)
+        self._have = 2 * self.history
+        self._consumed = 0      # bytes of the previous u8 batch still to be slid out
+        self._eof = False
+
+    def _read_upto(self, want_end):
+        if len(self._buf) < want_end:
+            self._buf.extend(bytes(want_end - len(self._buf)))
+        while self._have < want_end and not self._eof:
+            view = memoryview(self._buf)[self._have:want_end]
+            if hasattr(self.stream, "readinto"):
+                got = self.stream.readinto(view) or 0
+            else:
+                more = self.stream.read(want_end - self._have)
+                got = len(more)
+                view[:got] = more
+            del view
+            if got == 0:
+                self._eof = True
+            self._have += got
+
+    def _slide(self, used):
+        """Drop `used` consumed bytes: the bytes before the new position become the carry."""
+        if used:
+            tail = self._have - used
+            self._buf[:tail] = self._buf[used:self._have]
+            self._have = tail
+
+    def next_batch(self, max_blocks):
+        """-> ("c64", stamps, idxs int64[n], complex64[n, size])  for the lead-in blocks,
+              ("u8", stamps, idxs int64[n], memoryview of the bytes of n overlapping blocks),
+              or None at EOF.  The u8 view aliases this reader's buffer: valid until the next call."""
+        step, carry = 2 * self.new, 2 * self.history
+        self._slide(self._consumed)
+        self._consumed = 0
+        if self._next_idx < self._n_lead:
+            blocks, idxs = [], []
+            while len(blocks) < max_blocks and self._next_idx < self._n_lead:
+                self._read_upto(carry + step)
+                if self._have < carry + step:
+                    break                                   # short tail: dropped, like the reference
+                chunk = np.frombuffer(self._buf, dtype=np.uint8, count=step, offset=carry)
+                self._lead = np.concatenate([self._lead[self.new:], raw_to_complex(chunk)])
+                del chunk
+                blocks.append(self._lead)
+                idxs.append(self._next_idx)
+                self._next_idx += 1
+                self._slide(step)
+            if not blocks:
+                return None
+            return "c64", [time.time()] * len(blocks), np.asarray(idxs, dtype=np.int64), np.stack(blocks)
+        self._read_upto(carry + max_blocks * step)
+        n = (self._have - carry) // step
+        if n <= 0:
+            return None
+        idxs = np.arange(self._next_idx, self._next_idx + n, dtype=np.int64)
+        self._next_idx += n
+        self._consumed = n * step
+        return "u8", [time.time()] * n, idxs, memoryview(self._buf)[:carry + n * step]
+
+    def __iter__(self):
+        return block_reader(self.stream, self.size, self.history)
+
+
 def card_line(timestamp, block_idx, raw):
     """Format one .card line (fastcard_cli.c:187-192: "%ld.%06ld %PRId64 %s\\n")."""
     sec = int(timestamp)

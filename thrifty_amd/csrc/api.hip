@@ -311,7 +311,7 @@ int run_batch_generic(thr_handle* h, const void* d_samples, int format,
                       float2* dump_fft, float2* dump_xhat, float2* dump_corr, int dump_template,
                       bool carrier_only) {
     const size_t n = size_t(h->cfg.block_len), T = size_t(h->cfg.n_templates);
-    const size_t blk_bytes = n * (format == THR_IN_U8 ? 2 : 8);
+    const size_t blk_bytes = size_t(h->dev.blk_stride);
     h->prof = h->prof_every > 0 && (h->batch_no++ % h->prof_every) == 0;
     for (int off = 0; off < n_blocks; off += h->gen_batch) {
         const int nb = std::min(h->gen_batch, n_blocks - off);
@@ -360,7 +360,7 @@ int run_batch_long(thr_handle* h, const void* d_samples, int format,
                    const long long* d_block_idx, int n_blocks, thr_record* d_out, float2* dump_fft,
                    float2* dump_xhat, float2* dump_corr, int dump_template, bool carrier_only) {
     const size_t n = size_t(h->cfg.block_len), T = size_t(h->cfg.n_templates);
-    const size_t blk_bytes = n * (format == THR_IN_U8 ? 2 : 8);
+    const size_t blk_bytes = size_t(h->dev.blk_stride);
     const int r0 = int(n / 16384);
     h->prof = h->prof_every > 0 && (h->batch_no++ % h->prof_every) == 0;
     for (int off = 0; off < n_blocks; off += h->long_batch) {
@@ -400,7 +400,9 @@ int run_batch_long(thr_handle* h, const void* d_samples, int format,
 
 int run_batch(thr_handle* h, const void* d_samples, int format, const long long* d_block_idx,
               int n_blocks, thr_record* d_out, float2* dump_fft, float2* dump_xhat,
-              float2* dump_corr, int dump_template, bool carrier_only) {
+              float2* dump_corr, int dump_template, bool carrier_only, size_t stride = 0) {
+    // stride 0: blocks packed back to back; otherwise raw-stream framing (overlapping blocks)
+    h->dev.blk_stride = stride ? stride : size_t(h->cfg.block_len) * (format == THR_IN_U8 ? 2 : 8);
     return (h->fast ? run_batch_fast : h->lng ? run_batch_long : run_batch_generic)(
         h, d_samples, format, d_block_idx, n_blocks, d_out, dump_fft, dump_xhat, dump_corr,
         dump_template, carrier_only);
@@ -605,6 +607,73 @@ int thr_detect_device(thr_handle* h, const void* d_samples, int format,
     HIP_TRY(hipSetDevice(h->device));
     return run_batch(h, d_samples, format, reinterpret_cast<const long long*>(d_block_idx),
                      int(n_blocks), d_out, nullptr, nullptr, nullptr, 0, false);
+}
+
+// Raw-stream framing on the device (block_data.py:70-98; fastcard raw_reader.c:15-46): block i
+// is the 2N bytes that start 2 (N - H) i bytes into the stream, so consecutive blocks overlap
+// by H samples and the history copy of the host-side readers disappears.
+static int stream_stride(thr_handle* h, size_t* stride) {
+    const size_t s = size_t(h->cfg.block_len - h->cfg.history_len) * 2;
+    if (s % 4 != 0)
+        return fail(THR_ERR_ARG, "raw-stream framing needs an even block_len - history_len (got %d)",
+                    h->cfg.block_len - h->cfg.history_len);
+    *stride = s;
+    return THR_OK;
+}
+
+int thr_detect_stream_device(thr_handle* h, const uint8_t* d_stream, const int64_t* d_block_idx,
+                             size_t n_blocks, thr_record* d_out) {
+    if (!h || !d_stream || !d_out) return fail(THR_ERR_ARG, "thr_detect_stream_device: null argument");
+    if (n_blocks == 0) return THR_OK;
+    if (n_blocks > size_t(h->cfg.max_batch))
+        return fail(THR_ERR_ARG, "n_blocks %zu exceeds max_batch %d", n_blocks, h->cfg.max_batch);
+    if (reinterpret_cast<uintptr_t>(d_stream) % 4 != 0)
+        return fail(THR_ERR_ARG, "stream pointer must be 4-byte aligned");
+    size_t stride = 0;
+    int rc = stream_stride(h, &stride);
+    if (rc != THR_OK) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    return run_batch(h, d_stream, THR_IN_U8, reinterpret_cast<const long long*>(d_block_idx),
+                     int(n_blocks), d_out, nullptr, nullptr, nullptr, 0, false, stride);
+}
+
+int thr_detect_stream(thr_handle* h, const uint8_t* stream, size_t n_bytes, int64_t first_block_idx,
+                      thr_record* out, size_t out_capacity, size_t* n_blocks_out) {
+    if (!h || !stream || !out || !n_blocks_out)
+        return fail(THR_ERR_ARG, "thr_detect_stream: null argument");
+    *n_blocks_out = 0;
+    size_t stride = 0;
+    int rc = stream_stride(h, &stride);
+    if (rc != THR_OK) return rc;
+    const size_t blk = size_t(h->cfg.block_len) * 2;
+    if (n_bytes < blk) return THR_OK;
+    const size_t n_blocks = (n_bytes - blk) / stride + 1;
+    if (n_blocks > out_capacity)
+        return fail(THR_ERR_ARG, "stream holds %zu blocks, records array only %zu", n_blocks,
+                    out_capacity);
+    HIP_TRY(hipSetDevice(h->device));
+    rc = ensure_staging(h, THR_IN_U8);
+    if (rc != THR_OK) return rc;
+    const size_t nt = size_t(h->cfg.n_templates);
+    std::vector<long long> idx;
+    for (size_t done = 0; done < n_blocks;) {
+        const size_t nb = std::min(n_blocks - done, size_t(h->cfg.max_batch));
+        HIP_TRY(hipMemcpyAsync(h->d_in, stream + done * stride, (nb - 1) * stride + blk,
+                               hipMemcpyHostToDevice, h->stream));
+        idx.resize(nb);
+        for (size_t i = 0; i < nb; ++i) idx[i] = (long long)(first_block_idx + int64_t(done + i));
+        HIP_TRY(hipMemcpyAsync(h->d_idx, idx.data(), nb * sizeof(long long), hipMemcpyHostToDevice,
+                               h->stream));
+        rc = run_batch(h, h->d_in, THR_IN_U8, h->d_idx, int(nb), h->d_rec, nullptr, nullptr, nullptr, 0,
+                       false, stride);
+        if (rc != THR_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(out + done * nt, h->d_rec, nb * nt * sizeof(thr_record),
+                               hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));  // also keeps idx alive long enough
+        done += nb;
+    }
+    *n_blocks_out = n_blocks;
+    return THR_OK;
 }
 
 int thr_detect(thr_handle* h, const void* samples, int format, const int64_t* block_idx,

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples
     // ~35 % earlier; raising either half's priority was measured to change nothing here
     if (cfg.prio_mode == 1 && threadIdx.x >= NT / 2) __builtin_amdgcn_s_setprio(1);
     if (cfg.prio_mode == 2 && threadIdx.x < NT / 2) __builtin_amdgcn_s_setprio(1);
-    const size_t blk_bytes = size_t(N) * (FMT == THR_IN_U8 ? 2 : 8);
+    const size_t blk_bytes = cfg.blk_stride;  // dense: N * sample size; raw streams: 2 (N - H)
     int parity = 0;
 
     RawSamples<FMT> cur;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(NT) void k_carrier_pruned(const void* __restrict__ 
     // dev knob (THR_PRIO): see k_carrier
     if (cfg.prio_mode == 1 && threadIdx.x >= NT / 2) __builtin_amdgcn_s_setprio(1);
     if (cfg.prio_mode == 2 && threadIdx.x < NT / 2) __builtin_amdgcn_s_setprio(1);
-    const size_t blk_bytes = size_t(N) * (FMT == THR_IN_U8 ? 2 : 8);
+    const size_t blk_bytes = cfg.blk_stride;  // dense: N * sample size; raw streams: 2 (N - H)
     int parity = 0;
 
     RawSamples<FMT> cur;
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(NT) void k_correlate(
     // ~35 % earlier; raising either half's priority was measured to change nothing here
     if (cfg.prio_mode == 1 && threadIdx.x >= NT / 2) __builtin_amdgcn_s_setprio(1);
     if (cfg.prio_mode == 2 && threadIdx.x < NT / 2) __builtin_amdgcn_s_setprio(1);
-    const size_t blk_bytes = size_t(N) * (FMT == THR_IN_U8 ? 2 : 8);
+    const size_t blk_bytes = cfg.blk_stride;  // dense: N * sample size; raw streams: 2 (N - H)
     const int n_work = *work_count;
     int parity = 0;
 

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(NT) void k_carrier_w16(const void* __restrict__ sam
 
     load_tables(lds, tables);
     __syncthreads();
-    const size_t blk_bytes = size_t(N) * (FMT == THR_IN_U8 ? 2 : 8);
+    const size_t blk_bytes = cfg.blk_stride;  // dense: N * sample size; raw streams: 2 (N - H)
     int parity = 0;
 
     Raw<FMT> cur;
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(NT) void k_carrier_pruned_w16(const void* __restric
 
     load_tables(lds, tables);
     __syncthreads();
-    const size_t blk_bytes = size_t(N) * (FMT == THR_IN_U8 ? 2 : 8);
+    const size_t blk_bytes = cfg.blk_stride;  // dense: N * sample size; raw streams: 2 (N - H)
     int parity = 0;
 
     Raw<FMT> cur;
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(NT) void k_correlate_w16(
 
     load_tables(lds, tables);
     __syncthreads();
-    const size_t blk_bytes = size_t(N) * (FMT == THR_IN_U8 ? 2 : 8);
+    const size_t blk_bytes = cfg.blk_stride;  // dense: N * sample size; raw streams: 2 (N - H)
     const int n_work = *work_count;
     int parity = 0;
 

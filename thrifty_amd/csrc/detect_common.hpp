@@ -24,6 +24,8 @@ struct DevCfg {
     float car_thr[3];
     float cor_thr[3];
     float tmpl_energy[kMaxTemplates];  // sum t^2 (soa_estimator.py:65)
+    unsigned long long blk_stride;  // bytes from one block's first sample to the next one's: N * sample
+                                    // size for packed blocks, 2 (N - H) for raw-stream framing
     int car_prune;     // pruned FFT#1 (16384 path): 0 off, 1 window+margin inside bins [0,128),
                        // 2 any window of <= 122 bins (samples pre-shifted by win_lo - 3)
     unsigned long long* timeline;  // dev only (-DTHR_TIMELINE): [8 waves][16] s_memtime stamps

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(NT) void k_carrier_sub(const void* __restrict__ sam
     load_tables(lds, tables);
     __syncthreads();
     const int NL = R0 * M, nl_mask = NL - 1;
-    const size_t blk_bytes = size_t(NL) * (FMT == THR_IN_U8 ? 2 : 8);
+    const size_t blk_bytes = cfg.blk_stride;
     const int win_w = min(cfg.win_count + 6, NL);
     const int win_base = cfg.win_lo - 3;
     int parity = 0;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(NT) void k_correlate_sub(
     load_tables(lds, tables);
     __syncthreads();
     const int NL = R0 * M, nl_mask = NL - 1;
-    const size_t blk_bytes = size_t(NL) * (FMT == THR_IN_U8 ? 2 : 8);
+    const size_t blk_bytes = cfg.blk_stride;
     const int n_work = *work_count;
     const int T = cfg.n_templates;
     int parity = 0;

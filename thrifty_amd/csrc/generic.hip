@@ -23,8 +23,9 @@ __device__ __forceinline__ cpx2 gmul(cpx2 a, cpx2 b) {
 
 // ---- stage 0: samples -> complex64 (optionally times the shift phasor)
 template <int FMT, bool SHIFT>
-__global__ __launch_bounds__(256) void g_load(const void* __restrict__ samples, int n, int log2n,
-                                              int n_blocks, const cpx2* __restrict__ twn,
+__global__ __launch_bounds__(256) void g_load(const void* __restrict__ samples, size_t blk_stride,
+                                              int n, int log2n, int n_blocks,
+                                              const cpx2* __restrict__ twn,
                                               const ShiftParams* __restrict__ shifts,
                                               const thr_record* __restrict__ records, int n_tpl,
                                               cpx2* __restrict__ out) {
@@ -34,11 +35,13 @@ __global__ __launch_bounds__(256) void g_load(const void* __restrict__ samples, 
     if (SHIFT && !(records[size_t(b) * n_tpl].flags & THR_FLAG_CARRIER)) return;
     cpx2 x;
     if (FMT == THR_IN_U8) {
-        const uchar2 q = reinterpret_cast<const uchar2*>(samples)[gid];
+        const uchar2 q = reinterpret_cast<const uchar2*>(
+            static_cast<const unsigned char*>(samples) + size_t(b) * blk_stride)[i];
         constexpr float sc = 1.0f / 128.0f, of = -127.4f / 128.0f;
         x = cpx2{fmaf((float)q.x, sc, of), fmaf((float)q.y, sc, of)};
     } else {
-        x = reinterpret_cast<const cpx2*>(samples)[gid];
+        x = reinterpret_cast<const cpx2*>(static_cast<const unsigned char*>(samples) +
+                                          size_t(b) * blk_stride)[i];
     }
     if (SHIFT) {
         const ShiftParams* sp = shifts + b;
@@ -298,10 +301,10 @@ hipError_t generic_carrier(int fmt, const void* samples, int n_blocks, const Dev
     const size_t total = size_t(n_blocks) * n;
     const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
     if (fmt == THR_IN_U8)
-        hipLaunchKernelGGL((g_load<THR_IN_U8, false>), grid, blk, 0, stream, samples, n, log2n, n_blocks,
+        hipLaunchKernelGGL((g_load<THR_IN_U8, false>), grid, blk, 0, stream, samples, size_t(cfg.blk_stride), n, log2n, n_blocks,
                            tw, nullptr, nullptr, 1, a);
     else
-        hipLaunchKernelGGL((g_load<THR_IN_C64, false>), grid, blk, 0, stream, samples, n, log2n,
+        hipLaunchKernelGGL((g_load<THR_IN_C64, false>), grid, blk, 0, stream, samples, size_t(cfg.blk_stride), n, log2n,
                            n_blocks, tw, nullptr, nullptr, 1, a);
     hipError_t e = hipSuccess;
     cpx2* res = run_fft(a, b, n, n_blocks, false, tw, nullptr, 1, stream, &e);
@@ -327,10 +330,10 @@ hipError_t generic_correlate(int fmt, const void* samples, int n_blocks, const D
     const size_t total = size_t(n_blocks) * n;
     const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
     if (fmt == THR_IN_U8)
-        hipLaunchKernelGGL((g_load<THR_IN_U8, true>), grid, blk, 0, stream, samples, n, log2n, n_blocks,
+        hipLaunchKernelGGL((g_load<THR_IN_U8, true>), grid, blk, 0, stream, samples, size_t(cfg.blk_stride), n, log2n, n_blocks,
                            tw, shifts, records, T, a);
     else
-        hipLaunchKernelGGL((g_load<THR_IN_C64, true>), grid, blk, 0, stream, samples, n, log2n, n_blocks,
+        hipLaunchKernelGGL((g_load<THR_IN_C64, true>), grid, blk, 0, stream, samples, size_t(cfg.blk_stride), n, log2n, n_blocks,
                            tw, shifts, records, T, a);
     hipError_t e = hipSuccess;
     cpx2* xhat = run_fft(a, b, n, n_blocks, false, tw, records, T, stream, &e);

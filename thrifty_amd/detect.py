@@ -18,7 +18,7 @@ from types import SimpleNamespace
 import numpy as np
 
 from thrifty_amd import _native, toads_data, util
-from thrifty_amd.block_data import CardStream, block_reader, card_reader
+from thrifty_amd.block_data import CardStream, RawStream, block_reader, card_reader
 from thrifty_amd.setting_parsers import normalize_freq_range
 from thrifty_amd.settings import load_args
 
@@ -49,6 +49,9 @@ class Detector(object):
         self.settings = settings
         # a CardStream is consumed in whole batches with the base64 payloads decoded on the GPU
         self._card = blocks if isinstance(blocks, CardStream) and not yield_data else None
+        # a RawStream likewise: the overlapping blocks are framed on the GPU from the byte stream
+        self._raw = (blocks if isinstance(blocks, RawStream) and blocks.device_framing
+                     and not yield_data else None)
         self.blocks = iter(blocks) if blocks is not None else None
         self.rxid = rxid
         self.yield_data = yield_data
@@ -164,6 +167,18 @@ class Detector(object):
                 return
             stamps, idxs, text, offs = batch
             recs = self._engine.detect_card(text, offs, idxs)[:, 0]
+            self._ready.extend(self._results(stamps, idxs, recs))
+            return
+        if self._raw is not None:
+            batch = self._raw.next_batch(self.batch_size)
+            if batch is None:
+                self._exhausted = True
+                return
+            kind, stamps, idxs, data = batch
+            if kind == "u8":
+                recs = self._engine.detect_stream(data, int(idxs[0]))[:, 0]
+            else:   # lead-in blocks that still contain the all-zero initial history
+                recs = self._engine.detect(data, idxs)[:, 0]
             self._ready.extend(self._results(stamps, idxs, recs))
             return
         items = []
@@ -335,7 +350,9 @@ def detector_cli(detector_class, parser=None, extra_args=None, argv=None):
     info_out = sys.stderr if output_file is sys.stdout else sys.stdout
     window = normalize_freq_range(config.carrier_window, config.sample_rate / config.block_size)
     if args.raw:
-        blocks = block_reader(args.input, config.block_size, config.block_history)
+        # byte stream -> overlapping blocks framed on the device (block_reader-compatible
+        # tuples if the detector class iterates it the classic way)
+        blocks = RawStream(args.input, config.block_size, config.block_history)
     else:
         # binary stream -> batches with on-device base64 decode (card_reader-compatible tuples
         # if the detector class iterates it the classic way)
