@@ -275,6 +275,88 @@ class OracleDetector(object):
 
 
 # --------------------------------------------------------------------------
+# 8(f) rank 2: PreshiftDetector              (experimental/detect_preshift.py)
+# --------------------------------------------------------------------------
+def parabolic_offset(mag, peak_idx):
+    """3-point parabola on the FFT magnitudes (experimental/carrier_interpolators.py:44-49).
+    `mag` is float32, so is the result; mag[peak-1] wraps for peak 0 (Python negative
+    index) and mag[peak+1] raises IndexError past the end, like the reference."""
+    a, b, c = mag[peak_idx - 1], mag[peak_idx], mag[peak_idx + 1]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return (c - a) / (4 * b - 2 * a - 2 * c)
+
+
+class PreshiftBank(object):
+    """`num` template spectra, pre-shifted by -0.5 .. 0.5 bins (detect_preshift.py:24-45)."""
+
+    def __init__(self, template, block_len, num=21):
+        template = np.asarray(template)
+        self.corr_len = block_len - len(template) + 1
+        padded = np.concatenate([template, np.zeros(self.corr_len - 1)])
+        self.shifts = np.linspace(-0.5, 0.5, num)
+        ramp = np.arange(block_len) * 1.0 / block_len - 0.5
+        self.spectra_conj = []
+        for shift in self.shifts:
+            rot = np.exp(-2j * np.pi * shift * ramp)
+            self.spectra_conj.append(np.conj(np.fft.fft(padded * rot)))
+        self.num = num
+
+    def nearest(self, frac):
+        assert -0.5 <= frac <= 0.5
+        return int(np.round((frac + 0.5) * (self.num - 1)))
+
+
+class OraclePreshiftDetector(object):
+    """Functional twin of the reference ``PreshiftDetector`` (defaults: num=21, parabolic
+    interpolator, corr_shift off -- the constructor forces it off, detect_preshift.py:60):
+    FFT#1 is rolled by the rounded carrier bin instead of re-transforming the shifted
+    block, and the residual sub-bin offset picks the nearest pre-shifted template."""
+
+    def __init__(self, block_len, history_len, template, carrier_thresh, carrier_window,
+                 corr_thresh, num=21):
+        self.block_len, self.history_len = block_len, history_len
+        self.new_len = block_len - history_len
+        self.bank = TemplateBank(template, block_len, history_len)   # energy, window
+        self.shifted = PreshiftBank(template, block_len, num)
+        self.carrier_thresh, self.carrier_window = carrier_thresh, carrier_window
+        self.corr_thresh = corr_thresh
+        self.last = None        # (int_shift, frac_shift, template index) of the last block
+
+    def detect_block(self, block_idx, x):
+        assert len(x) == self.block_len
+        spec = np.fft.fft(x)                       # complex64 in -> complex64 out
+        mag = np.abs(spec)
+        det, idx, peak, noise, thr = carrier_detect(mag, self.carrier_thresh,
+                                                    self.carrier_window)
+        off = 0
+        self.last = None
+        if not det:
+            return BlockResult(False, None, CarrierStage(det, idx, off, peak, noise, thr), None)
+        off = parabolic_offset(mag, idx)           # carrier_sync.py:68-70
+        car = CarrierStage(det, idx, off, peak, noise, thr)
+        # the reference's peak index is an np.int64 (argmax + start), so int64 + float32 -> float64
+        shift = -(np.int64(idx) + off)             # carrier_sync.py:71
+        int_shift = int(np.round(shift))           # detect_preshift.py:62-65
+        frac = shift - int_shift
+        rolled = np.roll(spec, int_shift)          # carrier_sync.py:241-245
+        j = self.shifted.nearest(frac)
+        self.last = (int_shift, frac, j)
+        corr = np.fft.ifft(rolled * self.shifted.spectra_conj[j])[: self.shifted.corr_len]
+        # the rest is soa_estimator.py:78-92 unchanged (noise from the rolled complex64 FFT#1)
+        cmag = np.abs(corr)
+        pk, peak_mag = corr_peak(cmag, self.bank.window)
+        cnoise = corr_noise(rolled, self.bank, peak_mag)
+        cthr = threshold_value(cmag, self.corr_thresh, cnoise)
+        cdet = bool(peak_mag > cthr)
+        coff = clip_offset(log_parabola(cmag, pk) if cdet else 0)
+        cs = CorrStage(cdet, pk, coff, peak_mag, cnoise, cthr)
+        return BlockResult(cdet, self.new_len * block_idx + pk + coff, car, cs)
+
+    def detect_u8(self, block_idx, raw):
+        return self.detect_block(block_idx, iq_u8_to_c64(raw))
+
+
+# --------------------------------------------------------------------------
 # a16: .toad line                                      (toads_data.py:47-61)
 # --------------------------------------------------------------------------
 def toad_line(rxid, timestamp, block_idx, res):

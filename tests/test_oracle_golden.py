@@ -165,3 +165,38 @@ def test_iq_conversion_known_answers():
 def test_fft_bin(num):
     got = np.array([onp.fft_bin(i, num) for i in range(num)])
     np.testing.assert_array_equal(got, np.fft.fftfreq(num, 1. / num))
+
+
+# ---- PreshiftDetector variant: fixtures from the reference's
+# ---- experimental/detect_preshift.py (tests/golden/make_golden_preshift.py)
+PRESHIFT_FIXTURES = ["preshift_c2", "preshift_c2_straddle", "preshift_c2_stddev", "preshift_c1",
+                     "preshift_small"]
+
+
+@pytest.mark.parametrize("name", PRESHIFT_FIXTURES)
+def test_preshift_oracle_matches_reference_records(golden, name):
+    g = golden(name)
+    orc = onp.OraclePreshiftDetector(
+        int(g["block_len"]), int(g["history_len"]), g["template"], tuple(g["carrier_thresh"]),
+        tuple(int(v) for v in g["carrier_window"]), tuple(g["corr_thresh"]), num=int(g["num"]))
+    lines = []
+    for i, raw in enumerate(g["blocks"]):
+        if g["index_error"][i]:
+            with pytest.raises(IndexError):
+                orc.detect_u8(int(g["block_idx"][i]), raw)
+            continue
+        res = orc.detect_u8(int(g["block_idx"][i]), raw)
+        car = res.carrier
+        assert car.bin == g["cbin"][i] and car.detected == bool(g["carrier_det"][i])
+        assert res.detected == bool(g["det"][i])
+        assert car.energy == g["cenergy"][i] and car.noise == g["cnoise"][i]
+        if not car.detected:
+            continue
+        assert isinstance(car.offset, np.float32) and car.offset == g["coff"][i]
+        assert orc.last[1] == g["frac_shift"][i]
+        cs = res.corr
+        assert cs.sample == g["sample"][i]
+        assert cs.offset == g["soff"][i] and cs.energy == g["energy"][i] and cs.noise == g["noise"][i]
+        if res.detected:
+            lines.append(onp.toad_line(int(g["rxid"]), 1000.0 + i, int(g["block_idx"][i]), res))
+    assert "\n".join(lines) == str(g["toad"])          # byte for byte what the reference prints
