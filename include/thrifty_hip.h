@@ -79,7 +79,7 @@ typedef struct thr_record {
     float carrier_noise;    /* CarrierSyncInfo.noise  (rms)                        */
     float corr_energy;      /* CorrDetectionInfo.energy (peak magnitude)           */
     float corr_noise;       /* CorrDetectionInfo.noise  (rms)                      */
-    uint64_t reserved;
+    uint64_t reserved;      /* 0 (default detector); see thr_create_preshift       */
 } thr_record;
 
 typedef struct thr_handle thr_handle;
@@ -96,6 +96,21 @@ const char* thr_last_error(void);
  * array need only live for the duration of the call.
  */
 int thr_create(const thr_settings* settings, thr_handle** out);
+/*
+ * PreshiftDetector variant -- replaces `PreshiftDetector.__init__` + `TemplateShifts`
+ * (thrifty/experimental/detect_preshift.py:24-60; defaults num=21, parabolic carrier
+ * interpolator experimental/carrier_interpolators.py:44-49, corr_shift off): the
+ * carrier offset is a 3-point parabola on |FFT#1|, FFT#1 is rolled by the rounded shift
+ * (freq_shift_integer, carrier_sync.py:241-245) and correlated against the nearest of
+ * `num_shifts` template spectra pre-shifted by -0.5 .. +0.5 bin.  Every other entry
+ * point then behaves as documented with these semantics: carrier_offset is the float32
+ * parabola offset; THR_FLAG_INDEX_ERROR marks carrier_bin + 1 >= block_len (where the
+ * reference's fft_mag[peak+1] raises); `reserved` = (uint32 rolled shift << 32) | bank
+ * index.  One template only; thr_debug_* stage dumps are unavailable.  block_len 16384
+ * runs ONE fused kernel per block (FFT, verdict, gather-multiply, IFFT); other lengths
+ * use the multi-pass pipeline.
+ */
+int thr_create_preshift(const thr_settings* settings, int num_shifts, thr_handle** out);
 /* Replaces fastcard_free() (fastcard.c:119-146). */
 void thr_destroy(thr_handle* h);
 

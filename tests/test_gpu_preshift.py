@@ -1,0 +1,145 @@
+"""GPU parity of the PreshiftDetector variant (SURVEY.md 8(f) rank 2;
+csrc/detect16k_preshift.hip + the multi-pass pipeline for other block lengths) against
+fixtures produced by the reference's thrifty/experimental/detect_preshift.py and against the
+pinned oracle restatement."""
+import numpy as np
+import pytest
+
+from oracle import thrifty_np as onp
+from thrifty_amd import _native as F
+from thrifty_amd import block_data, synth
+from thrifty_amd.detect import DetectorSettings
+from thrifty_amd.experimental.detect_preshift import PreshiftDetector
+
+pytestmark = pytest.mark.gpu
+
+FIXTURES = ["preshift_c2", "preshift_c2_straddle", "preshift_c2_stddev", "preshift_c1", "preshift_small"]
+
+
+def engine_for(g, **kw):
+    return F.Engine(int(g["block_len"]), int(g["history_len"]), g["template"],
+                    tuple(g["carrier_thresh"]), tuple(int(v) for v in g["carrier_window"]),
+                    tuple(g["corr_thresh"]), preshift_num=int(g["num"]), **kw)
+
+
+def check_records(rec, g):
+    """bit-exact bin / sample index / verdicts; offsets and energies to the stated tolerance."""
+    n = len(g["blocks"])
+    assert len(rec) == n
+    for i in range(n):
+        r = rec[i]
+        assert r["block_idx"] == g["block_idx"][i]
+        assert r["carrier_bin"] == g["cbin"][i]
+        if g["index_error"][i]:
+            assert r["flags"] & F.FLAG_INDEX_ERROR and not r["flags"] & F.FLAG_CARRIER
+            continue
+        assert bool(r["flags"] & F.FLAG_CARRIER) == bool(g["carrier_det"][i])
+        assert bool(r["flags"] & F.FLAG_CORR) == bool(g["det"][i])
+        np.testing.assert_allclose(r["carrier_energy"], g["cenergy"][i], rtol=1e-5)
+        np.testing.assert_allclose(r["carrier_noise"], g["cnoise"][i], rtol=1e-4)
+        if not g["carrier_det"][i]:
+            continue
+        np.testing.assert_allclose(r["carrier_offset"], g["coff"][i], atol=2e-5)
+        assert r["corr_sample"] == g["sample"][i]                       # bit-exact SoA sample
+        np.testing.assert_allclose(r["corr_energy"], g["energy"][i], rtol=1e-4)
+        np.testing.assert_allclose(r["corr_noise"], g["noise"][i], rtol=1e-4)
+        if g["det"][i]:
+            np.testing.assert_allclose(r["corr_offset"], g["soff"][i], atol=1e-4)
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_matches_reference_goldens(golden, name):
+    g = golden(name)
+    rec = engine_for(g, max_batch=8).detect(g["blocks"], g["block_idx"])[:, 0]
+    check_records(rec, g)
+    # the debug word carries the roll and the bank index the reference would have used
+    for i in range(len(rec)):
+        if g["carrier_det"][i]:
+            shift = -(float(g["cbin"][i]) + float(g["coff"][i]))
+            assert np.int32(np.uint32(rec[i]["reserved"] >> np.uint64(32))) == int(np.round(shift))
+            frac = g["frac_shift"][i]
+            assert int(rec[i]["reserved"] & np.uint64(0xFFFFFFFF)) == int(np.round((frac + 0.5) * (int(g["num"]) - 1)))
+
+
+def test_c64_input_and_generic_pipeline_agree(golden, monkeypatch):
+    g = golden("preshift_c2")
+    eng = engine_for(g, max_batch=8)
+    rec_u8 = eng.detect(g["blocks"], g["block_idx"])[:, 0]
+    c64 = np.stack([block_data.raw_to_complex(b) for b in g["blocks"]])
+    rec_c = eng.detect(c64, g["block_idx"])[:, 0]
+    assert rec_u8.tobytes() == rec_c.tobytes()
+    monkeypatch.setenv("THR_FORCE_GENERIC", "1")
+    eng_gen = engine_for(g, max_batch=8)
+    monkeypatch.delenv("THR_FORCE_GENERIC")
+    rec_gen = eng_gen.detect(g["blocks"], g["block_idx"])[:, 0]
+    check_records(rec_gen, g)
+    assert np.array_equal(rec_gen["corr_sample"], rec_u8["corr_sample"])
+    assert np.array_equal(rec_gen["reserved"], rec_u8["reserved"])
+
+
+@pytest.mark.parametrize("num", [1, 2, 21, 64])
+def test_random_blocks_match_oracle(num):
+    n, h = 16384, 4096
+    tpl = synth.gold_template(10, 3, 1.0)
+    win = onp.unique_window(n, h, len(tpl))
+    rng = np.random.default_rng(1000 + num)
+    nb = 300
+    blocks, _ = synth.synth_blocks(rng, nb, n, tpl, win, signal_frac=0.85)
+    eng = F.Engine(n, h, tpl, (0, 15, 0), (7, 110), (0, 15, 0), max_batch=128, preshift_num=num)
+    rec = eng.detect(blocks, np.arange(nb))[:, 0]
+    orc = onp.OraclePreshiftDetector(n, h, tpl, (0, 15, 0), (7, 110), (0, 15, 0), num=num)
+    hits = bank_flips = 0
+    for i in range(nb):
+        res = orc.detect_u8(i, blocks[i])
+        r = rec[i]
+        assert r["carrier_bin"] == res.carrier.bin
+        assert bool(r["flags"] & F.FLAG_CARRIER) == res.carrier.detected
+        if not res.carrier.detected:
+            continue
+        # float32 parabola: |X| differs from np.abs(complex64) by an ulp or two and the
+        # denominator 4b - 2a - 2c amplifies that; SURVEY 8(c) allows 1e-3 bin here
+        np.testing.assert_allclose(r["carrier_offset"], res.carrier.offset, atol=1e-4)
+        if int(r["reserved"] & np.uint64(0xFFFFFFFF)) != orc.last[2]:
+            bank_flips += 1          # offset within float rounding of a bank boundary
+            continue
+        assert bool(r["flags"] & F.FLAG_CORR) == res.detected
+        assert r["corr_sample"] == res.corr.sample
+        np.testing.assert_allclose(r["corr_energy"], res.corr.energy, rtol=1e-4)
+        if res.detected:
+            hits += 1
+            np.testing.assert_allclose(r["corr_offset"], res.corr.offset, atol=1e-4)
+    assert hits > 200 and bank_flips <= 1
+
+
+def test_detector_class_serialises_like_the_reference(golden):
+    g = golden("preshift_c2")
+    st = DetectorSettings(int(g["block_len"]), int(g["history_len"]), len(g["template"]),
+                          tuple(g["carrier_thresh"]), tuple(int(v) for v in g["carrier_window"]),
+                          g["template"], tuple(g["corr_thresh"]))
+    blocks = [(1000.0 + i, int(g["block_idx"][i]), g["blocks"][i]) for i in range(len(g["blocks"]))]
+    det = PreshiftDetector(st, blocks, rxid=int(g["rxid"]), num=int(g["num"]), batch_size=7)
+    lines = [res.serialize() for detected, res in det if detected]
+    want = str(g["toad"]).split("\n")
+    assert len(lines) == len(want)
+    for a, b in zip(lines, want):
+        fa, fb = a.split(), b.split()
+        assert fa[:3] == fb[:3] and fa[4] == fb[4] and fa[8] == fb[8]      # rxid ts block | sample | bin
+        np.testing.assert_allclose(float(fa[3]), float(fb[3]), atol=2e-4)   # soa
+        np.testing.assert_allclose([float(v) for v in fa[5:8]], [float(v) for v in fb[5:8]], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(float(fa[9]), float(fb[9]), atol=2e-5)   # float32 carrier offset
+        assert float(np.float32(float(fa[9]))) == float(fa[9])   # a widened float32, like the reference's
+    with pytest.raises(NotImplementedError):
+        PreshiftDetector(st, None, interpolator=lambda m, p: 0)
+    with pytest.raises(F.NativeError, match="exactly one template"):
+        F.Engine(16384, 4096, np.ones((2, 100)), (0, 15, 0), (7, 110), (0, 15, 0), preshift_num=21)
+
+
+def test_index_error_is_raised_like_the_reference(golden):
+    g = golden("preshift_c2_straddle")
+    st = DetectorSettings(int(g["block_len"]), int(g["history_len"]), len(g["template"]),
+                          tuple(g["carrier_thresh"]), tuple(int(v) for v in g["carrier_window"]),
+                          g["template"], tuple(g["corr_thresh"]))
+    det = PreshiftDetector(st, None, num=int(g["num"]))
+    bad = int(np.flatnonzero(g["index_error"])[0])
+    with pytest.raises(IndexError):
+        det.detect(0.0, 0, g["blocks"][bad])

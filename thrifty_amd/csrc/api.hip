@@ -105,6 +105,9 @@ struct thr_handle {
     int* d_work_count = nullptr;
     float4* d_xhat_scratch = nullptr;
     int* d_ncompact = nullptr;
+    // PreshiftDetector variant (thr_create_preshift): bank of pre-shifted template spectra
+    int preshift_num = 0;       // 0 = default detector
+    float2* d_bank = nullptr;   // [num][N]; 16384: [k3][k1][k2] gather layout, else natural order
     // .card ingest staging (lazy)
     unsigned char* d_text = nullptr;
     size_t d_text_bytes = 0;
@@ -256,6 +259,33 @@ int build_constants(thr_handle* h) {
     return THR_OK;
 }
 
+// Pre-shifted template spectra of the PreshiftDetector variant (detect_preshift.py:24-40):
+// conj(FFT(template_padded * exp(-2 pi i shift_j (n/N - 1/2)))) / N, shift_j = linspace(-.5, .5, num).
+int build_preshift_bank(thr_handle* h) {
+    const int n = h->cfg.block_len, w = h->cfg.template_len, num = h->preshift_num;
+    std::vector<float2> bank(size_t(num) * n);
+    const double pi = 3.14159265358979323846;
+    for (int j = 0; j < num; ++j) {
+        const double shift = num > 1 ? -0.5 + double(j) / double(num - 1) : -0.5;
+        std::vector<std::complex<double>> buf(n, 0.0);
+        for (int i = 0; i < w; ++i) {
+            const double ph = -2.0 * pi * shift * (double(i) / double(n) - 0.5);
+            buf[i] = h->cfg.templates[i] * std::complex<double>(std::cos(ph), std::sin(ph));
+        }
+        host_fft(buf);
+        float2* out = bank.data() + size_t(j) * n;
+        for (int k = 0; k < n; ++k) {
+            const std::complex<double> c = std::conj(buf[k]) / double(n);
+            // 16384 kernel: bin k = k1 + 16 k2 + 512 k3 lives at (k3 * 16 + k1) * 32 + k2
+            const int pos = h->fast ? (((k >> 9) * 16 + (k & 15)) * 32 + ((k >> 4) & 31)) : k;
+            out[pos] = float2{float(c.real()), float(c.imag())};
+        }
+    }
+    HIP_TRY(hipMalloc(&h->d_bank, bank.size() * sizeof(float2)));
+    HIP_TRY(hipMemcpy(h->d_bank, bank.data(), bank.size() * sizeof(float2), hipMemcpyHostToDevice));
+    return THR_OK;
+}
+
 int ensure_staging(thr_handle* h, int format) {
     const size_t need = size_t(h->cfg.max_batch) * h->cfg.block_len * (format == THR_IN_U8 ? 2 : 8);
     if (h->d_in_bytes < need) {
@@ -277,6 +307,20 @@ int run_batch_fast(thr_handle* h, const void* d_samples, int format,
                    float2* dump_xhat, float2* dump_corr, int dump_template, bool carrier_only) {
     const int grid = std::min(n_blocks, h->n_cu);
     h->prof = h->prof_every > 0 && (h->batch_no++ % h->prof_every) == 0;
+    if (h->preshift_num) {
+        if (dump_fft || dump_xhat || dump_corr || carrier_only)
+            return fail(THR_ERR_ARG, "stage dumps are not available in the preshift variant");
+        {
+            ProfScope p(h, 2);   // the fused kernel is accounted in k_correlate's slot
+            HIP_TRY(thr::launch_preshift_16k(format, d_samples, n_blocks, h->dev, h->d_tables,
+                                             h->d_bank, h->preshift_num, d_block_idx,
+                                             h->d_corr_stats, d_out, grid, h->stream));
+        }
+        ProfScope p(h, 3);
+        HIP_TRY(thr::launch_finish(n_blocks, h->dev, h->d_corr_stats, d_out, h->d_work_count,
+                                   h->stream));
+        return THR_OK;
+    }
     {
         ProfScope p(h, 0);
         HIP_TRY((h->w16 ? thr::launch_carrier_16k_w16 : thr::launch_carrier_16k)(
@@ -327,6 +371,25 @@ int run_batch_generic(thr_handle* h, const void* d_samples, int format,
             HIP_TRY(hipMemcpyAsync(dump_fft + size_t(off) * n, spectrum, size_t(nb) * n * sizeof(float2),
                                    hipMemcpyDeviceToDevice, h->stream));
         if (carrier_only) continue;
+        if (h->preshift_num) {
+            if (dump_xhat || dump_corr)
+                return fail(THR_ERR_ARG, "stage dumps are not available in the preshift variant");
+            {
+                ProfScope p(h, 1);
+                HIP_TRY(thr::launch_fit_preshift(nb, h->dev, h->preshift_num, h->d_stats,
+                                                 d_block_idx ? d_block_idx + off : nullptr,
+                                                 h->d_shifts, out, h->stream));
+            }
+            {
+                ProfScope p(h, 2);
+                HIP_TRY(thr::generic_preshift_correlate(nb, h->dev, h->d_twn, h->d_bank, h->d_shifts,
+                                                        out, h->d_gen_scratch, spectrum,
+                                                        h->d_corr_stats, h->stream));
+            }
+            ProfScope p(h, 3);
+            HIP_TRY(thr::launch_finish(nb, h->dev, h->d_corr_stats, out, h->d_work_count, h->stream));
+            continue;
+        }
         {
             ProfScope p(h, 1);
             HIP_TRY(thr::launch_fit(nb, h->dev, h->d_stats, d_block_idx ? d_block_idx + off : nullptr,
@@ -421,7 +484,19 @@ const char* thr_kernel_name(int slot) {
     return (slot >= 0 && slot < THR_N_KERNEL_SLOTS) ? names[slot] : "";
 }
 
-int thr_create(const thr_settings* s, thr_handle** out) {
+static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out);
+
+int thr_create(const thr_settings* s, thr_handle** out) { return create_impl(s, 0, out); }
+
+int thr_create_preshift(const thr_settings* s, int num_shifts, thr_handle** out) {
+    if (num_shifts < 1 || num_shifts > 4096)
+        return fail(THR_ERR_ARG, "num_shifts %d out of range [1, 4096]", num_shifts);
+    if (s && s->n_templates != 1)
+        return fail(THR_ERR_ARG, "the preshift variant takes exactly one template");
+    return create_impl(s, num_shifts, out);
+}
+
+static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out) {
     if (!s || !out) return fail(THR_ERR_ARG, "thr_create: null argument");
     *out = nullptr;
     const int n = s->block_len;
@@ -448,11 +523,13 @@ int thr_create(const thr_settings* s, thr_handle** out) {
     h->cfg = *s;
     h->cfg.templates = nullptr;  // not retained beyond this call (re-pointed below)
     h->device = s->device_id;
+    h->preshift_num = preshift_num;
     h->fast = (n == 16384) && getenv("THR_FORCE_GENERIC") == nullptr;
-    h->lng = thr::long_supported(n) && getenv("THR_FORCE_GENERIC") == nullptr;
+    // the preshift variant has a fused kernel for 16384 only; other lengths use the multi-pass pipeline
+    h->lng = thr::long_supported(n) && getenv("THR_FORCE_GENERIC") == nullptr && !preshift_num;
     {
         const char* g = getenv("THR_GEOMETRY");  // "w8" | "w16": A/B of the two workgroup shapes
-        h->w16 = g != nullptr && std::string(g) == "w16";
+        h->w16 = g != nullptr && std::string(g) == "w16" && !preshift_num;
     }
     int rc = THR_OK;
     do {
@@ -514,6 +591,7 @@ int thr_create(const thr_settings* s, thr_handle** out) {
 
         h->cfg.templates = s->templates;
         rc = build_constants(h);
+        if (rc == THR_OK && preshift_num) rc = build_preshift_bank(h);
         h->cfg.templates = nullptr;
         if (rc != THR_OK) break;
 
@@ -523,6 +601,7 @@ int thr_create(const thr_settings* s, thr_handle** out) {
         break;                                                                        \
     }
         if (h->fast) CREATE_TRY(h->w16 ? thr::prepare_16k_w16() : thr::prepare_16k());
+        if (h->fast && preshift_num) CREATE_TRY(thr::prepare_preshift_16k());
         if (h->lng) {
             CREATE_TRY(thr::prepare_long(n));
             const int r0 = n / 16384;
@@ -576,7 +655,7 @@ void thr_destroy(thr_handle* h) {
         hipEventDestroy(e.a);
         hipEventDestroy(e.b);
     }
-    void* bufs[] = {h->d_tables, h->d_twn, h->d_tspec, h->d_stats, h->d_shifts, h->d_corr_stats, h->d_text, h->d_payload_off, h->d_bad, h->d_gen_scratch, h->d_tspec_nat, h->d_win_pow, h->d_partial, h->d_partial_x2, h->d_dsub, h->d_work_list,
+    void* bufs[] = {h->d_tables, h->d_twn, h->d_tspec, h->d_stats, h->d_shifts, h->d_corr_stats, h->d_text, h->d_payload_off, h->d_bad, h->d_gen_scratch, h->d_tspec_nat, h->d_bank, h->d_win_pow, h->d_partial, h->d_partial_x2, h->d_dsub, h->d_work_list,
                     h->d_work_count, h->d_xhat_scratch, h->d_ncompact, h->d_in, h->d_idx, h->d_rec};
     for (void* b : bufs)
         if (b) hipFree(b);

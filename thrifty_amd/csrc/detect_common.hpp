@@ -62,7 +62,19 @@ struct ShiftParams {
     float2 c0;        // exp(-pi i s)
     int si_mod;       // round(s) mod N
     float sf_over_n;  // (s - round(s)) / N
+    int bank;         // preshift variant (multi-pass pipeline): pre-shifted template index
+    int pad_;
 };
+
+// detect16k_preshift.hip -- PreshiftDetector variant (one fused kernel per block at 16384)
+hipError_t prepare_preshift_16k();
+hipError_t launch_preshift_16k(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,
+                               const float2* tables, const float2* bank, int num,
+                               const long long* block_idx, CorrStats* corr_stats,
+                               thr_record* records, int grid, hipStream_t stream);
+hipError_t launch_fit_preshift(int n_blocks, const DevCfg& cfg, int num, const CarStats* stats,
+                               const long long* block_idx, ShiftParams* shifts,
+                               thr_record* records, hipStream_t stream);
 
 // detect16k.hip
 hipError_t prepare_16k();
@@ -129,5 +141,12 @@ hipError_t generic_correlate(int fmt, const void* samples, int n_blocks, const D
                              const ShiftParams* shifts, const thr_record* records, float2* scratch,
                              CorrStats* corr_stats, int dump_template, float2** keep_xhat,
                              float2** keep_corr, hipStream_t stream);
+// preshift variant: `spectrum` = generic_carrier's FFT#1 (inside scratch), rolled by
+// shifts[b].si_mod and multiplied by bank[shifts[b].bank] (natural order, conj, /N)
+hipError_t generic_preshift_correlate(int n_blocks, const DevCfg& cfg, const float2* twn,
+                                      const float2* bank_nat, const ShiftParams* shifts,
+                                      const thr_record* records, float2* scratch,
+                                      const float2* spectrum, CorrStats* corr_stats,
+                                      hipStream_t stream);
 
 }  // namespace thr

@@ -194,6 +194,23 @@ __global__ __launch_bounds__(256) void g_mult(const cpx2* __restrict__ xhat,
     out[gid] = gmul(xhat[gid], tconj[i]);
 }
 
+// ---- preshift variant: roll(X, s)[k] * conj(T_bank)[k] / N, evaluated as X[k'] * Tc[(k' + s) mod N]
+// (the product comes out rotated by -s, which only modulates the correlation's phase;
+// carrier_sync.py:241-245, detect_preshift.py:67-70)
+__global__ __launch_bounds__(256) void g_mult_preshift(const cpx2* __restrict__ spectrum,
+                                                       const cpx2* __restrict__ bank, int n,
+                                                       int log2n, int n_blocks,
+                                                       const ShiftParams* __restrict__ shifts,
+                                                       const thr_record* __restrict__ records,
+                                                       cpx2* __restrict__ out) {
+    const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int b = int(gid >> log2n), i = int(gid & size_t(n - 1));
+    if (b >= n_blocks) return;
+    if (!(records[b].flags & THR_FLAG_CARRIER)) return;
+    const ShiftParams* sp = shifts + b;
+    out[gid] = gmul(spectrum[gid], bank[size_t(sp->bank) * n + ((i + sp->si_mod) & (n - 1))]);
+}
+
 // ---- correlation statistics of one block per workgroup (soa_estimator.py:137-143 + sums)
 __global__ __launch_bounds__(256) void g_corr_stats(const cpx2* __restrict__ corr,
                                                     const cpx2* __restrict__ xhat, DevCfg cfg,
@@ -355,6 +372,31 @@ hipError_t generic_correlate(int fmt, const void* samples, int n_blocks, const D
             if (T > 1) return hipGetLastError();  // debug dump of one template: stop here
         }
     }
+    return hipGetLastError();
+}
+
+hipError_t generic_preshift_correlate(int n_blocks, const DevCfg& cfg, const float2* twn,
+                                      const float2* bank_nat, const ShiftParams* shifts,
+                                      const thr_record* records, float2* scratch,
+                                      const float2* spectrum, CorrStats* corr_stats,
+                                      hipStream_t stream) {
+    const int n = cfg.block_len, log2n = ilog2(n);
+    cpx2* a = reinterpret_cast<cpx2*>(scratch);
+    cpx2* b = a + size_t(n_blocks) * n;
+    cpx2* c = b + size_t(n_blocks) * n;
+    const cpx2* spec = reinterpret_cast<const cpx2*>(spectrum);
+    cpx2* free1 = (spec == a) ? b : a;  // generic_carrier left FFT#1 in a or b
+    const cpx2* tw = reinterpret_cast<const cpx2*>(twn);
+    const size_t total = size_t(n_blocks) * n;
+    const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
+    hipLaunchKernelGGL(g_mult_preshift, grid, blk, 0, stream, spec,
+                       reinterpret_cast<const cpx2*>(bank_nat), n, log2n, n_blocks, shifts, records,
+                       free1);
+    hipError_t e = hipSuccess;
+    cpx2* corr = run_fft(free1, c, n, n_blocks, true, tw, records, 1, stream, &e);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(g_corr_stats, dim3(n_blocks), blk, 0, stream, corr, spec, cfg, 0, records,
+                       corr_stats);
     return hipGetLastError();
 }
 

@@ -44,8 +44,11 @@ class Detector(object):
     processed per launch, results are handed out one per input block, in order.
     """
 
+    _fit_reach = 3            # the carrier interpolator reads fft_mag[peak + 3] (carrier_sync.py:187)
+    _offset_type = float      # CarrierSyncInfo.offset as the reference types it
+
     def __init__(self, settings, blocks=None, rxid=-1, yield_data=False, batch_size=256,
-                 device_id=0):
+                 device_id=0, _preshift_num=0):
         self.settings = settings
         # a CardStream is consumed in whole batches with the base64 payloads decoded on the GPU
         self._card = blocks if isinstance(blocks, CardStream) and not yield_data else None
@@ -63,7 +66,7 @@ class Detector(object):
         self._engine = _native.Engine(
             settings.block_len, settings.history_len, template, settings.carrier_thresh,
             settings.carrier_window, settings.corr_thresh, carrier_len=settings.carrier_len,
-            device_id=device_id, max_batch=self.batch_size)
+            device_id=device_id, max_batch=self.batch_size, preshift_num=_preshift_num)
         self._ready = deque()
         self._exhausted = False
         corr_len = settings.block_len - len(template) + 1
@@ -91,12 +94,12 @@ class Detector(object):
         flags = int(rec["flags"])
         if flags & _native.FLAG_INDEX_ERROR:
             n = self.settings.block_len
-            # the reference indexes fft_mag[peak_idx + 3] without wrapping (carrier_sync.py:187)
+            # the reference indexes fft_mag[peak_idx + reach] without wrapping (carrier_sync.py:187)
             raise IndexError("index {} is out of bounds for axis 0 with size {}".format(
-                max(int(rec["carrier_bin"]) + 3, n), n))
+                max(int(rec["carrier_bin"]) + self._fit_reach, n), n))
         has_carrier = bool(flags & _native.FLAG_CARRIER)
         carrier = toads_data.CarrierSyncInfo(
-            int(rec["carrier_bin"]), float(rec["carrier_offset"]) if has_carrier else 0,
+            int(rec["carrier_bin"]), self._offset_type(rec["carrier_offset"]) if has_carrier else 0,
             np.float32(rec["carrier_energy"]), np.float32(rec["carrier_noise"]))
         if not has_carrier:
             return False, toads_data.DetectionResult(timestamp, block_idx, None, carrier, None,
@@ -117,7 +120,8 @@ class Detector(object):
             return [self._result(stamps[i], int(idxs[i]), recs[i]) for i in range(len(recs))]
         fl = flags.tolist()
         cbin = recs["carrier_bin"].tolist()
-        coff = recs["carrier_offset"].tolist()
+        coff = (recs["carrier_offset"].tolist() if self._offset_type is float
+                else recs["carrier_offset"].astype(self._offset_type))
         cen, cno = recs["carrier_energy"], recs["carrier_noise"]     # stay np.float32
         samp = recs["corr_sample"].tolist()
         soff = recs["corr_offset"].tolist()
