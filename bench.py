@@ -48,6 +48,10 @@ def parse_args():
     ap.add_argument("--profile-kernels", type=int, default=8,
                     help="n > 0: HIP events around the kernels of every n-th step of the timed "
                          "region (roofline leg; 1 = every step, costs ~4%%); 0 = off")
+    ap.add_argument("--variant", choices=["default", "preshift"], default="default",
+                    help="default: reference Detector (the headline); preshift: the reference's "
+                         "experimental PreshiftDetector (one fused kernel per block)")
+    ap.add_argument("--preshift-num", type=int, default=21, help="bank size of --variant preshift")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="wall budget of the CPU baseline leg (0 disables)")
     return ap.parse_args()
@@ -80,17 +84,23 @@ def synth_on_device(torch, dev, gen, n_blocks, template, window, signal_frac, ch
     return out
 
 
-def cpu_baseline(blocks_u8, idx, template, budget_s, gpu_rec, n_templates):
+def cpu_baseline(blocks_u8, idx, template, budget_s, gpu_rec, n_templates, preshift_num=0):
     """Oracle (oracle/thrifty_np.py, a NumPy port of the reference algorithm) timed on
     host cores over a bounded sample of the same blocks; also spot-checks parity."""
     from oracle import thrifty_np as onp
     from thrifty_amd import _native as F
     os.environ.setdefault("OMP_NUM_THREADS", "1")
-    orc = onp.OracleDetector(N_BLOCK, HISTORY, template, (0, 15, 0), (7, 110), (0, 15, 0))
+    if preshift_num:
+        orc = onp.OraclePreshiftDetector(N_BLOCK, HISTORY, template, (0, 15, 0), (7, 110), (0, 15, 0),
+                                         num=preshift_num)
+    else:
+        orc = onp.OracleDetector(N_BLOCK, HISTORY, template, (0, 15, 0), (7, 110), (0, 15, 0))
     done, mism = 0, 0
     t0 = time.perf_counter()
     for i in range(len(blocks_u8)):
-        (res,) = orc.detect_u8(int(idx[i]), blocks_u8[i])
+        res = orc.detect_u8(int(idx[i]), blocks_u8[i])
+        if not preshift_num:
+            (res,) = res
         r = gpu_rec[i]
         ok = (r["carrier_bin"] == res.carrier.bin and
               bool(r["flags"] & F.FLAG_CARRIER) == res.carrier.detected)
@@ -141,8 +151,9 @@ def main():
     pad = HISTORY - wlen + 1
     window = (pad // 2, (N_BLOCK - wlen + 1) - (pad - pad // 2))
 
+    pnum = args.preshift_num if args.variant == "preshift" else 0
     engs = [F.Engine(N_BLOCK, HISTORY, tpls, (0, 15, 0), (7, 110), (0, 15, 0), device_id=local,
-                     max_batch=B) for _ in range(max(1, args.streams))]
+                     max_batch=B, preshift_num=pnum) for _ in range(max(1, args.streams))]
     eng = engs[0]
     if len(engs) == 1:
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -208,6 +219,8 @@ def main():
         blocks_total = world * total
         value = blocks_total / dt
         bytes_per_block = 2 * N_BLOCK + 64 * T
+        if pnum:   # the fused kernel is timed in k_correlate's event slot
+            prof = {("k_preshift" if k == "k_correlate" else k): v for k, v in prof.items()}
         dom = max(prof, key=lambda k: prof[k][0])
         dom_ms, dom_cnt = prof[dom]
         if dom_cnt == 0:  # --profile-kernels 0: fall back to the whole step
@@ -230,6 +243,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: block_len=16384 history=4096 "
                                    "1023-chip Gold template (10-bit, 1 sample/chip), %s mix, "
                                    "%d blocks per GPU resident in HBM as u8 IQ" % (args.mix, total),
+                       "variant": args.variant if not pnum else "preshift(num=%d)" % pnum,
                        "blocks_per_step_per_gpu": B, "templates": T,
                        "carrier_window": [7, 110], "thresholds": "15*snr",
                        "parallelism": "block-shard x%d" % world,
@@ -245,7 +259,7 @@ def main():
             ns = min(total, 16384)
             line["cpu_baseline"] = cpu_baseline(
                 data[:ns].cpu().numpy(), np.arange(first, first + ns), tpls[0], args.cpu_seconds,
-                rec.view(total, T, 64)[:ns, 0].cpu().numpy().view(F.RECORD_DTYPE).reshape(-1), T)
+                rec.view(total, T, 64)[:ns, 0].cpu().numpy().view(F.RECORD_DTYPE).reshape(-1), T, pnum)
         print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()

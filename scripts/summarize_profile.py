@@ -10,7 +10,8 @@ root = sys.argv[1]
 
 
 def short(name):
-    for k in ("k_carrier_pruned", "k_carrier", "k_fit", "k_finish", "k_correlate", "k_compact"):
+    for k in ("k_carrier_pruned", "k_carrier", "k_fit_preshift", "k_fit", "k_finish", "k_correlate", "k_preshift",
+              "k_compact"):
         if k in name:
             return k
     return name[:60]
