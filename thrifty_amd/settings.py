@@ -13,29 +13,34 @@ from thrifty_amd import setting_parsers as sp
 
 Definition = namedtuple("SettingDefinition", "args parser default description")
 
-DEFINITIONS = {
-    "sample_rate": Definition(["--sample-rate", "-s"], sp.metric_float, "2.4M", "Sample rate (sps)"),
-    "chip_rate": Definition(["--chip-rate", "-p"], sp.metric_float, "0.999707M",
-                            "Rate at which the code is being transmitted (bps)"),
-    "tuner_freq": Definition(["--freq", "-f"], sp.metric_float, "433.83M", "Tuner center frequency (Hz)"),
-    "tuner_gain": Definition(["--gain", "-g"], float, "0", "Tuner gain (dB)"),
-    "capture_skip": Definition(["--skip", "-k"], int, "1",
-                               "Number of blocks to skip before starting capturing from the SDR"),
-    "block_size": Definition(["--block-size", "-b"], int, "16384",
-                             "Length of fixed-sized blocks, which should be a power of two (samples)"),
-    "block_history": Definition(["--history", "-y"], int, "4920",
-                                "The number of samples at the end of a block that should be repeated "
-                                "at the start of the next block (samples)"),
-    "carrier_window": Definition(["--carrier-window", "-w"], sp.freq_range, "0--1",
-                                 "Range of frequencies or frequency bins to look for carrier"),
-    "carrier_threshold": Definition(["--carrier-threshold", "-t"], sp.threshold, "15*snr",
-                                    "Threshold formula for carrier detector"),
-    "corr_threshold": Definition(["--corr-threshold", "-u"], sp.threshold, "15*snr",
-                                 "Threshold formula for correlation peak detector"),
-    "template": Definition(["--template", "-z"], str, "template.npy",
-                           "Load template from a Numpy .npy file"),
-    "rxid": Definition(["--rxid", "-r"], int, -1, "Unique identifier of this receiver"),
-}
+# key -> (long flag, short flag, value parser, default as the user would type it, help).
+# Keys, flags and defaults are the reference's CLI/config contract; the help text is ours.
+_TABLE = (
+    ("sample_rate", "--sample-rate", "-s", sp.metric_float, "2.4M",
+     "ADC rate of the receiver in samples per second; SI suffixes allowed"),
+    ("chip_rate", "--chip-rate", "-p", sp.metric_float, "0.999707M",
+     "chips per second of the transmitted spreading code"),
+    ("tuner_freq", "--freq", "-f", sp.metric_float, "433.83M",
+     "frequency the SDR tuner is centred on, in Hz"),
+    ("tuner_gain", "--gain", "-g", float, "0", "SDR tuner gain in dB"),
+    ("capture_skip", "--skip", "-k", int, "1",
+     "how many blocks the capture tool discards before it starts writing"),
+    ("block_size", "--block-size", "-b", int, "16384",
+     "samples per processing block; a power of two"),
+    ("block_history", "--history", "-y", int, "4920",
+     "samples of overlap: the tail of every block is replayed at the head of the next"),
+    ("carrier_window", "--carrier-window", "-w", sp.freq_range, "0--1",
+     "where to search for the carrier, as FFT bins or as frequencies (e.g. '7-110', '-20k - 20k')"),
+    ("carrier_threshold", "--carrier-threshold", "-t", sp.threshold, "15*snr",
+     "detection rule for the carrier peak: constant + k*snr + k*stddev"),
+    ("corr_threshold", "--corr-threshold", "-u", sp.threshold, "15*snr",
+     "detection rule for the correlation peak, same grammar"),
+    ("template", "--template", "-z", str, "template.npy",
+     "path of the .npy file holding the sampled positioning code"),
+    ("rxid", "--rxid", "-r", int, -1, "integer naming this receiver in the output"),
+)
+DEFINITIONS = {key: Definition([long_flag, short_flag], parser, default, text)
+               for key, long_flag, short_flag, parser, default, text in _TABLE}
 
 DEFAULT_CONFIG_PATH = "detector.cfg"
 CONFIG_COMMENT_CHAR = "#"
