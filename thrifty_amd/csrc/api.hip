@@ -582,9 +582,11 @@ static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out
         d.car_want_std = s->carrier_thresh[2] != 0.0;
         d.car_prune = 0;
         if (!d.car_want_std && getenv("THR_NO_PRUNE") == nullptr) {
-            if (d.win_lo >= 3 && d.win_lo + d.win_count + 3 <= 128)
-                d.car_prune = 1;  // window and fit margin already inside bins [0,128)
-            else if (d.win_count + 6 <= 128)
+            // long blocks: R0 sub-transforms, each pruned to its 128 lowest bins (mode 1 only)
+            const int span = 128 * (h->lng ? n / 16384 : 1);
+            if (d.win_lo >= 3 && d.win_lo + d.win_count + 3 <= span)
+                d.car_prune = 1;  // window and fit margin already inside bins [0, span)
+            else if (d.win_count + 6 <= 128 && !h->lng)
                 d.car_prune = 2;  // any narrow window: pre-shift by win_lo - 3
         }
         d.cor_want_std = s->corr_thresh[2] != 0.0;
@@ -608,9 +610,11 @@ static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out
             // sub-batch: large enough to amortise the small kernels' launch latency, small enough
             // that the per-(block, template) sub-transform outputs stay around 0.5 GiB
             h->long_batch = std::min(s->max_batch, std::max(64, 1024 / s->n_templates));
+            if (getenv("THR_LONG_BATCH")) h->long_batch = std::max(1, std::min(s->max_batch, atoi(getenv("THR_LONG_BATCH"))));
             const size_t lb = size_t(h->long_batch);
             const size_t win_w = size_t(std::min(h->dev.win_count + 6, n));
-            CREATE_TRY(hipMalloc(&h->d_win_pow, lb * win_w * sizeof(float)));
+            // (the decimation-in-time carrier stage parks R0 complex values per window bin here)
+            CREATE_TRY(hipMalloc(&h->d_win_pow, lb * win_w * sizeof(float) * 2 * r0));
             CREATE_TRY(hipMalloc(&h->d_partial, lb * r0 * 2 * sizeof(float)));
             CREATE_TRY(hipMalloc(&h->d_partial_x2, lb * r0 * sizeof(float)));
             CREATE_TRY(hipMalloc(&h->d_dsub, lb * s->n_templates * size_t(n) * sizeof(float2)));

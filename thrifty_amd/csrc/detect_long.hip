@@ -176,6 +176,221 @@ __global__ __launch_bounds__(NT) void k_carrier_sub(const void* __restrict__ sam
     }
 }
 
+// Pruned variant (cf. k_carrier_pruned in detect16k.hip): when the window plus its 3-bin
+// fit margin lies inside bins [0, 128 R0) every sub-transform only needs q = k1 + 16 k2 with
+// k2 < 8, k3 = 0 -- pass 2 keeps 8 of 32 outputs, pass 3 is a 32-term sum in 128 threads --
+// and its share of sum |X|^2 is M * sum |y_k0[m]|^2 (Parseval over the sub-transform's input).
+template <int FMT, int R0>
+__global__ __launch_bounds__(NT) void k_carrier_sub_pruned(const void* __restrict__ samples,
+                                                           int n_blocks, DevCfg cfg,
+                                                           const cpx* __restrict__ tables,
+                                                           const cpx* __restrict__ twn,
+                                                           float* __restrict__ win_pow,
+                                                           float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cpx* lds = reinterpret_cast<cpx*>(smem_raw);
+    unsigned char* sc_red = reinterpret_cast<unsigned char*>(lds + OFF_S);
+    float2* sc_rp = reinterpret_cast<float2*>(sc_red + 2 * red_slot_bytes<NT / 64>());  // [16]
+    float2* sc_g = sc_rp + 16;                                                            // [R0]
+
+    load_tables(lds, tables);
+    __syncthreads();
+    const int NL = R0 * M, nl_mask = NL - 1;
+    const size_t blk_bytes = cfg.blk_stride;
+    const int win_w = cfg.win_count + 6;
+    const int win_base = cfg.win_lo - 3;
+    int parity = 0;
+    const bool per_block = n_blocks >= int(gridDim.x);
+    const int n_iter = per_block ? ((n_blocks - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x)) * R0
+                                 : (n_blocks * R0 - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x);
+    for (int it = 0; it < n_iter; ++it) {
+        const int item = per_block ? (int(blockIdx.x) + (it / R0) * int(gridDim.x)) * R0 + it % R0
+                                   : int(blockIdx.x) + it * int(gridDim.x);
+        const int b = item / R0, k0 = item % R0;
+        const int t = opaque_tid();
+        __syncthreads();  // scratch factors of the previous item are no longer read
+        item_factors<R0>(sc_rp, sc_g, nullptr, twn, k0, nl_mask);
+        cpx p[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) p[e] = twn[((2 * t + e) * k0) & nl_mask];  // W_NL^(m' k0)
+        __syncthreads();
+        RawLong<FMT, R0, FMT == THR_IN_C64> raw{
+            static_cast<const unsigned char*>(samples) + size_t(b) * blk_bytes, sc_g, t, k0};
+        float sums[1];
+        fwd_pass1<true>(lds, raw, sc_rp, p[0], p[1], &sums[0]);
+        __syncthreads();
+        fwd_pass2<8>(lds);
+        __builtin_amdgcn_sched_barrier(0);
+        const int k2 = t & 31;
+        if (k2 < 8) {
+            const f4* src = reinterpret_cast<const f4*>(lds + (t >> 5) * ROW + k2 * CHUNK);
+            f4 acc = src[0];
+#pragma unroll
+            for (int j = 1; j < R3 / 2; ++j) acc += src[j];
+            const cpx x = cpx{acc.x + acc.z, acc.y + acc.w};
+            const int k = k0 + R0 * ((t >> 5) + 16 * k2);
+            const unsigned wi = unsigned(k - win_base);
+            if (wi < unsigned(win_w)) win_pow[size_t(b) * win_w + wi] = cnorm(x);
+        }
+        double tot[1];
+        unsigned long long dummy = 0;
+        block_reduce<1, NT / 64>(sums, tot, dummy, sc_red, parity);
+        parity ^= 1;
+        if (t == 0) {
+            partial[(size_t(b) * R0 + k0) * 2 + 0] = (float)(tot[0] * double(M));  // Parseval
+            partial[(size_t(b) * R0 + k0) * 2 + 1] = 0.f;
+        }
+    }
+}
+
+// Decimation-in-time carrier stage: when window + margin lie inside bins [0, 128) the R0
+// sub-transforms can run over the DECIMATED sequences x[R0 m + r] instead -- every sample is
+// converted once (the radix-R0 pre-stage above re-reads and re-converts the whole block for
+// each k0), each pruned transform yields F_r[k], k < 128, and k_select_dit finishes
+// X[k] = sum_r W_NL^(r k) F_r[k] for the ~110 window bins.  sum |X|^2 = NL * sum |x|^2.
+template <int FMT, int R0>
+struct RawDecim;
+template <int R0>
+struct RawDecim<THR_IN_U8, R0> {
+    // Sample R0*m + r is 2 bytes at byte 2*R0*m + 2r, so ONE aligned 4*R0-byte load per n1
+    // covers m = 2t, 2t+1 for every r: the block is fetched once (16 x uint4 = 64 VGPRs for
+    // R0 = 4) and each of the R0 decimated transforms picks its two samples out of it.
+    static_assert(R0 == 2 || R0 == 4, "radix");
+    typedef unsigned word_t __attribute__((ext_vector_type(R0)));
+    word_t w[R1];
+    unsigned q[R1];   // the selected pair: sample 2t in the low half, 2t+1 in the high half
+    __device__ __forceinline__ void fetch(const void* __restrict__ blk, int t) {
+        const word_t* p = reinterpret_cast<const word_t*>(blk) + t;
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) w[n1] = p[n1 * (S1 / 2)];
+    }
+    __device__ __forceinline__ void select(int r) {
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) {
+            unsigned lo, hi;
+            if constexpr (R0 == 4) {
+                lo = (r & 2) ? w[n1].y : w[n1].x;
+                hi = (r & 2) ? w[n1].w : w[n1].z;
+            } else {
+                lo = w[n1].x;
+                hi = w[n1].y;
+            }
+            q[n1] = (r & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
+        }
+    }
+    __device__ __forceinline__ void get(int n1, cpx& a, cpx& b) const {
+        const unsigned v = q[n1];
+        constexpr float sc = 1.0f / 128.0f, of = -127.4f / 128.0f;
+        a = cpx{fmaf(float(v & 0xffu), sc, of), fmaf(float((v >> 8) & 0xffu), sc, of)};
+        b = cpx{fmaf(float((v >> 16) & 0xffu), sc, of), fmaf(float(v >> 24), sc, of)};
+    }
+};
+template <int R0>
+struct RawDecim<THR_IN_C64, R0> {
+    const cpx* base;
+    const cpx* p;
+    __device__ __forceinline__ void fetch(const void* __restrict__ blk, int t) {
+        base = reinterpret_cast<const cpx*>(blk) + size_t(2 * t) * R0;
+    }
+    __device__ __forceinline__ void select(int r) { p = base + r; }
+    __device__ __forceinline__ void get(int n1, cpx& a, cpx& b) const {
+        a = p[size_t(n1) * S1 * R0];
+        b = p[size_t(n1) * S1 * R0 + R0];
+        __builtin_amdgcn_sched_barrier(0);  // see RawLong: keep the loads from being hoisted en bloc
+    }
+};
+
+template <int FMT, int R0>
+__global__ __launch_bounds__(NT) void k_carrier_dit(const void* __restrict__ samples, int n_blocks,
+                                                    DevCfg cfg, const cpx* __restrict__ tables,
+                                                    cpx* __restrict__ win_f,      // [b][R0][win_w]
+                                                    float* __restrict__ partial)  // [b][R0][2]
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cpx* lds = reinterpret_cast<cpx*>(smem_raw);
+    unsigned char* sc_red = reinterpret_cast<unsigned char*>(lds + OFF_S);
+    load_tables(lds, tables);
+    __syncthreads();
+    const size_t blk_bytes = cfg.blk_stride;
+    const int win_w = cfg.win_count + 6, win_base = cfg.win_lo - 3;
+    int parity = 0;
+    for (int b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+      RawDecim<FMT, R0> raw;
+      raw.fetch(static_cast<const unsigned char*>(samples) + size_t(b) * blk_bytes, opaque_tid());
+#pragma nounroll
+      for (int r = 0; r < R0; ++r) {
+        const int t = opaque_tid();
+        raw.select(r);
+        float sums[1];
+        // (the previous item's pass-3 LDS reads precede its reduction barrier)
+        fwd_pass1<false>(lds, raw, nullptr, cpx{}, cpx{}, &sums[0]);
+        __syncthreads();
+        fwd_pass2<8>(lds);
+        __builtin_amdgcn_sched_barrier(0);
+        const int k2 = t & 31;
+        if (k2 < 8) {
+            const f4* src = reinterpret_cast<const f4*>(lds + (t >> 5) * ROW + k2 * CHUNK);
+            f4 acc = src[0];
+#pragma unroll
+            for (int j = 1; j < R3 / 2; ++j) acc += src[j];
+            const int k = (t >> 5) + 16 * k2;
+            const unsigned wi = unsigned(k - win_base);
+            if (wi < unsigned(win_w))
+                win_f[(size_t(b) * R0 + r) * win_w + wi] = cpx{acc.x + acc.z, acc.y + acc.w};
+        }
+        double tot[1];
+        unsigned long long dummy = 0;
+        block_reduce<1, NT / 64>(sums, tot, dummy, sc_red, parity);
+        parity ^= 1;
+        if (t == 0) {
+            partial[(size_t(b) * R0 + r) * 2 + 0] = (float)(tot[0] * double(R0 * M));  // Parseval
+            partial[(size_t(b) * R0 + r) * 2 + 1] = 0.f;
+        }
+      }
+    }
+}
+
+// combine the decimated transforms on the window bins, then select as k_select does
+__global__ __launch_bounds__(128) void k_select_dit(int r0, DevCfg cfg, const cpx* __restrict__ win_f,
+                                                    const cpx* __restrict__ twn,
+                                                    const float* __restrict__ partial,
+                                                    CarStats* __restrict__ stats) {
+    __shared__ float pw[128];
+    __shared__ unsigned long long sh[2];
+    const int b = blockIdx.x, nl = cfg.block_len;
+    const int win_w = cfg.win_count + 6, win_base = cfg.win_lo - 3;
+    const int i = threadIdx.x;
+    unsigned long long best = 0;
+    if (i < win_w) {
+        const int k = win_base + i;
+        cpx x = win_f[size_t(b) * r0 * win_w + i];
+        for (int r = 1; r < r0; ++r)
+            x += cmul(win_f[(size_t(b) * r0 + r) * win_w + i], twn[(r * k) & (nl - 1)]);
+        const float p = cnorm(x);
+        pw[i] = p;
+        const int wi = i - 3;
+        if (wi >= 0 && wi < cfg.win_count)
+            best = ((unsigned long long)__float_as_uint(p) << 32) | (0xFFFFFFFFu - unsigned(wi));
+    }
+    best = wave_max(best);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        best = sh[1] > sh[0] ? sh[1] : sh[0];
+        const int wi = int(0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu));
+        CarStats st;
+        float s2 = 0.f;
+        for (int r = 0; r < r0; ++r) s2 += partial[(size_t(b) * r0 + r) * 2 + 0];
+        st.sum_mag2 = s2;
+        st.sum_mag = 0.f;
+        st.peak_mag = sqrtf(__uint_as_float(unsigned(best >> 32)));
+        st.peak_idx = wi + cfg.win_lo;   // < 128: the reference's wrap quirk cannot trigger
+        for (int d = 0; d < 7; ++d) st.nb[d] = sqrtf(pw[wi + d]);
+        st.pad = 0;
+        stats[b] = st;
+    }
+}
+
 // window first-max + neighbourhood + totals, one workgroup per block
 __global__ __launch_bounds__(256) void k_select(int r0, DevCfg cfg, const float* __restrict__ win_pow,
                                                 const float* __restrict__ partial,
@@ -422,6 +637,10 @@ hipError_t prepare_r0() {
         reinterpret_cast<const void*>(&k_carrier_sub<THR_IN_C64, R0, true, false>),
         reinterpret_cast<const void*>(&k_carrier_sub<THR_IN_C64, R0, false, true>),
         reinterpret_cast<const void*>(&k_carrier_sub<THR_IN_C64, R0, true, true>),
+        reinterpret_cast<const void*>(&k_carrier_dit<THR_IN_U8, R0>),
+        reinterpret_cast<const void*>(&k_carrier_dit<THR_IN_C64, R0>),
+        reinterpret_cast<const void*>(&k_carrier_sub_pruned<THR_IN_U8, R0>),
+        reinterpret_cast<const void*>(&k_carrier_sub_pruned<THR_IN_C64, R0>),
         reinterpret_cast<const void*>(&k_correlate_sub<THR_IN_U8, R0, false>),
         reinterpret_cast<const void*>(&k_correlate_sub<THR_IN_U8, R0, true>),
         reinterpret_cast<const void*>(&k_correlate_sub<THR_IN_C64, R0, false>),
@@ -439,6 +658,27 @@ hipError_t carrier_r0(int fmt, const void* samples, int n_blocks, const DevCfg& 
                       CarStats* stats, float2* dump_fft, int grid, hipStream_t stream) {
     typedef void (*fn_t)(const void*, int, DevCfg, const cpx*, const cpx*, float*, float*, cpx*);
     const bool st = cfg.car_want_std != 0, dump = dump_fft != nullptr;
+    if (cfg.car_prune == 1 && !st && !dump && cfg.win_lo + cfg.win_count + 3 <= 128) {
+        typedef void (*dfn_t)(const void*, int, DevCfg, const cpx*, cpx*, float*);
+        dfn_t dfn = fmt == THR_IN_U8 ? &k_carrier_dit<THR_IN_U8, R0> : &k_carrier_dit<THR_IN_C64, R0>;
+        hipLaunchKernelGGL(dfn, dim3(grid), dim3(NT), LDS_BYTES, stream, samples, n_blocks, cfg,
+                           reinterpret_cast<const cpx*>(tables), reinterpret_cast<cpx*>(win_pow), partial);
+        hipLaunchKernelGGL(k_select_dit, dim3(n_blocks), dim3(128), 0, stream, R0, cfg,
+                           reinterpret_cast<const cpx*>(win_pow), reinterpret_cast<const cpx*>(twn),
+                           partial, stats);
+        return hipGetLastError();
+    }
+    if (cfg.car_prune == 1 && !st && !dump) {
+        typedef void (*pfn_t)(const void*, int, DevCfg, const cpx*, const cpx*, float*, float*);
+        pfn_t pfn = fmt == THR_IN_U8 ? &k_carrier_sub_pruned<THR_IN_U8, R0>
+                                     : &k_carrier_sub_pruned<THR_IN_C64, R0>;
+        hipLaunchKernelGGL(pfn, dim3(grid), dim3(NT), LDS_BYTES, stream, samples, n_blocks, cfg,
+                           reinterpret_cast<const cpx*>(tables), reinterpret_cast<const cpx*>(twn),
+                           win_pow, partial);
+        hipLaunchKernelGGL(k_select, dim3(n_blocks), dim3(256), 0, stream, R0, cfg, win_pow, partial,
+                           stats);
+        return hipGetLastError();
+    }
     fn_t fn;
     if (fmt == THR_IN_U8)
         fn = st ? (dump ? &k_carrier_sub<THR_IN_U8, R0, true, true> : &k_carrier_sub<THR_IN_U8, R0, true, false>)
