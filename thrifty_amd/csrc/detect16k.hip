@@ -576,8 +576,15 @@ __global__ __launch_bounds__(NT) void k_correlate(
                 });
             }
         }
+        // THR_MULTI_PARK (dev A/B): park the shifted spectrum in a per-workgroup global scratch
+        // row between templates instead of keeping its 64 VGPRs live (measured slower)
+#ifdef THR_MULTI_PARK
+        constexpr bool PARK = MULTI;
+#else
+        constexpr bool PARK = false;
+#endif
         f4* park = nullptr;
-        if constexpr (MULTI) {
+        if constexpr (PARK) {
             park = xhat_scratch + size_t(blockIdx.x) * (N / 2) + t;
             static_for<R3 / 2>([&](auto J) {
                 constexpr int j = decltype(J)::value;
@@ -590,14 +597,14 @@ __global__ __launch_bounds__(NT) void k_correlate(
         for (int tpl = 0; tpl < n_tpl; ++tpl) {
             // ---- X * conj(T)/N in digit-reversed register order
             const int t = opaque_tid();  // re-derive per template: keeps LICM off the loop body
-            if constexpr (MULTI) park = xhat_scratch + size_t(blockIdx.x) * (N / 2) + t;
+            if constexpr (PARK) park = xhat_scratch + size_t(blockIdx.x) * (N / 2) + t;
             const f4* ts = tspec + size_t(tpl) * (N / 2) + t;
             cpx z[R3];
             static_for<R3 / 2>([&](auto J) {
                 constexpr int j = decltype(J)::value;
                 const f4 q = ts[j * NT];
                 cpx x0, x1;
-                if constexpr (MULTI) {
+                if constexpr (PARK) {
                     const f4 xx = park[j * NT];  // own writes: program order suffices
                     x0 = cpx{xx.x, xx.y};
                     x1 = cpx{xx.z, xx.w};
