@@ -57,10 +57,12 @@ def parse_args():
     return ap.parse_args()
 
 
-def synth_on_device(torch, dev, gen, n_blocks, template, window, signal_frac, chunk=2048):
+def synth_on_device(torch, dev, gen, n_blocks, template, window, signal_frac, chunk=2048,
+                    truth=None):
     """SURVEY.md 8(d) generator, on the GPU: OOK burst 0.3*(t+1)/2 at a uniform lag in
     the unique window, carrier bin ~ U(10,100), AWGN sigma 0.02, u8 quantiser
-    (x*128 + 127.4, truncating).  Returns uint8 [n_blocks, 2N]."""
+    (x*128 + 127.4, truncating).  Returns uint8 [n_blocks, 2N]; if `truth` is a dict it
+    receives the drawn lag / carrier bin / has-signal tensors (tests/test_gpu_fullsize.py)."""
     n, w = N_BLOCK, len(template)
     lo, hi = window
     out = torch.empty((n_blocks, 2 * n), dtype=torch.uint8, device=dev)
@@ -80,6 +82,10 @@ def synth_on_device(torch, dev, gen, n_blocks, template, window, signal_frac, ch
         x[rows, idx, 1] += amp * torch.sin(ph).to(torch.float32)
         q = (x * 128.0 + 127.4).clamp_(0, 255).to(torch.uint8)
         out[s:s + b] = q.view(b, 2 * n)
+        if truth is not None:
+            truth.setdefault("pos", []).append(pos)
+            truth.setdefault("car", []).append(car)
+            truth.setdefault("has", []).append(has)
         del x, q
     return out
 
