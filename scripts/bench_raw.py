@@ -27,3 +27,19 @@ for name, mk in (("host framing (block_reader)", lambda: block_data.block_reader
     dt = time.perf_counter() - t0
     print("%-30s %8.0f blocks/s (%d detections, %.1f MB stream, %.1f MS/s)" % (
         name, nb / dt, cnt, len(raw) / 1e6, nb * new / dt / 1e6))
+
+# sparse stream (a burst in every 10th block), detections only -- what `thrifty detect --raw --quiet` does
+x2 = (rng.normal(0, 0.02, new * 640) + 1j * rng.normal(0, 0.02, new * 640))
+for j in range(64):
+    s = 10 * j * new + 3000 + 97 * j
+    k = np.arange(len(tpl))
+    x2[s:s + len(tpl)] += ook * np.exp(2j * np.pi * (20 + j) * (k + s) / n)
+nb2 = 640 * 32
+raw2 = np.tile(synth.quantise_iq(x2), nb2 // 640).tobytes()
+det = Detector(st, block_data.RawStream(io.BytesIO(raw2), n, h), batch_size=2048)
+det.only_detections = True
+t0 = time.perf_counter()
+cnt = sum(1 for d, r in det if d)
+dt = time.perf_counter() - t0
+print("%-30s %8.0f blocks/s (%d detections, %.1f MB stream, %.1f MS/s)" % (
+    "sparse, detections only", nb2 / dt, cnt, len(raw2) / 1e6, nb2 * new / dt / 1e6))

@@ -104,6 +104,28 @@ def test_detector_cli_end_to_end(golden, tmp_path, capsys):
     assert len(summary) == len(g["blocks"]) and summary[0].startswith("blk=5; carrier: yes")
 
 
+def test_quiet_cli_and_detections_only_iteration(golden, tmp_path, capsys):
+    """--quiet skips the per-block objects of undetected blocks: same .toad, no summary."""
+    g = golden("c2")
+    np.save(tmp_path / "template.npy", g["template"])
+    (tmp_path / "detector.cfg").write_text(
+        "rxid: 0\nsample_rate: 2.4M\nblock_size: 16384\nblock_history: 4096\n"
+        "carrier_window: 7 - 110\ncarrier_threshold: 15 * snr\ncorr_threshold: 15*snr\n"
+        "template: %s\n" % (tmp_path / "template.npy"))
+    (tmp_path / "rx.card").write_text(card_text(g))
+    detector_cli(Detector, argv=[str(tmp_path / "rx.card"), "-o", str(tmp_path / "rx.toad"), "--quiet",
+                                 "-c", str(tmp_path / "detector.cfg")])
+    assert_toad_close((tmp_path / "rx.toad").read_text().strip().split("\n"), g["toad"])
+    assert capsys.readouterr().out.strip() == ""
+    # library use: batches without any detection contribute nothing and do not end the iteration
+    st = DetectorSettings(16384, 4096, len(g["template"]), (0, 15, 0), (7, 110), g["template"], (0, 15, 0))
+    det = Detector(st, block_data.CardStream(io.BytesIO(card_text(g).encode()), 16384), rxid=0, batch_size=2)
+    det.only_detections = True
+    got = list(det)
+    assert all(d for d, _ in got) and len(got) == int(g["det"].sum())
+    assert [r.block for _, r in got] == [int(b) for b, d in zip(g["block_idx"], g["det"]) if d]
+
+
 def test_multi_template_detector(golden):
     gs = [golden("c5_tx%d" % i) for i in range(4)]
     tpls = np.stack([g["template"] for g in gs])

@@ -226,10 +226,14 @@ class RawStream(object):
         self._consumed = 0      # bytes of the previous u8 batch still to be slid out
         self._eof = False
 
-    def _read_upto(self, want_end):
+    def _read_upto(self, want_end, need_end=None):
+        """Read until `need_end` valid bytes are buffered (default: want_end) or EOF, never
+        asking for more than `want_end`: on a live pipe a batch is whatever has arrived, as
+        long as it holds at least one block."""
+        need_end = want_end if need_end is None else need_end
         if len(self._buf) < want_end:
             self._buf.extend(bytes(want_end - len(self._buf)))
-        while self._have < want_end and not self._eof:
+        while self._have < need_end and not self._eof:
             view = memoryview(self._buf)[self._have:want_end]
             if hasattr(self.stream, "readinto"):
                 got = self.stream.readinto(view) or 0
@@ -272,7 +276,7 @@ class RawStream(object):
             if not blocks:
                 return None
             return "c64", [time.time()] * len(blocks), np.asarray(idxs, dtype=np.int64), np.stack(blocks)
-        self._read_upto(carry + max_blocks * step)
+        self._read_upto(carry + max_blocks * step, need_end=carry + step)
         n = (self._have - carry) // step
         if n <= 0:
             return None

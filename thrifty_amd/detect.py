@@ -47,7 +47,7 @@ class Detector(object):
     _fit_reach = 3            # the carrier interpolator reads fft_mag[peak + 3] (carrier_sync.py:187)
     _offset_type = float      # CarrierSyncInfo.offset as the reference types it
 
-    def __init__(self, settings, blocks=None, rxid=-1, yield_data=False, batch_size=256,
+    def __init__(self, settings, blocks=None, rxid=-1, yield_data=False, batch_size=1024,
                  device_id=0, _preshift_num=0):
         self.settings = settings
         # a CardStream is consumed in whole batches with the base64 payloads decoded on the GPU
@@ -69,6 +69,9 @@ class Detector(object):
             device_id=device_id, max_batch=self.batch_size, preshift_num=_preshift_num)
         self._ready = deque()
         self._exhausted = False
+        # batch readers only (CardStream / RawStream): hand out detections only, skipping the
+        # per-block Python objects of everything else (set by detector_cli under --quiet)
+        self.only_detections = False
         corr_len = settings.block_len - len(template) + 1
         # descriptive twins of the reference's sub-objects (read-only facts)
         self.sync = SimpleNamespace(thresh_coeffs=settings.carrier_thresh,
@@ -171,7 +174,7 @@ class Detector(object):
                 return
             stamps, idxs, text, offs = batch
             recs = self._engine.detect_card(text, offs, idxs)[:, 0]
-            self._ready.extend(self._results(stamps, idxs, recs))
+            self._emit(stamps, idxs, recs)
             return
         if self._raw is not None:
             batch = self._raw.next_batch(self.batch_size)
@@ -183,7 +186,7 @@ class Detector(object):
                 recs = self._engine.detect_stream(data, int(idxs[0]))[:, 0]
             else:   # lead-in blocks that still contain the all-zero initial history
                 recs = self._engine.detect(data, idxs)[:, 0]
-            self._ready.extend(self._results(stamps, idxs, recs))
+            self._emit(stamps, idxs, recs)
             return
         items = []
         while len(items) < self.batch_size and not self._exhausted:
@@ -196,12 +199,19 @@ class Detector(object):
         else:
             self._ready.extend(self.detect_batch(items))
 
+    def _emit(self, stamps, idxs, recs):
+        if self.only_detections:
+            keep = np.flatnonzero(recs["flags"] & (_native.FLAG_CORR | _native.FLAG_INDEX_ERROR))
+            if len(keep) != len(recs):
+                stamps, idxs, recs = [stamps[i] for i in keep], idxs[keep], recs[keep]
+        self._ready.extend(self._results(stamps, idxs, recs))
+
     def next(self):
         """Result for the next block of the `blocks` iterator."""
-        if not self._ready:
-            if self.blocks is None:
-                raise TypeError("Detector was constructed without a block source")
-            self._refill()
+        if self.blocks is None and not self._ready:
+            raise TypeError("Detector was constructed without a block source")
+        while not self._ready and not self._exhausted:
+            self._refill()      # (a batch may contribute nothing under only_detections)
         if not self._ready:
             raise StopIteration
         return self._ready.popleft()
@@ -367,6 +377,8 @@ def detector_cli(detector_class, parser=None, extra_args=None, argv=None):
                                 carrier_window=window, template=template,
                                 corr_thresh=config.corr_threshold)
     detections = detector_class(settings, blocks, rxid=config.rxid, **kwargs)
+    if args.quiet and hasattr(detections, "only_detections"):
+        detections.only_detections = True   # nothing is printed for the other blocks anyway
     summary = SummaryLineFormatter(config.sample_rate, config.block_size, add_dt=True)
     for detected, result in detections:
         if detected and output_file is not None:
