@@ -215,6 +215,32 @@ int thr_debug_stage(thr_handle* h, const void* samples, int format, size_t n_blo
                     int template_id, float* shifted_fft_out /* [n][block_len][2] */,
                     float* corr_out /* [n][block_len][2] */);
 
+/*
+ * identify: merge-side post-processing of detections (thrifty/identify.py:26-181) --
+ * transmitter classification from the carrier bin, the duplicate filter, output order.
+ * Columns in, columns out (host pointers, synchronous, handle-free; `device_id` picks
+ * the GPU that sorts).  `map` / `n_map`: the frequency map of load_freqmap
+ * (identify.py:184-215) flattened in its iteration order -- inclusive ranges on
+ * carrier_bin + carrier_offset, the LAST matching entry wins, -1 if none
+ * (classify_transmitters, identify.py:109-121); n_map == 0 selects the automatic mode
+ * (detect_transmitter_windows + np.digitize, identify.py:26-106).
+ * Outputs: txid_out[n]; keep_out[n] = the mask of identify_duplicates (identify.py:140-172,
+ * including its quirks: the neighbour test ignores rxid/txid and wraps around the sorted
+ * ends); kept_order_out[0 .. *n_kept_out) = indices of the kept detections sorted by
+ * timestamp, stable (filter_duplicates, identify.py:175-181).
+ */
+typedef struct thr_freq_range {
+    int32_t rxid;
+    int32_t txid;
+    double lo;
+    double hi;
+} thr_freq_range;
+
+int thr_identify(int device_id, size_t n, const int32_t* rxid, const int32_t* block,
+                 const double* timestamp, const int32_t* carrier_bin, const double* carrier_offset,
+                 const double* energy, const thr_freq_range* map, size_t n_map, int32_t* txid_out,
+                 uint8_t* keep_out, int64_t* kept_order_out, size_t* n_kept_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -357,6 +357,77 @@ class OraclePreshiftDetector(object):
 
 
 # --------------------------------------------------------------------------
+# 8(f) rank 3: identify -- TX classification + duplicate filter   (identify.py)
+# --------------------------------------------------------------------------
+def transmitter_windows(freqs):
+    """Window edges from the histogram of carrier bins (identify.py:26-77): a window opens
+    where the count exceeds 1.25 std and closes where it drops below 0.4 std; edges are the
+    mid-points between consecutive windows, framed by the first bin and last bin + 1."""
+    freqs = np.asarray(freqs)
+    first_bin = np.min(freqs)
+    cnts = np.bincount(freqs - first_bin)
+    last_bin = first_bin + len(cnts)
+    low, high = np.std(cnts) * 0.4, np.std(cnts) * 1.25
+    peaks, below, start = [], True, None
+    for i, cnt in enumerate(cnts):
+        if not below and cnt < low:
+            peaks.append((start, i))
+            start, below = None, True
+        if below and cnt > high:
+            start, below = i, False
+    if not below:
+        peaks.append((start, len(cnts) - 1))
+    mids = [(peaks[i][1] + peaks[i + 1][0]) // 2 for i in range(len(peaks) - 1)]
+    return np.concatenate([[first_bin], np.array(mids) + first_bin, [last_bin]])
+
+
+def auto_classify(rxid, carrier_bin):
+    """txid per detection = index of its RX's window (identify.py:80-106)."""
+    rxid, carrier_bin = np.asarray(rxid), np.asarray(carrier_bin)
+    txid = np.zeros(len(rxid), dtype=np.int64)
+    edges = {}
+    for rx in np.unique(rxid):
+        sel = rxid == rx
+        edges[int(rx)] = transmitter_windows(carrier_bin[sel])
+        txid[sel] = np.digitize(carrier_bin[sel], edges[int(rx)][:-1]) - 1
+    return txid, edges
+
+
+def classify_by_map(rxid, carrier_bin, carrier_offset, freqmap):
+    """freqmap: {rxid: {txid: (lo, hi)}} in insertion order; inclusive ranges on
+    bin + offset, the LAST matching range wins, -1 if none (identify.py:109-121)."""
+    txid = np.full(len(rxid), -1, dtype=np.int64)
+    for i in range(len(rxid)):
+        freq = carrier_bin[i] + carrier_offset[i]
+        for tx, (lo, hi) in freqmap[int(rxid[i])].items():
+            if lo <= freq <= hi:
+                txid[i] = tx
+    return txid
+
+
+def duplicate_mask(rxid, txid, block, timestamp, energy):
+    """True = keep (identify.py:140-172): sort by (rxid, txid, block, timestamp); drop a
+    detection whose sorted neighbour sits in the adjacent block with more energy (the
+    neighbour test does not look at rxid/txid and wraps around the ends, like np.roll), and
+    every unidentified (-1) one."""
+    order = np.lexsort((timestamp, block, txid, rxid))
+    blk, en, tx = np.asarray(block)[order], np.asarray(energy)[order], np.asarray(txid)[order]
+    pb, pe = np.roll(blk, 1), np.roll(en, 1)
+    nb, ne = np.roll(blk, -1), np.roll(en, -1)
+    drop = ((blk == pb + 1) & (en < pe)) | ((blk == nb - 1) & (en < ne)) | (tx == -1)
+    mask = np.empty(len(order), dtype=bool)
+    mask[order] = ~drop
+    return mask
+
+
+def filter_order(mask, timestamp):
+    """Indices of the kept detections in output order: by timestamp, stable
+    (identify.py:175-181)."""
+    kept = np.flatnonzero(mask)
+    return kept[np.argsort(np.asarray(timestamp)[kept], kind="stable")]
+
+
+# --------------------------------------------------------------------------
 # a16: .toad line                                      (toads_data.py:47-61)
 # --------------------------------------------------------------------------
 def toad_line(rxid, timestamp, block_idx, res):

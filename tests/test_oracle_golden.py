@@ -200,3 +200,28 @@ def test_preshift_oracle_matches_reference_records(golden, name):
         if res.detected:
             lines.append(onp.toad_line(int(g["rxid"]), 1000.0 + i, int(g["block_idx"][i]), res))
     assert "\n".join(lines) == str(g["toad"])          # byte for byte what the reference prints
+
+
+# ---- identify: fixtures from the reference's identify.py
+# ---- (tests/golden/make_golden_identify.py)
+def freqmap_of(g):
+    fm = {}
+    for rx, tx, lo, hi in zip(g["map_rx"], g["map_tx"], g["map_lo"], g["map_hi"]):
+        fm.setdefault(int(rx), {})[int(tx)] = (float(lo), float(hi))
+    return fm
+
+
+@pytest.mark.parametrize("name", ["identify_auto3", "identify_auto1", "identify_map"])
+def test_identify_oracle_matches_reference(golden, name):
+    g = golden(name)
+    if "edges" in g.files:
+        txid, edges = onp.auto_classify(g["rxid"], g["carrier_bin"])
+        for j, rx in enumerate(g["edge_rx"]):
+            want = g["edges"][g["edge_ptr"][j]:g["edge_ptr"][j + 1]]
+            assert np.array_equal(np.asarray(edges[int(rx)], dtype=np.int64), want)
+    else:
+        txid = onp.classify_by_map(g["rxid"], g["carrier_bin"], g["carrier_offset"], freqmap_of(g))
+    assert np.array_equal(txid, g["txid"])
+    mask = onp.duplicate_mask(g["rxid"], txid, g["block"], g["timestamp"], g["energy"])
+    assert np.array_equal(mask, g["dup_mask"])
+    assert np.array_equal(onp.filter_order(mask, g["timestamp"]), g["kept_order"])

@@ -24,7 +24,7 @@ EXPORTS = [
     "thr_abi_version", "thr_last_error", "thr_create", "thr_destroy", "thr_detect",
     "thr_create_preshift", "thr_detect_card", "thr_detect_stream", "thr_detect_stream_device", "thr_detect_device", "thr_sync", "thr_set_stream", "thr_compact_device",
     "thr_profile_enable", "thr_profile_read", "thr_kernel_name", "thr_debug_fft",
-    "thr_debug_stage",
+    "thr_debug_stage", "thr_identify",
 ]
 
 
@@ -117,6 +117,8 @@ def load_library():
     lib.thr_profile_read.argtypes = [vp, C.POINTER(C.c_double), i64p]
     lib.thr_debug_fft.argtypes = [vp, vp, C.c_int, C.c_size_t, vp]
     lib.thr_debug_stage.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_int, vp, vp]
+    lib.thr_identify.argtypes = [C.c_int, C.c_size_t, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp, vp,
+                                 vp, C.POINTER(C.c_size_t)]
     _lib = lib
     return lib
 
@@ -124,6 +126,36 @@ def load_library():
 def _check(lib, rc):
     if rc != 0:
         raise NativeError("libthriftyhip: %s (code %d)" % (lib.thr_last_error().decode(), rc))
+
+
+FREQ_RANGE_DTYPE = np.dtype([("rxid", "<i4"), ("txid", "<i4"), ("lo", "<f8"), ("hi", "<f8")])
+
+
+def identify(rxid, block, timestamp, carrier_bin, carrier_offset, energy, freq_ranges=None,
+             device_id=0):
+    """thr_identify on columns -> (txid int32[n], keep bool[n], kept_order int64[k]).
+    freq_ranges: None (automatic windows) or rows (rxid, txid, lo, hi) in map order."""
+    lib = load_library()
+    n = len(rxid)
+    cols = [np.ascontiguousarray(rxid, dtype=np.int32), np.ascontiguousarray(block, dtype=np.int32),
+            np.ascontiguousarray(timestamp, dtype=np.float64),
+            np.ascontiguousarray(carrier_bin, dtype=np.int32),
+            np.ascontiguousarray(carrier_offset, dtype=np.float64),
+            np.ascontiguousarray(energy, dtype=np.float64)]
+    assert all(len(c) == n for c in cols)
+    fmap = (np.zeros(0, dtype=FREQ_RANGE_DTYPE) if freq_ranges is None
+            else np.ascontiguousarray(np.asarray(freq_ranges, dtype=FREQ_RANGE_DTYPE)))
+    if freq_ranges is not None and len(fmap) == 0:
+        raise ValueError("empty frequency map")
+    txid = np.zeros(n, dtype=np.int32)
+    keep = np.zeros(n, dtype=np.uint8)
+    order = np.zeros(n, dtype=np.int64)
+    n_kept = C.c_size_t(0)
+    _check(lib, lib.thr_identify(int(device_id), n, *[c.ctypes.data for c in cols],
+                                 fmap.ctypes.data if len(fmap) else None, len(fmap),
+                                 txid.ctypes.data, keep.ctypes.data, order.ctypes.data,
+                                 C.byref(n_kept)))
+    return txid, keep.astype(bool), order[:n_kept.value]
 
 
 class Engine(object):

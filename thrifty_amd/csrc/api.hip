@@ -27,6 +27,23 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+}  // namespace
+
+namespace thr {
+// error reporting for the other translation units of the library (identify.hip)
+int fail_msg(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+}  // namespace thr
+
+namespace {
+
 #define HIP_TRY(expr)                                                                  \
     do {                                                                               \
         hipError_t _e = (expr);                                                        \
