@@ -43,9 +43,9 @@ def parse_args():
     ap.add_argument("--mix", choices=["dense", "sparse"], default="dense",
                     help="dense: every block carries a signal; sparse: 10%% do")
     ap.add_argument("--templates", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=1,
+    ap.add_argument("--streams", type=int, default=2,
                     help="engine handles (each with its own HIP stream) the steps alternate over")
-    ap.add_argument("--profile-kernels", type=int, default=8,
+    ap.add_argument("--profile-kernels", type=int, default=16,
                     help="n > 0: HIP events around the kernels of every n-th step of the timed "
                          "region (roofline leg; 1 = every step, costs ~4%%); 0 = off")
     ap.add_argument("--variant", choices=["default", "preshift"], default="default",
@@ -194,12 +194,26 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    # Steps alternate over the engine handles (double buffering: the latency-bound k_fit and
+    # the launch gaps of one batch hide under the other batch's kernels).  Kernel durations
+    # measured while two batches overlap would be inflated by the sharing, so with more than
+    # one handle the roofline leg times SOLO steps: every `profile_kernels`-th step of the
+    # timed region runs with the other handle drained (costs the overlap of that step).
+    solo = len(engs) > 1 and args.profile_kernels > 0
     for e in engs:
-        e.profile_enable(args.profile_kernels)
+        e.profile_enable(0 if solo else args.profile_kernels)
         e.profile_read()  # reset accumulators
     t0 = time.perf_counter()
     for i in range(K):
-        step(i)
+        if solo and i % args.profile_kernels == 0:
+            sync_engines()
+            e = engs[i % len(engs)]
+            e.profile_enable(1)
+            step(i)
+            e.sync()
+            e.profile_enable(0)
+        else:
+            step(i)
     if len(engs) > 1:
         sync_engines()
     # K7 + C1: compact detected records, gather them to rank 0 (the only collective)
@@ -253,6 +267,7 @@ def main():
                        "blocks_per_step_per_gpu": B, "templates": T,
                        "carrier_window": [7, 110], "thresholds": "15*snr",
                        "parallelism": "block-shard x%d" % world,
+                       "handles_per_gpu": len(engs),
                        "detections_gathered": int(gathered.shape[0])},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -594,6 +594,7 @@ static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out
             hipMemset(d.timeline, 0, 128 * sizeof(unsigned long long));
 #endif
         d.stagger = getenv("THR_STAGGER") ? atoi(getenv("THR_STAGGER")) : 1;
+        d.dyn_sched = getenv("THR_DYN") ? atoi(getenv("THR_DYN")) : 1;
         d.prio_mode = getenv("THR_PRIO") ? atoi(getenv("THR_PRIO")) : 0;
         d.ablate = getenv("THR_ABLATE") ? atoi(getenv("THR_ABLATE")) : 0;
         d.car_want_std = s->carrier_thresh[2] != 0.0;
@@ -651,8 +652,8 @@ static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out
         CREATE_TRY(hipMalloc(&h->d_shifts, mb * sizeof(thr::ShiftParams)));
         CREATE_TRY(hipMalloc(&h->d_corr_stats, mb * s->n_templates * sizeof(thr::CorrStats)));
         CREATE_TRY(hipMalloc(&h->d_work_list, mb * sizeof(int)));
-        CREATE_TRY(hipMalloc(&h->d_work_count, sizeof(int)));
-        CREATE_TRY(hipMemset(h->d_work_count, 0, sizeof(int)));  // re-armed by k_finish
+        CREATE_TRY(hipMalloc(&h->d_work_count, 4 * sizeof(int)));  // [0] work count, [1] dynamic cursor
+        CREATE_TRY(hipMemset(h->d_work_count, 0, 4 * sizeof(int)));  // re-armed by k_finish
         CREATE_TRY(hipMalloc(&h->d_ncompact, sizeof(int)));
         if (h->fast && s->n_templates > 1)
             CREATE_TRY(hipMalloc(&h->d_xhat_scratch, size_t(h->n_cu) * n * sizeof(float2)));

@@ -268,6 +268,66 @@ __device__ __forceinline__ void dirichlet_eval(double u, double n, double w, dou
     dd = (pi * w / n * cw * s1 - sw * pi / n * c1) / (w * s1 * s1);
 }
 
+// The fit evaluates D at u = x_j - o with x_j = j - 3 fixed per lane and only the offset o
+// moving, so the two sincospi calls per evaluation (~150 dependent fp64 instructions each,
+// and the fit is one long dependent chain: it bounds k_fit's latency) reduce to the angle
+// addition sin(a x - a o) = sin(a x) cos(a o) - cos(a x) sin(a o) with per-lane constants
+// and a short polynomial for the small angles a o (|pi w o / n| < 0.5 for any offset the
+// fit visits in practice; outside that the libm path takes over).
+struct DirichletLane {
+    double sa, ca;  // sin, cos(pi w x / n)
+    double sb, cb;  // sin, cos(pi x / n)
+};
+__device__ __forceinline__ DirichletLane dirichlet_lane(double x, double n, double w) {
+    DirichletLane c;
+    sincospi(w * x / n, &c.sa, &c.ca);
+    sincospi(x / n, &c.sb, &c.cb);
+    return c;
+}
+__device__ __forceinline__ void sincos_small(double x, double& sn, double& cs) {
+    if (fabs(x) < 0.5) {
+        // Taylor to x^17 / x^16: truncation < 2e-23 / 6e-22 on |x| < 0.5
+        const double z = x * x;
+        double ps = -1.0 / 355687428096000.0;                     // 1/17!
+        ps = fma(ps, z, 1.0 / 1307674368000.0);                   // 1/15!
+        ps = fma(ps, z, -1.0 / 6227020800.0);                     // 1/13!
+        ps = fma(ps, z, 1.0 / 39916800.0);                        // 1/11!
+        ps = fma(ps, z, -1.0 / 362880.0);                         // 1/9!
+        ps = fma(ps, z, 1.0 / 5040.0);
+        ps = fma(ps, z, -1.0 / 120.0);
+        ps = fma(ps, z, 1.0 / 6.0);
+        sn = fma(-x * z, ps, x);
+        double pc = 1.0 / 20922789888000.0;                       // 1/16!
+        pc = fma(pc, z, -1.0 / 87178291200.0);                    // 1/14!
+        pc = fma(pc, z, 1.0 / 479001600.0);                       // 1/12!
+        pc = fma(pc, z, -1.0 / 3628800.0);                        // 1/10!
+        pc = fma(pc, z, 1.0 / 40320.0);
+        pc = fma(pc, z, -1.0 / 720.0);
+        pc = fma(pc, z, 1.0 / 24.0);
+        pc = fma(pc, z, -0.5);
+        cs = fma(pc, z, 1.0);
+    } else {
+        sincos(x, &sn, &cs);
+    }
+}
+// D and dD/du at u = x - o for the lane whose constants are `c`
+__device__ __forceinline__ void dirichlet_eval_at(const DirichletLane& c, double x, double o,
+                                                  double n, double w, double& d, double& dd) {
+    if (fabs(x - o) < 1e-12) {
+        d = 1.0;
+        dd = 0.0;
+        return;
+    }
+    const double pi = 3.14159265358979323846;
+    double so, co, se, ce;
+    sincos_small(pi * w / n * o, so, co);
+    sincos_small(pi / n * o, se, ce);
+    const double sw = c.sa * co - c.ca * so, cw = c.ca * co + c.sa * so;
+    const double s1 = c.sb * ce - c.cb * se, c1 = c.cb * ce + c.sb * se;
+    d = sw / (w * s1);
+    dd = (pi * w / n * cw * s1 - sw * pi / n * c1) / (w * s1 * s1);
+}
+
 // Sum over the 8-lane group, bitwise identical in all 8 lanes, on the DPP path
 // (quad_perm xor 1, xor 2, then row_half_mirror: i <-> 7-i) -- three VALU-speed steps
 // instead of ds_bpermute round trips (the fit is a chain of ~50 dependent group sums).
@@ -300,16 +360,20 @@ __device__ inline double dirichlet_fit8(float yj, float y_peak, int j, double n,
     const double y = live ? (double)yj : 0.0;
     const double x = double(j - 3);
     double A = y_peak, o = 0.0, lambda = 1e-3;
+    const DirichletLane lane = dirichlet_lane(x, n, w);
     auto cost_of = [&](double a, double off) {
         double d, dd;
-        dirichlet_eval(x - off, n, w, d, dd);
+        dirichlet_eval_at(lane, x, off, n, w, d, dd);
         const double r = live ? y - a * fabs(d) : 0.0;
         return group8_sum(r * r);
     };
     double cost = cost_of(A, o);
-    for (int it = 0; it < 60; ++it) {
+#ifndef THR_FIT_MAXIT
+#define THR_FIT_MAXIT 60
+#endif
+    for (int it = 0; it < THR_FIT_MAXIT; ++it) {
         double d, dd;
-        dirichlet_eval(x - o, n, w, d, dd);
+        dirichlet_eval_at(lane, x, o, n, w, d, dd);
         const double fa = live ? fabs(d) : 0.0;                       // df/dA
         const double fo = live ? -A * (d < 0 ? -1.0 : 1.0) * dd : 0.0;  // df/do (u = x - o)
         const double r = live ? y - A * fa : 0.0;
@@ -424,9 +488,21 @@ __global__ __launch_bounds__(64) void k_fit(int n_blocks, DevCfg cfg,
                 if (sim < 0) sim += n;
                 sp->si_mod = int(sim);
                 sp->sf_over_n = float((s - si) / double(n));
-                const int slot = atomicAdd(work_count, 1);
-                work_list[slot] = b;
             }
+        }
+    }
+    // work-list append, one atomic per wave (8 blocks) instead of one per block: 8192
+    // same-address atomics serialise in L2 and were most of this kernel's 30 us
+    {
+        const bool push = detected && valid && j == 0;
+        const unsigned long long m = __ballot(push);
+        if (m != 0) {
+            const int lane = threadIdx.x & 63;
+            const int leader = __ffsll((long long)m) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(work_count, __popcll(m));
+            base = __shfl(base, leader, 64);
+            if (push) work_list[base + __popcll(m & ((1ull << lane) - 1ull))] = b;
         }
     }
     if (valid && j < cfg.n_templates) {
@@ -503,21 +579,33 @@ __global__ __launch_bounds__(NT) void k_correlate(
                  opaque_tid());
         shift_phasor(shifts + b_next, twn, opaque_tid(), p);
     }
-    for (int wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+    // Work distribution.  Static: workgroup g takes entries g, g + G, g + 2G, ...  Dynamic
+    // (cfg.dyn_sched): the first two entries are static (their prefetches are already in
+    // flight), every later one comes from a global counter, fetched by thread 0 two
+    // iterations ahead and handed to the workgroup through LDS across the pass-1 barrier --
+    // a CU that runs a few percent slower then simply takes fewer blocks instead of making
+    // the whole launch wait for its last one.
+    const bool dyn = cfg.dyn_sched != 0;
+    int* dyn_ctr = const_cast<int*>(work_count) + 1;
+    int* sc_dyn = reinterpret_cast<int*>(sc_red + 768);
+    int wi_nxt = int(blockIdx.x + gridDim.x);
+    for (int wi = blockIdx.x, iter = 0; wi < n_work; ++iter) {
 #ifdef THR_TIMELINE
-        const bool tl_on = blockIdx.x == 0 && wi == 3 * int(gridDim.x) && cfg.timeline != nullptr;
+        const bool tl_on = blockIdx.x == 0 && iter == 3 && cfg.timeline != nullptr;
 #endif
         THR_STAMP(0);
         const int b = b_next;
         const int t = opaque_tid();
         const ShiftParams* sp = shifts + b;
+        int wi_dyn = 0;
+        if (dyn && t == 0) wi_dyn = 2 * int(gridDim.x) + atomicAdd(dyn_ctr, 1);
         // next block's samples: issued now, consumed one iteration later
         RawSamples<FMT> nxt = cur;
-        const bool more = wi + int(gridDim.x) < n_work;
+        const bool more = wi_nxt < n_work;
         if (more) {
             b_next = b_next2;
             nxt.load(static_cast<const unsigned char*>(samples) + size_t(b_next) * blk_bytes, t);
-            if (wi + 2 * int(gridDim.x) < n_work) b_next2 = work_list[wi + 2 * gridDim.x];
+            if (!dyn && wi_nxt + int(gridDim.x) < n_work) b_next2 = work_list[wi_nxt + gridDim.x];
         }
 
         THR_STAMP(1);
@@ -532,7 +620,13 @@ __global__ __launch_bounds__(NT) void k_correlate(
         const bool early_half = cfg.stagger == 0 || threadIdx.x < NT / 2;
         if (more && early_half) shift_phasor(shifts + b_next, twn, t, p);
         THR_STAMP(3);
+        if (dyn && t == 0) *sc_dyn = wi_dyn;
         __syncthreads();
+        // (sc_dyn is rewritten only after two more barriers: every thread has read it by then)
+        const int wi_nxt2 = dyn ? *sc_dyn : wi_nxt + int(gridDim.x);
+        if (dyn && wi_nxt2 < n_work) b_next2 = work_list[wi_nxt2];
+        wi = wi_nxt;
+        wi_nxt = wi_nxt2;
         if (more && !early_half) shift_phasor(shifts + b_next, twn, t, p);
 #ifdef THR_DEV_ABLATE
         if (cfg.stagger >= 2 && threadIdx.x >= NT / 2) {
@@ -728,7 +822,10 @@ __global__ __launch_bounds__(256) void k_finish(int n_records, DevCfg cfg,
                                                 thr_record* __restrict__ records,
                                                 int* __restrict__ work_count) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) *work_count = 0;  // k_correlate is done with it: re-arm for the next batch
+    if (i == 0) {  // k_correlate is done with them: re-arm for the next batch
+        work_count[0] = 0;
+        work_count[1] = 0;  // dynamic-scheduling counter
+    }
     if (i >= n_records) return;
     thr_record* r = records + i;
     if (!(r->flags & THR_FLAG_CARRIER)) return;
