@@ -9,7 +9,7 @@ O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 export TMPDIR=/tmp
 cd $R
-BENCH="python bench.py --steps 16 --warmup 2 --batch 8192 --cpu-seconds 0 --profile-kernels 0 $*"
+BENCH="python bench.py --streams 1 --steps 16 --warmup 2 --batch 8192 --cpu-seconds 0 --profile-kernels 0 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o stats -- $BENCH > $O/bench_stats.log 2>&1
 pass() {  # name counters...
   local name=$1; shift
