@@ -111,6 +111,23 @@ int thr_create(const thr_settings* settings, thr_handle** out);
  * use the multi-pass pipeline.
  */
 int thr_create_preshift(const thr_settings* settings, int num_shifts, thr_handle** out);
+/*
+ * fastdet-compatible variant -- the algorithm of the reference's NATIVE detector
+ * (fastcard/cardet.c:7-41 + fastdet/corr_detector.cpp:88-197), which differs from the Python
+ * one: float32 power-domain verdicts `max > c + s * noise_power` for carrier and correlation
+ * (carrier_thresh / corr_thresh hold c, s in the POWER domain; the third coefficient must be
+ * 0), carrier noise (sum - 2 max)/(N - 1), correlation noise clamped at 0 and computed from
+ * the integer-truncated peak power, integer roll by -argmax against the unshifted template
+ * (no FFT#2), carrier offset = parabola on sqrt(power) and correlation offset = Gaussian on
+ * log sqrt(power), both clipped to +-0.5, window [min, max] non-wrapping (a window with
+ * min < 0 <= max is refused like cardet_normalize_window, cardet.c:44-48).  Records then hold
+ * what fastdet prints (fastdet.cpp:188-206): energies / noises are the square roots of the
+ * powers.  Same kernel structure as the preshift variant (one fused kernel at 16384).
+ * Parity status: restated from the C/C++ sources; fastdet itself needs FFTW3f, VOLK and
+ * librtlsdr and cannot be built in this environment, so this variant is NOT pinned against
+ * reference output.
+ */
+int thr_create_fastdet(const thr_settings* settings, thr_handle** out);
 /* Replaces fastcard_free() (fastcard.c:119-146). */
 void thr_destroy(thr_handle* h);
 

@@ -12,6 +12,9 @@ signal_utils.py:10-32) and against the known-answer tables of the reference's
 own unit tests (tests/test_carrier_detect.py, test_carrier_sync.py,
 test_soa_estimator.py, test_block_data.py, test_util.py).
 
+Exception: the fastdet-compatible section near the end is PARITY UNPINNED (its header says
+why); everything else is pinned as described above.
+
 Each function cites the reference file:line it follows (paths relative to the
 reference checkout).  Third-party arithmetic: ``np.fft`` (pocketfft) and
 ``scipy.optimize.curve_fit`` (MINPACK lmdif) exactly as the reference calls
@@ -425,6 +428,100 @@ def filter_order(mask, timestamp):
     (identify.py:175-181)."""
     kept = np.flatnonzero(mask)
     return kept[np.argsort(np.asarray(timestamp)[kept], kind="stable")]
+
+
+# --------------------------------------------------------------------------
+# 8(f) rank 4: fastdet-compatible mode   (fastcard/cardet.c, fastdet/corr_detector.cpp)
+#
+# PARITY UNPINNED: fastdet needs FFTW3f, VOLK, librtlsdr and argp and cannot be built in this
+# environment, and the reference has no fixtures for it.  This is a restatement of the C/C++
+# sources (float32 where they use float); summation orders of VOLK's accumulators are not
+# reproduced.  It pins the GPU variant to the restatement, not to fastdet's own output.
+# --------------------------------------------------------------------------
+FastdetResult = namedtuple("FastdetResult",
+                           "carrier detected argmax carrier_max carrier_noise carrier_offset "
+                           "peak_idx peak_offset peak_power noise_power soa")
+
+
+def fastdet_window(start, stop, n):
+    """cardet_normalize_window (cardet.c:43-70): inclusive [min, max], no wrap-around."""
+    if start < 0 <= stop:
+        raise ValueError("Carrier frequency window range not supported.")
+    if start < 0:
+        start += n
+    if stop < 0:
+        stop += n
+    if start >= n or stop >= n:
+        raise ValueError("Carrier frequency window out of range.")
+    return (stop, start) if stop < start else (start, stop)
+
+
+class OracleFastdet(object):
+    """cardet_detect (cardet.c:7-41) + CorrDetector::detect (corr_detector.cpp:125-197)."""
+
+    def __init__(self, block_len, history_len, template, carrier_thresh, carrier_window,
+                 corr_thresh):
+        self.n, self.new_len = block_len, block_len - history_len
+        template = np.asarray(template, dtype=np.float32)
+        self.tenergy = np.float32(np.sum(template.astype(np.float32) ** 2, dtype=np.float32))
+        padded = np.zeros(block_len, dtype=np.complex64)
+        padded[:len(template)] = template
+        self.tconj = np.conj(np.fft.fft(padded)).astype(np.complex64)
+        self.corr_len = block_len - len(template) + 1
+        self.window = unique_window(block_len, history_len, len(template))   # set_window, 72-86
+        self.cwin = fastdet_window(carrier_window[0], carrier_window[1], block_len)
+        self.cthr = (np.float32(carrier_thresh[0]), np.float32(carrier_thresh[1]))
+        self.xthr = (np.float32(corr_thresh[0]), np.float32(corr_thresh[1]))
+
+    @staticmethod
+    def _clip(v):
+        return -0.5 if v < -0.5 else 0.5 if v > 0.5 else v
+
+    def detect_block(self, block_idx, x):
+        f32 = np.float32
+        spec = np.fft.fft(np.asarray(x, dtype=np.complex64)).astype(np.complex64)
+        power = (spec.real.astype(f32) ** 2 + spec.imag.astype(f32) ** 2).astype(f32)
+        total = f32(np.sum(power, dtype=np.float32))
+        lo, hi = self.cwin
+        argmax = int(np.argmax(power[lo:hi + 1])) + lo
+        mx = power[argmax]
+        noise = f32(0) if total == 0 else f32((total - f32(2) * mx) / f32(self.n - 1))
+        thr = f32(self.cthr[0] + self.cthr[1] * noise)
+        if not mx > thr:
+            return FastdetResult(False, False, argmax, mx, noise, 0.0, -1, 0.0, 0.0, 0.0, None)
+        a, b, c = (math.sqrt(float(power[(argmax + d) % self.n])) for d in (-1, 0, 1))
+        coff = self._clip((c - a) / (4 * b - 2 * a - 2 * c))              # interpolate_parabolic
+        rolled = np.roll(spec, -argmax)
+        corr = (np.fft.ifft(rolled * self.tconj)[:self.corr_len]).astype(np.complex64)
+        cpow = (corr.real.astype(f32) ** 2 + corr.imag.astype(f32) ** 2).astype(f32)
+        w0, w1 = self.window
+        pk = int(np.argmax(cpow[w0:w1])) + w0
+        peak = cpow[pk]
+        signal_energy = f32(total / f32(self.n))
+        # estimate_noise(size_t peak_power, ...): the peak power arrives truncated to an integer
+        noise_power = f32((f32(signal_energy * self.tenergy) - f32(int(peak))) / f32(self.n))
+        if noise_power < 0:
+            noise_power = f32(0)
+        det = bool(peak > f32(self.xthr[0] + self.xthr[1] * noise_power))
+        off = 0.0
+        if det and 0 < pk < self.corr_len - 1:
+            la, lb, lc = (math.log(math.sqrt(float(cpow[pk + d]))) for d in (-1, 0, 1))
+            off = self._clip((lc - la) / (4 * lb - 2 * la - 2 * lc))       # interpolate_gaussian
+        soa = self.new_len * block_idx + pk + off                           # fastdet.cpp:184-185
+        return FastdetResult(True, det, argmax, mx, noise, coff, pk, off, peak, noise_power, soa)
+
+    def detect_u8(self, block_idx, raw):
+        return self.detect_block(block_idx, iq_u8_to_c64(raw))
+
+
+def fastdet_toad_line(rxid, timestamp, block_idx, r):
+    """The line fastdet prints (fastdet.cpp:188-206): fixed precisions, roots of the powers."""
+    sec = int(timestamp)
+    usec = int(round((timestamp - sec) * 1e6))
+    return "%d %d.%06d %d %.8f %u %.12f %f %f %u %f %f %f" % (
+        rxid, sec, usec, block_idx, r.soa, r.peak_idx, r.peak_offset, math.sqrt(r.peak_power),
+        math.sqrt(r.noise_power), r.argmax, r.carrier_offset, math.sqrt(r.carrier_max),
+        math.sqrt(r.carrier_noise))
 
 
 # --------------------------------------------------------------------------

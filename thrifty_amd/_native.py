@@ -22,7 +22,7 @@ N_KERNEL_SLOTS = 4
 
 EXPORTS = [
     "thr_abi_version", "thr_last_error", "thr_create", "thr_destroy", "thr_detect",
-    "thr_create_preshift", "thr_detect_card", "thr_detect_stream", "thr_detect_stream_device", "thr_detect_device", "thr_sync", "thr_set_stream", "thr_compact_device",
+    "thr_create_preshift", "thr_create_fastdet", "thr_detect_card", "thr_detect_stream", "thr_detect_stream_device", "thr_detect_device", "thr_sync", "thr_set_stream", "thr_compact_device",
     "thr_profile_enable", "thr_profile_read", "thr_kernel_name", "thr_debug_fft",
     "thr_debug_stage", "thr_identify",
 ]
@@ -102,6 +102,7 @@ def load_library():
     lib.thr_kernel_name.argtypes = [C.c_int]
     lib.thr_create.argtypes = [C.POINTER(ThrSettings), C.POINTER(vp)]
     lib.thr_create_preshift.argtypes = [C.POINTER(ThrSettings), C.c_int, C.POINTER(vp)]
+    lib.thr_create_fastdet.argtypes = [C.POINTER(ThrSettings), C.POINTER(vp)]
     lib.thr_destroy.argtypes = [vp]
     lib.thr_destroy.restype = None
     lib.thr_detect.argtypes = [vp, vp, C.c_int, vp, C.c_size_t, vp]
@@ -162,8 +163,10 @@ class Engine(object):
     """One detector handle == one (device, stream).  Not thread-safe per handle."""
 
     def __init__(self, block_len, history_len, templates, carrier_thresh, carrier_window,
-                 corr_thresh, carrier_len=0, device_id=0, max_batch=256, preshift_num=0):
-        """preshift_num > 0 selects the PreshiftDetector variant (thr_create_preshift)."""
+                 corr_thresh, carrier_len=0, device_id=0, max_batch=256, preshift_num=0,
+                 fastdet=False):
+        """preshift_num > 0 selects the PreshiftDetector variant (thr_create_preshift);
+        fastdet=True the fastdet-compatible one (thr_create_fastdet, power-domain thresholds)."""
         lib = load_library()
         tpl = np.ascontiguousarray(np.atleast_2d(np.asarray(templates, dtype=np.float64)))
         if tpl.ndim != 2:
@@ -180,7 +183,9 @@ class Engine(object):
             st.corr_thresh[i] = float(corr_thresh[i])
         st.device_id, st.max_batch = int(device_id), int(max_batch)
         handle = C.c_void_p()
-        if preshift_num:
+        if fastdet:
+            _check(lib, lib.thr_create_fastdet(C.byref(st), C.byref(handle)))
+        elif preshift_num:
             _check(lib, lib.thr_create_preshift(C.byref(st), int(preshift_num), C.byref(handle)))
         else:
             _check(lib, lib.thr_create(C.byref(st), C.byref(handle)))

@@ -283,7 +283,8 @@ int build_preshift_bank(thr_handle* h) {
     std::vector<float2> bank(size_t(num) * n);
     const double pi = 3.14159265358979323846;
     for (int j = 0; j < num; ++j) {
-        const double shift = num > 1 ? -0.5 + double(j) / double(num - 1) : -0.5;
+        // (fastdet-compatible variant: ONE unshifted template spectrum)
+        const double shift = h->dev.variant == 2 ? 0.0 : num > 1 ? -0.5 + double(j) / double(num - 1) : -0.5;
         std::vector<std::complex<double>> buf(n, 0.0);
         for (int i = 0; i < w; ++i) {
             const double ph = -2.0 * pi * shift * (double(i) / double(n) - 0.5);
@@ -501,9 +502,19 @@ const char* thr_kernel_name(int slot) {
     return (slot >= 0 && slot < THR_N_KERNEL_SLOTS) ? names[slot] : "";
 }
 
-static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out);
+static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out, int variant = -1);
 
 int thr_create(const thr_settings* s, thr_handle** out) { return create_impl(s, 0, out); }
+
+int thr_create_fastdet(const thr_settings* s, thr_handle** out) {
+    if (!s || !out) return fail(THR_ERR_ARG, "thr_create_fastdet: null argument");
+    if (s->n_templates != 1) return fail(THR_ERR_ARG, "the fastdet variant takes exactly one template");
+    if (s->carrier_thresh[2] != 0.0 || s->corr_thresh[2] != 0.0)
+        return fail(THR_ERR_ARG, "fastdet thresholds are constant + snr * noise_power (no stddev term)");
+    if (s->carrier_window[0] < 0 && s->carrier_window[1] >= 0)   // cardet.c:44-48
+        return fail(THR_ERR_ARG, "Carrier frequency window range not supported.");
+    return create_impl(s, 1, out, 2);
+}
 
 int thr_create_preshift(const thr_settings* s, int num_shifts, thr_handle** out) {
     if (num_shifts < 1 || num_shifts > 4096)
@@ -513,7 +524,7 @@ int thr_create_preshift(const thr_settings* s, int num_shifts, thr_handle** out)
     return create_impl(s, num_shifts, out);
 }
 
-static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out) {
+static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out, int variant) {
     if (!s || !out) return fail(THR_ERR_ARG, "thr_create: null argument");
     *out = nullptr;
     const int n = s->block_len;
@@ -595,6 +606,7 @@ static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out
 #endif
         d.stagger = getenv("THR_STAGGER") ? atoi(getenv("THR_STAGGER")) : 1;
         d.dyn_sched = getenv("THR_DYN") ? atoi(getenv("THR_DYN")) : 1;
+        d.variant = variant >= 0 ? variant : (preshift_num ? 1 : 0);
         d.prio_mode = getenv("THR_PRIO") ? atoi(getenv("THR_PRIO")) : 0;
         d.ablate = getenv("THR_ABLATE") ? atoi(getenv("THR_ABLATE")) : 0;
         d.car_want_std = s->carrier_thresh[2] != 0.0;

@@ -831,6 +831,33 @@ __global__ __launch_bounds__(256) void k_finish(int n_records, DevCfg cfg,
     if (!(r->flags & THR_FLAG_CARRIER)) return;
     const int tpl = i % cfg.n_templates;
     const CorrStats cs = corr_stats[i];
+    if (cfg.variant == 2) {
+        // fastdet-compatible verdict (fastdet/corr_detector.cpp:103-175): float32, power domain,
+        // noise clamped at 0 and -- sic -- computed from the peak power truncated to an integer
+        // (estimate_noise takes it as size_t); Gaussian offset on log sqrt(power), clipped +-0.5.
+#pragma clang fp contract(off)
+        const float peak_power = cs.pm2;
+        const float signal_energy = cs.sum_x2 / float(cfg.block_len);
+        const float signal_corr_energy = signal_energy * cfg.tmpl_energy[0];
+        float noise_power =
+            (signal_corr_energy - float((unsigned long long)peak_power)) / float(cfg.block_len);
+        if (noise_power < 0) noise_power = 0;
+        const float threshold = cfg.cor_thr[0] + cfg.cor_thr[1] * noise_power;
+        const bool hit = peak_power > threshold;
+        double o = 0.0;
+        if (hit && cs.pk != 0 && cs.pk != cfg.corr_len - 1) {
+            const double a = log(sqrt(double(cs.m2[0]))), b = log(sqrt(double(cs.m2[1]))),
+                         c = log(sqrt(double(cs.m2[2])));
+            o = (c - a) / (4 * b - 2 * a - 2 * c);
+            o = o < -0.5 ? -0.5 : o > 0.5 ? 0.5 : o;
+        }
+        r->corr_sample = cs.pk;
+        r->corr_offset = o;
+        r->corr_energy = sqrtf(peak_power);
+        r->corr_noise = sqrtf(noise_power);
+        if (hit) r->flags |= THR_FLAG_CORR;
+        return;
+    }
     const double n = double(cfg.block_len);
     const double xenergy = double(corr_stats[i - tpl].sum_x2) / n;  // mean |X^|^2
     const double pm2 = double(cs.pm2);

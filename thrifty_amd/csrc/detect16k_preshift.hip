@@ -45,17 +45,48 @@ namespace {
 struct PreshiftVerdict {
     bool carrier, index_error;
     float peak_mag, noise_rms, offset;
+    double offset_f64;   // what goes into the record (fastdet keeps the double parabola)
     int s_mod;   // int_shift mod N, in [0, N)
     int bank;    // pre-shifted template index
     int int_shift;
 };
 
-// peak_mag, a, c = |X[peak]|, |X[peak-1]|, |X[peak+1]|
-__device__ __forceinline__ PreshiftVerdict preshift_verdict(const DevCfg& cfg, float peak_mag,
-                                                            float sum_mag2, float sum_mag,
-                                                            int peak_idx, float a, float c,
-                                                            int num) {
+// fastdet-compatible verdict (fastcard/cardet.c:7-41, fastdet/corr_detector.cpp:88-101,177-197):
+// float32 power-domain threshold c + s * noise_power with noise_power = (sum - 2 max)/(N - 1),
+// integer roll by -argmax against the UNSHIFTED template, carrier offset = parabola on the
+// square roots (double), clipped to +-0.5.
+__device__ __forceinline__ PreshiftVerdict fastdet_verdict(const DevCfg& cfg, float peak_pow,
+                                                           float sum_pow, int peak_idx, float a_mag,
+                                                           float c_mag) {
 #pragma clang fp contract(off)
+    PreshiftVerdict v;
+    const int n = cfg.block_len;
+    float noise_power = 0.f;
+    if (sum_pow != 0.f) noise_power = (sum_pow - 2.0f * peak_pow) / float(n - 1);
+    const float thr = cfg.car_thr[0] + cfg.car_thr[1] * noise_power;
+    v.carrier = peak_pow > thr;
+    v.index_error = false;
+    v.peak_mag = sqrtf(peak_pow);
+    v.noise_rms = sqrtf(noise_power);
+    const double a = double(a_mag), b = sqrt(double(peak_pow)), c = double(c_mag);
+    double off = (c - a) / (4 * b - 2 * a - 2 * c);
+    off = off < -0.5 ? -0.5 : off > 0.5 ? 0.5 : off;
+    v.offset = v.carrier ? float(off) : 0.f;
+    v.offset_f64 = v.carrier ? off : 0.0;
+    v.bank = 0;
+    v.int_shift = -peak_idx;
+    v.s_mod = (n - peak_idx) & (n - 1);
+    return v;
+}
+
+// peak_mag, a, c = |X[peak]|, |X[peak-1]|, |X[peak+1]|
+// (peak_pow = |X[peak]|^2 as summed; only the fastdet verdict, which never takes roots, uses it)
+__device__ __forceinline__ PreshiftVerdict preshift_verdict(const DevCfg& cfg, float peak_pow_raw,
+                                                            float peak_mag, float sum_mag2,
+                                                            float sum_mag, int peak_idx, float a,
+                                                            float c, int num) {
+#pragma clang fp contract(off)
+    if (cfg.variant == 2) return fastdet_verdict(cfg, peak_pow_raw, sum_mag2, peak_idx, a, c);
     PreshiftVerdict v;
     const int n = cfg.block_len;
     const float peak_pow = peak_mag * peak_mag;
@@ -75,6 +106,7 @@ __device__ __forceinline__ PreshiftVerdict preshift_verdict(const DevCfg& cfg, f
     const float b = peak_mag;
     const float two_a = 2.0f * a, two_c = 2.0f * c, four_b = 4.0f * b;
     v.offset = v.carrier ? (c - a) / ((four_b - two_a) - two_c) : 0.0f;
+    v.offset_f64 = double(v.offset);
     // shift = -(bin + offset), integer part rolled, rest -> nearest bank entry
     // (carrier_sync.py:71, detect_preshift.py:62-65,42-45; np.round == rint, half to even)
     const double shift = -(double(peak_idx) + double(v.offset));
@@ -96,7 +128,7 @@ __device__ __forceinline__ thr_record preshift_record(const PreshiftVerdict& vd,
     r.template_id = 0;
     r.carrier_bin = peak_idx;
     r.corr_sample = -1;
-    r.carrier_offset = double(vd.offset);
+    r.carrier_offset = vd.offset_f64;
     r.corr_offset = 0.0;
     r.carrier_energy = vd.peak_mag;
     r.carrier_noise = vd.noise_rms;
@@ -119,8 +151,9 @@ __global__ __launch_bounds__(64) void k_fit_preshift(int n_blocks, DevCfg cfg, i
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_blocks) return;
     const CarStats st = stats[b];
-    const PreshiftVerdict vd = preshift_verdict(cfg, st.peak_mag, st.sum_mag2, st.sum_mag,
-                                                st.peak_idx, st.nb[2], st.nb[4], num);
+    const PreshiftVerdict vd = preshift_verdict(cfg, st.peak_mag * st.peak_mag, st.peak_mag,
+                                                st.sum_mag2, st.sum_mag, st.peak_idx, st.nb[2],
+                                                st.nb[4], num);
     shifts[b].si_mod = vd.s_mod;
     shifts[b].bank = vd.bank;
     records[b] = preshift_record(vd, block_idx ? block_idx[b] : (long long)b, st.peak_idx);
@@ -207,7 +240,8 @@ __global__ __launch_bounds__(NT) void k_preshift(const void* __restrict__ sample
         const float pa = sc_nb[parity * 2], pc = sc_nb[parity * 2 + 1];
         parity ^= 1;
         const PreshiftVerdict vd =
-            preshift_verdict(cfg, sqrtf(__uint_as_float(unsigned(best >> 32))), (float)ctot[0],
+            preshift_verdict(cfg, __uint_as_float(unsigned(best >> 32)),
+                             sqrtf(__uint_as_float(unsigned(best >> 32))), (float)ctot[0],
                              CAR_STD ? (float)ctot[1] : 0.f, peak_idx, sqrtf(pa), sqrtf(pc), num);
         if (t == 0) records[b] = preshift_record(vd, block_idx ? block_idx[b] : (long long)b, peak_idx);
         if (!vd.carrier) continue;   // block-uniform: every thread computed the same verdict

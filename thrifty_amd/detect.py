@@ -48,7 +48,7 @@ class Detector(object):
     _offset_type = float      # CarrierSyncInfo.offset as the reference types it
 
     def __init__(self, settings, blocks=None, rxid=-1, yield_data=False, batch_size=1024,
-                 device_id=0, _preshift_num=0):
+                 device_id=0, _preshift_num=0, _fastdet=False):
         self.settings = settings
         # a CardStream is consumed in whole batches with the base64 payloads decoded on the GPU
         self._card = blocks if isinstance(blocks, CardStream) and not yield_data else None
@@ -66,7 +66,8 @@ class Detector(object):
         self._engine = _native.Engine(
             settings.block_len, settings.history_len, template, settings.carrier_thresh,
             settings.carrier_window, settings.corr_thresh, carrier_len=settings.carrier_len,
-            device_id=device_id, max_batch=self.batch_size, preshift_num=_preshift_num)
+            device_id=device_id, max_batch=self.batch_size, preshift_num=_preshift_num,
+            fastdet=_fastdet)
         self._ready = deque()
         self._exhausted = False
         # batch readers only (CardStream / RawStream): hand out detections only, skipping the
