@@ -101,6 +101,7 @@ struct thr_handle {
     bool w16 = false;        // fast path geometry: 16 waves x 16 elements (else 8 waves x 32)
     bool lng = false;        // block_len = 2 or 4 x 16384: R0 LDS sub-transforms per block
     int long_batch = 0;      // long path: blocks per internal sub-batch
+    int long_chunk = 0;      // long path: work-list slots per correlate-stage chunk (sizes d_dsub)
     float* d_win_pow = nullptr;     // long: [long_batch][win_w] |X|^2 of the window bins (+-3)
     float* d_partial = nullptr;     // long: [long_batch][R0][2] partial sums of FFT#1
     float* d_partial_x2 = nullptr;  // long: [long_batch][R0] partial sum |X^|^2
@@ -468,7 +469,7 @@ int run_batch_long(thr_handle* h, const void* d_samples, int format,
                 h->d_work_count, h->d_dsub, h->d_partial_x2, h->d_xhat_scratch, h->d_corr_stats,
                 dump_xhat ? dump_xhat + size_t(off) * n : nullptr,
                 dump_corr ? dump_corr + size_t(off) * n : nullptr, dump_template,
-                std::min(nb * r0, h->n_cu), h->stream));
+                std::min(nb * r0, h->n_cu), h->long_chunk, h->stream));
         }
         {
             ProfScope p(h, 3);
@@ -646,8 +647,11 @@ static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out
             // (the decimation-in-time carrier stage parks R0 complex values per window bin here)
             CREATE_TRY(hipMalloc(&h->d_win_pow, lb * win_w * sizeof(float) * 2 * r0));
             CREATE_TRY(hipMalloc(&h->d_partial, lb * r0 * 2 * sizeof(float)));
-            CREATE_TRY(hipMalloc(&h->d_partial_x2, lb * r0 * sizeof(float)));
-            CREATE_TRY(hipMalloc(&h->d_dsub, lb * s->n_templates * size_t(n) * sizeof(float2)));
+            h->long_chunk = std::min(h->long_batch, thr::long_chunk_blocks(n, s->n_templates));
+            if (getenv("THR_LONG_CHUNK")) h->long_chunk = std::max(1, std::min(h->long_batch, atoi(getenv("THR_LONG_CHUNK"))));
+            const size_t lc = size_t(h->long_chunk);
+            CREATE_TRY(hipMalloc(&h->d_partial_x2, lc * r0 * sizeof(float)));
+            CREATE_TRY(hipMalloc(&h->d_dsub, lc * s->n_templates * size_t(n) * sizeof(float2)));
             CREATE_TRY(hipMalloc(&h->d_xhat_scratch, size_t(h->n_cu) * 16384 * sizeof(float2)));
         }
         if (!h->fast && !h->lng) {

@@ -126,8 +126,9 @@ hipError_t launch_correlate_long(int fmt, const void* samples, int n_blocks, con
                                  const ShiftParams* shifts, const int* work_list,
                                  const int* work_count, float2* dsub, float* partial_x2,
                                  float4* xhat_scratch, CorrStats* corr_stats, float2* dump_xhat,
-                                 float2* dump_corr, int dump_template, int grid,
+                                 float2* dump_corr, int dump_template, int grid, int chunk,
                                  hipStream_t stream);
+int long_chunk_blocks(int block_len, int n_templates);
 
 // card_ingest.hip (.card base64 payloads -> u8 IQ on the device)
 hipError_t launch_b64_decode(const unsigned char* d_text, const long long* d_payload_off, int n_lines,

@@ -16,6 +16,8 @@
 // Reference lines as in detect16k.hip.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "detect_common.hpp"
 #include "fft_regs.hpp"
 #include "kernel_util.hpp"
@@ -439,8 +441,9 @@ __global__ __launch_bounds__(NT) void k_correlate_sub(
     const void* __restrict__ samples, DevCfg cfg, const cpx* __restrict__ tables,
     const cpx* __restrict__ twn, const f4* __restrict__ tspec,
     const ShiftParams* __restrict__ shifts, const int* __restrict__ work_list,
-    const int* __restrict__ work_count, f4* __restrict__ dsub,   // [slot][tpl][k0][M/2] float4
-    float* __restrict__ partial_x2,                               // [slot][R0]
+    const int* __restrict__ work_count, int slot_base, int slot_cap,
+    f4* __restrict__ dsub,           // [slot - slot_base][tpl][k0][M/2] float4
+    float* __restrict__ partial_x2,  // [slot - slot_base][R0]
     f4* __restrict__ xhat_scratch, cpx* __restrict__ dump_xhat) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cpx* lds = reinterpret_cast<cpx*>(smem_raw);
@@ -452,7 +455,10 @@ __global__ __launch_bounds__(NT) void k_correlate_sub(
     __syncthreads();
     const int NL = R0 * M, nl_mask = NL - 1;
     const size_t blk_bytes = cfg.blk_stride;
-    const int n_work = *work_count;
+    // this launch owns work-list slots [slot_base, slot_base + slot_cap): the correlate stage
+    // runs in chunks small enough for the d_k0 exchange to stay in the Infinity Cache
+    // (`work_list` already points at slot_base)
+    const int n_work = max(0, min(*work_count - slot_base, slot_cap));
     const int T = cfg.n_templates;
     int parity = 0;
 
@@ -560,12 +566,12 @@ __global__ __launch_bounds__(1024) void k_combine(DevCfg cfg, const cpx* __restr
                                                   const float* __restrict__ partial_x2,
                                                   const int* __restrict__ work_list,
                                                   const int* __restrict__ work_count,
-                                                  CorrStats* __restrict__ corr_stats,
+                                                  int slot_base, CorrStats* __restrict__ corr_stats,
                                                   cpx* __restrict__ dump_corr, int dump_template) {
     __shared__ __attribute__((aligned(16))) unsigned char scratch[2 * 16 * 32];
     const int T = cfg.n_templates;
-    const int slot = blockIdx.x / T, tpl = blockIdx.x % T;
-    if (slot >= *work_count) return;
+    const int slot = blockIdx.x / T, tpl = blockIdx.x % T;   // chunk-local; work_list points at slot_base
+    if (slot_base + slot >= *work_count) return;
     const int b = work_list[slot];
     const int NL = R0 * M, nl_mask = NL - 1;
     const cpx* d = dsub + (size_t(slot) * T + tpl) * NL;
@@ -699,22 +705,26 @@ hipError_t correlate_r0(int fmt, const void* samples, int n_blocks, const DevCfg
                         const ShiftParams* shifts, const int* work_list, const int* work_count,
                         float2* dsub, float* partial_x2, float4* xhat_scratch,
                         CorrStats* corr_stats, float2* dump_xhat, float2* dump_corr,
-                        int dump_template, int grid, hipStream_t stream) {
+                        int dump_template, int grid, int chunk, hipStream_t stream) {
     typedef void (*fn_t)(const void*, DevCfg, const cpx*, const cpx*, const f4*, const ShiftParams*,
-                         const int*, const int*, f4*, float*, f4*, cpx*);
+                         const int*, const int*, int, int, f4*, float*, f4*, cpx*);
     const bool dump = dump_xhat != nullptr;
     fn_t fn = fmt == THR_IN_U8
                   ? (dump ? &k_correlate_sub<THR_IN_U8, R0, true> : &k_correlate_sub<THR_IN_U8, R0, false>)
                   : (dump ? &k_correlate_sub<THR_IN_C64, R0, true> : &k_correlate_sub<THR_IN_C64, R0, false>);
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(NT), LDS_BYTES, stream, samples, cfg,
-                       reinterpret_cast<const cpx*>(tables), reinterpret_cast<const cpx*>(twn),
-                       reinterpret_cast<const f4*>(tspec), shifts, work_list, work_count,
-                       reinterpret_cast<f4*>(dsub), partial_x2, reinterpret_cast<f4*>(xhat_scratch),
-                       reinterpret_cast<cpx*>(dump_xhat));
-    hipLaunchKernelGGL(k_combine<R0>, dim3(n_blocks * cfg.n_templates), dim3(1024), 0, stream, cfg,
-                       reinterpret_cast<const cpx*>(twn), reinterpret_cast<const cpx*>(dsub),
-                       partial_x2, work_list, work_count, corr_stats,
-                       reinterpret_cast<cpx*>(dump_corr), dump_template);
+    // slot chunks: dsub / partial_x2 hold ONE chunk (see long_chunk_blocks)
+    for (int base = 0; base < n_blocks; base += chunk) {
+        const int cap = std::min(chunk, n_blocks - base);
+        hipLaunchKernelGGL(fn, dim3(std::min(grid, cap * R0)), dim3(NT), LDS_BYTES, stream, samples, cfg,
+                           reinterpret_cast<const cpx*>(tables), reinterpret_cast<const cpx*>(twn),
+                           reinterpret_cast<const f4*>(tspec), shifts, work_list + base, work_count, base,
+                           cap, reinterpret_cast<f4*>(dsub), partial_x2,
+                           reinterpret_cast<f4*>(xhat_scratch), reinterpret_cast<cpx*>(dump_xhat));
+        hipLaunchKernelGGL(k_combine<R0>, dim3(cap * cfg.n_templates), dim3(1024), 0, stream, cfg,
+                           reinterpret_cast<const cpx*>(twn), reinterpret_cast<const cpx*>(dsub),
+                           partial_x2, work_list + base, work_count, base, corr_stats,
+                           reinterpret_cast<cpx*>(dump_corr), dump_template);
+    }
     return hipGetLastError();
 }
 
@@ -742,15 +752,22 @@ hipError_t launch_correlate_long(int fmt, const void* samples, int n_blocks, con
                                  const ShiftParams* shifts, const int* work_list,
                                  const int* work_count, float2* dsub, float* partial_x2,
                                  float4* xhat_scratch, CorrStats* corr_stats, float2* dump_xhat,
-                                 float2* dump_corr, int dump_template, int grid,
+                                 float2* dump_corr, int dump_template, int grid, int chunk,
                                  hipStream_t stream) {
     return cfg.block_len == 2 * M
                ? correlate_r0<2>(fmt, samples, n_blocks, cfg, tables, twn, tspec, shifts, work_list,
                                  work_count, dsub, partial_x2, xhat_scratch, corr_stats, dump_xhat,
-                                 dump_corr, dump_template, grid, stream)
+                                 dump_corr, dump_template, grid, chunk, stream)
                : correlate_r0<4>(fmt, samples, n_blocks, cfg, tables, twn, tspec, shifts, work_list,
                                  work_count, dsub, partial_x2, xhat_scratch, corr_stats, dump_xhat,
-                                 dump_corr, dump_template, grid, stream);
+                                 dump_corr, dump_template, grid, chunk, stream);
+}
+
+// blocks per correlate-stage chunk: the d_k0 exchange (8 * block_len * T bytes per block) of one
+// chunk is kept near 128 MiB, half the Infinity Cache
+int long_chunk_blocks(int block_len, int n_templates) {
+    const size_t per_block = size_t(8) * block_len * n_templates;
+    return int(std::max<size_t>(16, (size_t(128) << 20) / per_block));
 }
 
 }  // namespace thr
