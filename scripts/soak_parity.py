@@ -1,0 +1,90 @@
+"""Dev/aux: large parity soak -- GPU records vs the CPU oracle over many synthetic blocks,
+the oracle spread over worker processes.  Usage: soak_parity.py [n_blocks] [procs] [variant]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import multiprocessing as mp
+import numpy as np
+
+N, H = 16384, 4096
+
+
+def work(args):
+    os.environ["OMP_NUM_THREADS"] = "1"
+    lo, blocks, tpl, variant = args
+    from oracle import thrifty_np as onp
+    if variant == "preshift":
+        orc = onp.OraclePreshiftDetector(N, H, tpl, (0, 15, 0), (7, 110), (0, 15, 0), num=21)
+    else:
+        orc = onp.OracleDetector(N, H, tpl, (0, 15, 0), (7, 110), (0, 15, 0))
+    out = []
+    for i in range(len(blocks)):
+        r = orc.detect_u8(lo + i, blocks[i])
+        if variant != "preshift":
+            (r,) = r
+        c = r.corr
+        out.append((r.carrier.bin, r.carrier.detected, r.carrier.offset,
+                    c.sample if c else -1, bool(c.detected) if c else False,
+                    c.energy if c else 0.0, c.offset if c else 0.0))
+    return lo, out
+
+
+def main():
+    total = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+    procs = int(sys.argv[2]) if len(sys.argv) > 2 else max(1, (os.cpu_count() or 2) // 2)
+    variant = sys.argv[3] if len(sys.argv) > 3 else "default"
+    import torch
+    import bench
+    from thrifty_amd import _native as F, synth
+    dev = torch.device("cuda", 0)
+    tpl = synth.gold_template(10, 2).astype(np.float64)
+    pad = H - len(tpl) + 1
+    window = (pad // 2, (N - len(tpl) + 1) - (pad - pad // 2))
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(777)
+    data = bench.synth_on_device(torch, dev, gen, total, tpl, window, 0.9)
+    eng = F.Engine(N, H, tpl, (0, 15, 0), (7, 110), (0, 15, 0), max_batch=8192,
+                   preshift_num=21 if variant == "preshift" else 0)
+    rec = torch.zeros((total, 64), dtype=torch.uint8, device=dev)
+    for s in range(0, total, 8192):
+        nb = min(8192, total - s)
+        eng.detect_device(data[s:s + nb].data_ptr(), F.THR_IN_U8, nb, rec[s:].data_ptr())
+    eng.sync()
+    rec = rec.cpu().numpy().view(F.RECORD_DTYPE).reshape(-1)
+    host = data.cpu().numpy()
+    chunk = 256
+    jobs = [(s, host[s:s + chunk], tpl, variant) for s in range(0, total, chunk)]
+    t0 = time.perf_counter()
+    mism = dict(bin=0, carrier=0, sample=0, det=0, energy=0, offset=0, car_off=0)
+    worst = dict(energy=0.0, offset=0.0, car_off=0.0)
+    with mp.Pool(procs) as pool:
+        for lo, out in pool.imap_unordered(work, jobs):
+            for i, (cbin, cdet, coff, samp, det, en, off) in enumerate(out):
+                r = rec[lo + i]
+                if r["carrier_bin"] != cbin:
+                    mism["bin"] += 1
+                    from oracle import thrifty_np as onp
+                    mag = np.abs(np.fft.fft(onp.iq_u8_to_c64(host[lo + i])))
+                    print("bin mismatch at block %d: gpu bin %d |X|=%.9g, oracle bin %d |X|=%.9g (rel diff %.3g)" % (
+                        lo + i, r["carrier_bin"], mag[r["carrier_bin"]], cbin, mag[cbin],
+                        abs(mag[r["carrier_bin"]] - mag[cbin]) / mag[cbin]))
+                mism["carrier"] += bool(r["flags"] & F.FLAG_CARRIER) != cdet
+                if not cdet:
+                    continue
+                mism["sample"] += r["corr_sample"] != samp
+                mism["det"] += bool(r["flags"] & F.FLAG_CORR) != det
+                e = abs(r["corr_energy"] - en) / abs(en)
+                o = abs(r["corr_offset"] - off) if det else 0.0
+                co = abs(r["carrier_offset"] - coff)
+                worst["energy"], worst["offset"], worst["car_off"] = (
+                    max(worst["energy"], e), max(worst["offset"], o), max(worst["car_off"], co))
+                mism["energy"] += e > 1e-4
+                mism["offset"] += o > 1e-4
+                mism["car_off"] += co > 1e-3
+    dt = time.perf_counter() - t0
+    print("variant=%s blocks=%d procs=%d oracle %.0f blocks/s (%.1f s)  mismatches=%s  worst=%s" % (
+        variant, total, procs, total / dt, dt, {k: int(v) for k, v in mism.items()},
+        {k: float("%.3g" % v) for k, v in worst.items()}))
+
+
+if __name__ == "__main__":
+    main()

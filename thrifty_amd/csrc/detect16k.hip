@@ -228,8 +228,10 @@ __global__ __launch_bounds__(NT) void k_carrier_pruned(const void* __restrict__ 
             const float p = cnorm(x);
             sc_bins[k] = p;
             const unsigned wi = unsigned(k - win_off) & unsigned(N - 1);
+            // the key carries |X| (not |X|^2): the reference takes argmax over float32 magnitudes,
+            // where powers an ulp apart can collide -- the first bin then wins, here as there
             if (wi < unsigned(cfg.win_count))
-                best = ((unsigned long long)__float_as_uint(p) << 32) | (0xFFFFFFFFu - wi);
+                best = ((unsigned long long)__float_as_uint(sqrtf(p)) << 32) | (0xFFFFFFFFu - wi);
         }
         double tot[1];
         block_reduce<1, NT / 64>(sums, tot, best, sc_red, parity);
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(NT) void k_carrier_pruned(const void* __restrict__ 
         if (t == 0) {
             st->sum_mag2 = (float)(tot[0] * double(N));  // Parseval
             st->sum_mag = 0.f;
-            st->peak_mag = sqrtf(__uint_as_float(unsigned(best >> 32)));
+            st->peak_mag = __uint_as_float(unsigned(best >> 32));
             st->peak_idx = peak_idx;
             st->pad = 0;
         }

@@ -372,7 +372,7 @@ __global__ __launch_bounds__(128) void k_select_dit(int r0, DevCfg cfg, const cp
         pw[i] = p;
         const int wi = i - 3;
         if (wi >= 0 && wi < cfg.win_count)
-            best = ((unsigned long long)__float_as_uint(p) << 32) | (0xFFFFFFFFu - unsigned(wi));
+            best = ((unsigned long long)__float_as_uint(sqrtf(p)) << 32) | (0xFFFFFFFFu - unsigned(wi));
     }
     best = wave_max(best);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = best;
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(128) void k_select_dit(int r0, DevCfg cfg, const cp
         for (int r = 0; r < r0; ++r) s2 += partial[(size_t(b) * r0 + r) * 2 + 0];
         st.sum_mag2 = s2;
         st.sum_mag = 0.f;
-        st.peak_mag = sqrtf(__uint_as_float(unsigned(best >> 32)));
+        st.peak_mag = __uint_as_float(unsigned(best >> 32));   // the key carries |X| (ties: see k_carrier_pruned)
         st.peak_idx = wi + cfg.win_lo;   // < 128: the reference's wrap quirk cannot trigger
         for (int d = 0; d < 7; ++d) st.nb[d] = sqrtf(pw[wi + d]);
         st.pad = 0;
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void k_select(int r0, DevCfg cfg, const float*
         // with a full-length window the +-3 margin cannot be stored: index modulo the array
         const float pw = wp[(wi + 3) % win_w];
         const unsigned long long key =
-            ((unsigned long long)__float_as_uint(pw) << 32) | (0xFFFFFFFFu - unsigned(wi));
+            ((unsigned long long)__float_as_uint(sqrtf(pw)) << 32) | (0xFFFFFFFFu - unsigned(wi));
         best = key > best ? key : best;
     }
     best = wave_max(best);
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void k_select(int r0, DevCfg cfg, const float*
         }
         st.sum_mag2 = s2;
         st.sum_mag = s1;
-        st.peak_mag = sqrtf(__uint_as_float(unsigned(best >> 32)));
+        st.peak_mag = __uint_as_float(unsigned(best >> 32));
         st.peak_idx = peak_idx;
         for (int d = 0; d < 7; ++d) st.nb[d] = sqrtf(wp[(wi + d) % win_w]);
         st.pad = 0;

@@ -156,8 +156,9 @@ __global__ __launch_bounds__(256) void g_carrier_stats(const cpx2* __restrict__ 
         if (cfg.car_want_std) s1 += sqrtf(p);
         const unsigned wi = unsigned(k - cfg.win_lo) & unsigned(n - 1);
         if (wi < unsigned(cfg.win_count)) {
+            // |X| in the key (the reference compares float32 magnitudes; ties go to the first bin)
             const unsigned long long key =
-                ((unsigned long long)__float_as_uint(p) << 32) | (0xFFFFFFFFu - wi);
+                ((unsigned long long)__float_as_uint(sqrtf(p)) << 32) | (0xFFFFFFFFu - wi);
             best = key > best ? key : best;
         }
     }
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256) void g_carrier_stats(const cpx2* __restrict__ 
         CarStats st;
         st.sum_mag2 = (float)s2;
         st.sum_mag = (float)s1;
-        st.peak_mag = sqrtf(__uint_as_float(unsigned(best >> 32)));
+        st.peak_mag = __uint_as_float(unsigned(best >> 32));
         st.peak_idx = peak_idx;
         for (int d = 0; d < 7; ++d) {
             const cpx2 v = x[(peak_idx - 3 + d) & (n - 1)];
