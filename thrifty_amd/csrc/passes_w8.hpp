@@ -23,9 +23,13 @@ constexpr int DATA = R1 * ROW;    // 17408 complex
 constexpr int OFF_C = DATA;             // C[32][32]  = W_1024^(a*b)
 constexpr int OFF_A = OFF_C + 1024;     // A[16][32]  = W_512^(n2*k1)   [k1][n2]
 constexpr int OFF_B = OFF_A + 512;      // Bt[16][32] = W_N^(m'*k1)     [k1][m']
-constexpr int OFF_S = OFF_B + 512;      // 128 complex (1 KiB) reduction scratch
-constexpr int LDS_CPX = OFF_S + 128;
-constexpr size_t LDS_BYTES = size_t(LDS_CPX) * sizeof(cpx);  // 156,672 B
+// Scratch (1.5 KiB): [0, 512) the block reductions (2 parities x 8 waves x 32 B); the rest is
+// per-kernel: k_carrier_pruned 128 window powers + 16 phasors ([512, 1152)), k_preshift its
+// two neighbour powers ([512, 528)), k_correlate the dynamic work cursor ([768, 772)), the
+// long-block kernels 16 + R0 item factors ([512, 672)).
+constexpr int OFF_S = OFF_B + 512;
+constexpr int LDS_CPX = OFF_S + 192;
+constexpr size_t LDS_BYTES = size_t(LDS_CPX) * sizeof(cpx);  // 157,184 B of the CU's 163,840
 }  // namespace k16
 
 using namespace k16;
