@@ -186,7 +186,7 @@ extern "C" int thr_identify(int device_id, size_t n_in, const int32_t* rxid, con
     if (!rxid || !block || !timestamp || !carrier_bin || !carrier_offset || !energy || !txid_out ||
         !keep_out || !kept_order_out || !n_kept_out)
         return thr::fail_msg(THR_ERR_ARG, "thr_identify: null argument");
-    if (n_in > size_t(1) << 30) return thr::fail_msg(THR_ERR_ARG, "thr_identify: too many detections");
+    if (n_in > size_t(1) << 28) return thr::fail_msg(THR_ERR_ARG, "thr_identify: too many detections");
     if (n_map > 0 && !map) return thr::fail_msg(THR_ERR_ARG, "thr_identify: null frequency map");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -198,19 +198,19 @@ extern "C" int thr_identify(int device_id, size_t n_in, const int32_t* rxid, con
     hipStream_t s = nullptr;
 
     DevBuf d_rx, d_blk, d_ts, d_bin, d_off, d_en, d_tx, d_keep, d_flag;
-    ID_TRY(d_rx.alloc(n * 4));
-    ID_TRY(d_blk.alloc(n * 4));
+    ID_TRY(d_rx.alloc(size_t(n) * 4));
+    ID_TRY(d_blk.alloc(size_t(n) * 4));
     ID_TRY(d_ts.alloc(size_t(n) * 8));
-    ID_TRY(d_bin.alloc(n * 4));
+    ID_TRY(d_bin.alloc(size_t(n) * 4));
     ID_TRY(d_off.alloc(size_t(n) * 8));
     ID_TRY(d_en.alloc(size_t(n) * 8));
-    ID_TRY(d_tx.alloc(n * 4));
+    ID_TRY(d_tx.alloc(size_t(n) * 4));
     ID_TRY(d_keep.alloc(n));
     ID_TRY(d_flag.alloc(n));
-    ID_TRY(hipMemcpy(d_rx.p, rxid, n * 4, hipMemcpyHostToDevice));
-    ID_TRY(hipMemcpy(d_blk.p, block, n * 4, hipMemcpyHostToDevice));
+    ID_TRY(hipMemcpy(d_rx.p, rxid, size_t(n) * 4, hipMemcpyHostToDevice));
+    ID_TRY(hipMemcpy(d_blk.p, block, size_t(n) * 4, hipMemcpyHostToDevice));
     ID_TRY(hipMemcpy(d_ts.p, timestamp, size_t(n) * 8, hipMemcpyHostToDevice));
-    ID_TRY(hipMemcpy(d_bin.p, carrier_bin, n * 4, hipMemcpyHostToDevice));
+    ID_TRY(hipMemcpy(d_bin.p, carrier_bin, size_t(n) * 4, hipMemcpyHostToDevice));
     ID_TRY(hipMemcpy(d_off.p, carrier_offset, size_t(n) * 8, hipMemcpyHostToDevice));
     ID_TRY(hipMemcpy(d_en.p, energy, size_t(n) * 8, hipMemcpyHostToDevice));
 
@@ -272,16 +272,16 @@ extern "C" int thr_identify(int device_id, size_t n_in, const int32_t* rxid, con
     size_t tmp_bytes = 0;
     ID_TRY(d_k64a.alloc(size_t(n) * 8));
     ID_TRY(d_k64b.alloc(size_t(n) * 8));
-    ID_TRY(d_k32a.alloc(n * 4));
-    ID_TRY(d_k32b.alloc(n * 4));
-    ID_TRY(d_pa.alloc(n * 4));
-    ID_TRY(d_pb.alloc(n * 4));
-    ID_TRY(d_pts.alloc(n * 4));
+    ID_TRY(d_k32a.alloc(size_t(n) * 4));
+    ID_TRY(d_k32b.alloc(size_t(n) * 4));
+    ID_TRY(d_pa.alloc(size_t(n) * 4));
+    ID_TRY(d_pb.alloc(size_t(n) * 4));
+    ID_TRY(d_pts.alloc(size_t(n) * 4));
     unsigned *pa = d_pa.as<unsigned>(), *pb = d_pb.as<unsigned>();
     hipLaunchKernelGGL(k_iota, grid, blk, 0, s, pa, n);
     hipLaunchKernelGGL(k_keys_f64, grid, blk, 0, s, d_ts.as<double>(), pa, n, d_k64a.as<unsigned long long>());
     ID_TRY(sort_pass(d_tmp, tmp_bytes, d_k64a.as<unsigned long long>(), d_k64b.as<unsigned long long>(), pa, pb, n, s));
-    ID_TRY(hipMemcpyAsync(d_pts.p, pb, n * 4, hipMemcpyDeviceToDevice, s));  // order by timestamp alone
+    ID_TRY(hipMemcpyAsync(d_pts.p, pb, size_t(n) * 4, hipMemcpyDeviceToDevice, s));  // order by timestamp alone
     std::swap(pa, pb);
     for (const int* col : {d_blk.as<int>(), d_tx.as<int>(), d_rx.as<int>()}) {
         hipLaunchKernelGGL(k_keys_i32, grid, blk, 0, s, col, pa, n, d_k32a.as<unsigned>());
@@ -296,7 +296,7 @@ extern "C" int thr_identify(int device_id, size_t n_in, const int32_t* rxid, con
                        n, d_flag.as<unsigned char>());
     ID_TRY(hipGetLastError());
     DevBuf d_sel, d_nsel, d_wide;
-    ID_TRY(d_sel.alloc(n * 4));
+    ID_TRY(d_sel.alloc(size_t(n) * 4));
     ID_TRY(d_nsel.alloc(4));
     ID_TRY(d_wide.alloc(size_t(n) * 8));
     {
@@ -316,7 +316,7 @@ extern "C" int thr_identify(int device_id, size_t n_in, const int32_t* rxid, con
     ID_TRY(hipGetLastError());
     int n_kept = 0;
     ID_TRY(hipMemcpy(&n_kept, d_nsel.p, 4, hipMemcpyDeviceToHost));
-    ID_TRY(hipMemcpy(txid_out, d_tx.p, n * 4, hipMemcpyDeviceToHost));
+    ID_TRY(hipMemcpy(txid_out, d_tx.p, size_t(n) * 4, hipMemcpyDeviceToHost));
     ID_TRY(hipMemcpy(keep_out, d_keep.p, n, hipMemcpyDeviceToHost));
     ID_TRY(hipMemcpy(kept_order_out, d_wide.p, size_t(n_kept) * 8, hipMemcpyDeviceToHost));
     *n_kept_out = size_t(n_kept);
