@@ -156,7 +156,22 @@ class CardStream(object):
         `text` is this reader's buffer: valid until the next call."""
         stamps, idxs, offs = [], [], []
         buf = self._buf
+        chars = self.payload_chars
         while len(offs) < max_blocks:
+            # Fast path: a data line is `<ts> <idx> ` + exactly payload_chars characters, so its
+            # end is known from the two spaces of the short header -- no 43 KB newline scan.
+            start = self._pos
+            if start < self._end and 0x30 <= buf[start] <= 0x39:
+                sp1 = buf.find(b" ", start, min(start + 40, self._end))
+                sp2 = buf.find(b" ", sp1 + 1, min(sp1 + 32, self._end)) if sp1 >= 0 else -1
+                end = sp2 + 1 + chars
+                if sp2 >= 0 and end < self._end and (
+                        buf[end] == 0x0A or (buf[end] == 0x0D and end + 1 < self._end and buf[end + 1] == 0x0A)):
+                    stamps.append(float(buf[start:sp1]))
+                    idxs.append(int(buf[sp1 + 1:sp2]))
+                    offs.append(sp2 + 1)
+                    self._pos = end + (1 if buf[end] == 0x0A else 2)
+                    continue
             end = buf.find(b"\n", self._pos, self._end)
             if end < 0:
                 if offs:
