@@ -19,8 +19,12 @@ for j in range(64):
     x[s:s + len(tpl)] += ook * np.exp(2j * np.pi * (20 + j) * (k + s) / n)
 raw = np.tile(synth.quantise_iq(x), nb // 64).tobytes()
 st = DetectorSettings(n, h, len(tpl), (0, 15, 0), (7, 110), tpl, (0, 15, 0))
+import tempfile
+tmp = tempfile.NamedTemporaryFile(suffix=".bin", delete=False)
+tmp.write(raw); tmp.close()
 for name, mk in (("host framing (block_reader)", lambda: block_data.block_reader(io.BytesIO(raw), n, h)),
-                 ("device framing (RawStream)", lambda: block_data.RawStream(io.BytesIO(raw), n, h))):
+                 ("device framing (RawStream, pipe)", lambda: block_data.RawStream(io.BytesIO(raw), n, h)),
+                 ("device framing (RawStream, file)", lambda: block_data.RawStream(open(tmp.name, "rb"), n, h))):
     det = Detector(st, mk(), batch_size=1024)
     t0 = time.perf_counter()
     cnt = sum(1 for d, r in det if d)
@@ -36,10 +40,12 @@ for j in range(64):
     x2[s:s + len(tpl)] += ook * np.exp(2j * np.pi * (20 + j) * (k + s) / n)
 nb2 = 640 * 32
 raw2 = np.tile(synth.quantise_iq(x2), nb2 // 640).tobytes()
-det = Detector(st, block_data.RawStream(io.BytesIO(raw2), n, h), batch_size=2048)
+tmp2 = tempfile.NamedTemporaryFile(suffix=".bin", delete=False)
+tmp2.write(raw2); tmp2.close()
+det = Detector(st, block_data.RawStream(open(tmp2.name, "rb"), n, h), batch_size=2048)
 det.only_detections = True
 t0 = time.perf_counter()
 cnt = sum(1 for d, r in det if d)
 dt = time.perf_counter() - t0
 print("%-30s %8.0f blocks/s (%d detections, %.1f MB stream, %.1f MS/s)" % (
-    "sparse, detections only", nb2 / dt, cnt, len(raw2) / 1e6, nb2 * new / dt / 1e6))
+    "sparse file, detections only", nb2 / dt, cnt, len(raw2) / 1e6, nb2 * new / dt / 1e6))

@@ -307,3 +307,56 @@ def test_rawstream_batches_frame_like_block_reader(n, h):
     # plain iteration is block_reader
     again = list(block_data.RawStream(io.BytesIO(data), n, h))
     assert len(again) == len(ref) and all(np.array_equal(a[2], b[2]) for a, b in zip(again, ref))
+
+
+def test_batch_readers_map_regular_files(tmp_path):
+    """A regular file is framed straight out of an mmap (no read buffer); the batches are the
+    same as through the buffered path a pipe takes."""
+    import io
+    import mmap
+    rng = np.random.default_rng(11)
+    for n, h in [(64, 16), (64, 40), (64, 0), (64, 62)]:
+        data = rng.integers(0, 256, size=2 * (n - h) * 23 + 5, dtype=np.uint8).tobytes()
+        path = tmp_path / ("r_%d_%d.bin" % (n, h))
+        path.write_bytes(data)
+
+        def collect(src):
+            rs, out = block_data.RawStream(src, n, h), []
+            while True:
+                batch = rs.next_batch(5)
+                if batch is None:
+                    return out, rs
+                kind, _, idx, payload = batch
+                if kind == "c64":
+                    out += [(int(i), np.array(x)) for i, x in zip(idx, payload)]
+                else:
+                    a = np.frombuffer(payload, dtype=np.uint8)
+                    step = 2 * (n - h)
+                    out += [(int(i), block_data.raw_to_complex(a[j * step: j * step + 2 * n]))
+                            for j, i in enumerate(idx)]
+        buffered, rb = collect(io.BytesIO(data))
+        with open(path, "rb") as f:
+            mapped, rm = collect(f)
+        assert rb._map is None and isinstance(rm._map, mmap.mmap)
+        assert len(buffered) == len(mapped)
+        assert all(a[0] == b[0] and np.array_equal(a[1], b[1]) for a, b in zip(buffered, mapped))
+    n = 256
+    blocks = [rng.integers(0, 256, size=2 * n, dtype=np.uint8) for _ in range(9)]
+    text = "# hdr\nUsing Volk machine: x\n\n" + "".join(
+        block_data.card_line(10.0 + i, i * 3, blocks[i]) for i in range(9))
+    text = text.replace("\n", "\r\n", 3).encode()
+    (tmp_path / "c.card").write_bytes(text)
+
+    def card_collect(src):
+        cs, out = block_data.CardStream(src, n), []
+        while True:
+            batch = cs.next_batch(4)
+            if batch is None:
+                return out, cs
+            stamps, idx, buf, offs = batch
+            out += [(s, int(i), bytes(buf[o:o + cs.payload_chars])) for s, i, o in zip(stamps, idx, offs)]
+    a, _ = card_collect(io.BytesIO(text))
+    with open(tmp_path / "c.card", "rb") as f:
+        b, cm = card_collect(f)
+        assert isinstance(cm._buf, mmap.mmap)
+    assert a == b and len(a) == 9

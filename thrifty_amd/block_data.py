@@ -9,6 +9,9 @@ so the GPU engine can ingest 2 bytes/sample instead of 8 (the conversion
 from __future__ import annotations
 
 import base64
+import mmap
+import os
+import stat
 import time
 
 import numpy as np
@@ -102,6 +105,20 @@ def card_reader(stream):
         yield float(timestamp), int(idx), IQBlock(raw_to_complex(raw), raw)
 
 
+def _map_regular_file(stream):
+    """mmap of `stream` if it is a regular, seekable, non-empty binary file (else None): the
+    batch readers then frame records straight out of the page cache and the H2D copy is the
+    only pass over the bytes."""
+    try:
+        fd = stream.fileno()
+        st = os.fstat(fd)
+        if not stat.S_ISREG(st.st_mode) or st.st_size == 0 or "b" not in getattr(stream, "mode", "b"):
+            return None, 0
+        return mmap.mmap(fd, 0, access=mmap.ACCESS_READ), stream.tell()
+    except (AttributeError, OSError, ValueError):
+        return None, 0
+
+
 class CardStream(object):
     """Batch-oriented .card reader for the GPU engine.
 
@@ -120,6 +137,10 @@ class CardStream(object):
         self.chunk_bytes = max(int(chunk_bytes), 2 * line_max)
         # ONE reusable buffer: refills move the unconsumed tail (< one line) to the front and
         # read the next chunk in place -- no per-chunk reallocation / concatenation copies
+        mapped, at = _map_regular_file(stream)
+        if mapped is not None:       # regular file: the whole text is "already read"
+            self._buf, self._pos, self._end, self._eof = mapped, at, len(mapped), True
+            return
         self._buf = bytearray(self.chunk_bytes)
         self._pos = 0   # first unconsumed byte
         self._end = 0   # one past the last valid byte
@@ -186,7 +207,7 @@ class CardStream(object):
             stop = end - 1 if end > start and buf[end - 1] == 0x0D else end
             if stop <= start or buf[start] == 0x23:      # blank or '#'
                 continue
-            if buf.startswith(b"Using Volk machine:", start) or buf.startswith(b"linux;", start):
+            if buf[start:start + 19] == b"Using Volk machine:" or buf[start:start + 6] == b"linux;":
                 continue
             sp1 = buf.find(b" ", start, stop)
             sp2 = buf.find(b" ", sp1 + 1, stop)
@@ -240,6 +261,9 @@ class RawStream(object):
         self._have = 2 * self.history
         self._consumed = 0      # bytes of the previous u8 batch still to be slid out
         self._eof = False
+        # regular file: overlapping blocks are plain slices of the mapping (no carry, no copy)
+        self._map, self._off = _map_regular_file(stream)
+        self._origin = self._off    # stream byte 0 (the caller may have consumed a header)
 
     def _read_upto(self, want_end, need_end=None):
         """Read until `need_end` valid bytes are buffered (default: want_end) or EOF, never
@@ -273,6 +297,8 @@ class RawStream(object):
               ("u8", stamps, idxs int64[n], memoryview of the bytes of n overlapping blocks),
               or None at EOF.  The u8 view aliases this reader's buffer: valid until the next call."""
         step, carry = 2 * self.new, 2 * self.history
+        if self._map is not None:
+            return self._next_batch_mapped(max_blocks, step, carry)
         self._slide(self._consumed)
         self._consumed = 0
         if self._next_idx < self._n_lead:
@@ -299,6 +325,31 @@ class RawStream(object):
         self._next_idx += n
         self._consumed = n * step
         return "u8", [time.time()] * n, idxs, memoryview(self._buf)[:carry + n * step]
+
+    def _next_batch_mapped(self, max_blocks, step, carry):
+        m, size = self._map, len(self._map)
+        if self._next_idx < self._n_lead:
+            blocks, idxs = [], []
+            while len(blocks) < max_blocks and self._next_idx < self._n_lead and self._off + step <= size:
+                chunk = np.frombuffer(m, dtype=np.uint8, count=step, offset=self._off)
+                self._lead = np.concatenate([self._lead[self.new:], raw_to_complex(chunk)])
+                blocks.append(self._lead)
+                idxs.append(self._next_idx)
+                self._next_idx += 1
+                self._off += step
+            if not blocks:
+                return None
+            return "c64", [time.time()] * len(blocks), np.asarray(idxs, dtype=np.int64), np.stack(blocks)
+        n = min(max_blocks, (size - self._off) // step)
+        if n <= 0:
+            return None
+        # block i of the batch starts `carry` bytes before its new samples; the lead-in has
+        # consumed at least `carry` bytes, so the slice never reaches before the stream's start
+        view = memoryview(m)[self._off - carry:self._off + n * step]
+        idxs = np.arange(self._next_idx, self._next_idx + n, dtype=np.int64)
+        self._next_idx += n
+        self._off += n * step
+        return "u8", [time.time()] * n, idxs, view
 
     def __iter__(self):
         return block_reader(self.stream, self.size, self.history)
