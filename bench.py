@@ -52,6 +52,9 @@ def parse_args():
                     help="default: reference Detector (the headline); preshift: the reference's "
                          "experimental PreshiftDetector (one fused kernel per block)")
     ap.add_argument("--preshift-num", type=int, default=21, help="bank size of --variant preshift")
+    ap.add_argument("--cpu-procs", type=int, default=0,
+                    help="n > 0: also time the CPU oracle on n worker processes (spawned; adds "
+                         "cpu_baseline.all_cores; off by default to keep the default run short)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="wall budget of the CPU baseline leg (0 disables)")
     return ap.parse_args()
@@ -125,6 +128,32 @@ def cpu_baseline(blocks_u8, idx, template, budget_s, gpu_rec, n_templates, presh
                       "oracle/thrifty_np.py (NumPy %s pocketfft + SciPy curve_fit), 1 thread, %.1f s"
                       % (done, np.__version__, dt),
             "parity_checked": done, "parity_mismatches": mism}
+
+
+def _oracle_worker(job):
+    """(spawned process) run the oracle over a slab of blocks; returns (n, seconds)."""
+    os.environ["OMP_NUM_THREADS"] = "1"
+    blocks, template = job
+    from oracle import thrifty_np as onp
+    orc = onp.OracleDetector(N_BLOCK, HISTORY, template, (0, 15, 0), (7, 110), (0, 15, 0))
+    t0 = time.perf_counter()
+    for i in range(len(blocks)):
+        orc.detect_u8(i, blocks[i])
+    return len(blocks), time.perf_counter() - t0
+
+
+def cpu_all_cores(blocks_u8, template, procs, per_proc=384):
+    """Oracle throughput with `procs` spawned workers, each over its own slab of the blocks."""
+    import multiprocessing as mp
+    jobs = [(blocks_u8[(i * per_proc) % len(blocks_u8):][:per_proc], template) for i in range(procs)]
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(procs) as pool:
+        pool.map(_oracle_worker, [(j[0][:4], template) for j in jobs])   # warm imports
+        t0 = time.perf_counter()
+        done = pool.map(_oracle_worker, jobs)
+        dt = time.perf_counter() - t0
+    n = sum(d[0] for d in done)
+    return {"value": n / dt, "unit": "blocks/s", "procs": procs, "blocks": n, "seconds": dt}
 
 
 def main():
@@ -281,6 +310,9 @@ def main():
             line["cpu_baseline"] = cpu_baseline(
                 data[:ns].cpu().numpy(), np.arange(first, first + ns), tpls[0], args.cpu_seconds,
                 rec.view(total, T, 64)[:ns, 0].cpu().numpy().view(F.RECORD_DTYPE).reshape(-1), T, pnum)
+            if args.cpu_procs > 0 and not pnum:
+                line["cpu_baseline"]["all_cores"] = cpu_all_cores(
+                    data[:ns].cpu().numpy(), tpls[0], args.cpu_procs)
         print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()
