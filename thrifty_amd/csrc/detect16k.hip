@@ -20,6 +20,7 @@
 #include "detect_common.hpp"
 #include "fft_regs.hpp"
 #include "kernel_util.hpp"
+#include "lmdif8.hpp"
 #include "passes_w8.hpp"
 
 namespace thr {
@@ -252,163 +253,9 @@ __global__ __launch_bounds__(NT) void k_carrier_pruned(const void* __restrict__ 
 }
 
 // =========================================================================
-// K_fit: 8 lanes per block (one per fitted point, lane 7 idles in the sums)
+// K_fit: 8 lanes per block (one per fitted point, lane 7 idles in the sums).  The fit itself
+// is MINPACK's lmdif as SciPy's curve_fit drives it (lmdif8.hpp).
 // =========================================================================
-__device__ __forceinline__ void dirichlet_eval(double u, double n, double w, double& d,
-                                               double& dd) {
-    // D(u) = sin(pi w u / n) / (w sin(pi u / n)),  dD/du
-    if (fabs(u) < 1e-12) {
-        d = 1.0;
-        dd = 0.0;
-        return;
-    }
-    double sw, cw, s1, c1;
-    sincospi(w * u / n, &sw, &cw);
-    sincospi(u / n, &s1, &c1);
-    const double pi = 3.14159265358979323846;
-    d = sw / (w * s1);
-    dd = (pi * w / n * cw * s1 - sw * pi / n * c1) / (w * s1 * s1);
-}
-
-// The fit evaluates D at u = x_j - o with x_j = j - 3 fixed per lane and only the offset o
-// moving, so the two sincospi calls per evaluation (~150 dependent fp64 instructions each,
-// and the fit is one long dependent chain: it bounds k_fit's latency) reduce to the angle
-// addition sin(a x - a o) = sin(a x) cos(a o) - cos(a x) sin(a o) with per-lane constants
-// and a short polynomial for the small angles a o (|pi w o / n| < 0.5 for any offset the
-// fit visits in practice; outside that the libm path takes over).
-struct DirichletLane {
-    double sa, ca;  // sin, cos(pi w x / n)
-    double sb, cb;  // sin, cos(pi x / n)
-};
-__device__ __forceinline__ DirichletLane dirichlet_lane(double x, double n, double w) {
-    DirichletLane c;
-    sincospi(w * x / n, &c.sa, &c.ca);
-    sincospi(x / n, &c.sb, &c.cb);
-    return c;
-}
-__device__ __forceinline__ void sincos_small(double x, double& sn, double& cs) {
-    if (fabs(x) < 0.5) {
-        // Taylor to x^17 / x^16: truncation < 2e-23 / 6e-22 on |x| < 0.5
-        const double z = x * x;
-        double ps = -1.0 / 355687428096000.0;                     // 1/17!
-        ps = fma(ps, z, 1.0 / 1307674368000.0);                   // 1/15!
-        ps = fma(ps, z, -1.0 / 6227020800.0);                     // 1/13!
-        ps = fma(ps, z, 1.0 / 39916800.0);                        // 1/11!
-        ps = fma(ps, z, -1.0 / 362880.0);                         // 1/9!
-        ps = fma(ps, z, 1.0 / 5040.0);
-        ps = fma(ps, z, -1.0 / 120.0);
-        ps = fma(ps, z, 1.0 / 6.0);
-        sn = fma(-x * z, ps, x);
-        double pc = 1.0 / 20922789888000.0;                       // 1/16!
-        pc = fma(pc, z, -1.0 / 87178291200.0);                    // 1/14!
-        pc = fma(pc, z, 1.0 / 479001600.0);                       // 1/12!
-        pc = fma(pc, z, -1.0 / 3628800.0);                        // 1/10!
-        pc = fma(pc, z, 1.0 / 40320.0);
-        pc = fma(pc, z, -1.0 / 720.0);
-        pc = fma(pc, z, 1.0 / 24.0);
-        pc = fma(pc, z, -0.5);
-        cs = fma(pc, z, 1.0);
-    } else {
-        sincos(x, &sn, &cs);
-    }
-}
-// D and dD/du at u = x - o for the lane whose constants are `c`
-__device__ __forceinline__ void dirichlet_eval_at(const DirichletLane& c, double x, double o,
-                                                  double n, double w, double& d, double& dd) {
-    if (fabs(x - o) < 1e-12) {
-        d = 1.0;
-        dd = 0.0;
-        return;
-    }
-    const double pi = 3.14159265358979323846;
-    double so, co, se, ce;
-    sincos_small(pi * w / n * o, so, co);
-    sincos_small(pi / n * o, se, ce);
-    const double sw = c.sa * co - c.ca * so, cw = c.ca * co + c.sa * so;
-    const double s1 = c.sb * ce - c.cb * se, c1 = c.cb * ce + c.sb * se;
-    d = sw / (w * s1);
-    dd = (pi * w / n * cw * s1 - sw * pi / n * c1) / (w * s1 * s1);
-}
-
-// Sum over the 8-lane group, bitwise identical in all 8 lanes, on the DPP path
-// (quad_perm xor 1, xor 2, then row_half_mirror: i <-> 7-i) -- three VALU-speed steps
-// instead of ds_bpermute round trips (the fit is a chain of ~50 dependent group sums).
-// Each step adds the same two operands in both partners, so all lanes agree bit for
-// bit PROVIDED nothing gets contracted into the adds: with HIP's default
-// -ffp-contract=fast the caller's `x*x` is fused into the first add as fma(x, x, partner)
-// on one side and fma(y, y, ...) on the other, partner lanes then differ by an ulp, and
-// an accept/reject decision in the LM loop eventually flips in some lanes only.
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-    const unsigned long long u = __double_as_longlong(v);
-    const unsigned lo = dpp_u32<CTRL, 0xf>(0u, (unsigned)u);
-    const unsigned hi = dpp_u32<CTRL, 0xf>(0u, (unsigned)(u >> 32));
-    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
-}
-__device__ __forceinline__ double group8_sum(double v) {
-#pragma clang fp contract(off)
-    asm volatile("" : "+v"(v));  // materialise the operand: nothing upstream may fuse into the adds
-    v = v + dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
-    v = v + dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
-    v = v + dpp_f64<0x141>(v);  // row_half_mirror
-    return v;
-}
-
-// Levenberg-Marquardt on f_j(A, o) = A * |D(x_j - o)|, x_j = j - 3, from
-// p0 = (y[3], 0) -- same model and start as carrier_sync.py:179-194.  Lane j of
-// the 8-lane group owns point j; every lane follows the same control flow.
-__device__ inline double dirichlet_fit8(float yj, float y_peak, int j, double n, double w) {
-    const bool live = j < 7;
-    const double y = live ? (double)yj : 0.0;
-    const double x = double(j - 3);
-    double A = y_peak, o = 0.0, lambda = 1e-3;
-    const DirichletLane lane = dirichlet_lane(x, n, w);
-    auto cost_of = [&](double a, double off) {
-        double d, dd;
-        dirichlet_eval_at(lane, x, off, n, w, d, dd);
-        const double r = live ? y - a * fabs(d) : 0.0;
-        return group8_sum(r * r);
-    };
-    double cost = cost_of(A, o);
-#ifndef THR_FIT_MAXIT
-#define THR_FIT_MAXIT 60
-#endif
-    for (int it = 0; it < THR_FIT_MAXIT; ++it) {
-        double d, dd;
-        dirichlet_eval_at(lane, x, o, n, w, d, dd);
-        const double fa = live ? fabs(d) : 0.0;                       // df/dA
-        const double fo = live ? -A * (d < 0 ? -1.0 : 1.0) * dd : 0.0;  // df/do (u = x - o)
-        const double r = live ? y - A * fa : 0.0;
-        const double jaa = group8_sum(fa * fa), jao = group8_sum(fa * fo),
-                     joo = group8_sum(fo * fo), ga = group8_sum(fa * r), go = group8_sum(fo * r);
-        bool accepted = false;
-        double dA = 0, dO = 0;
-        for (int tries = 0; tries < 12 && !accepted; ++tries) {
-            const double a11 = jaa * (1 + lambda), a22 = joo * (1 + lambda), a12 = jao;
-            const double det = a11 * a22 - a12 * a12;
-            if (!(fabs(det) > 0)) {
-                lambda *= 10;
-                continue;
-            }
-            dA = (a22 * ga - a12 * go) / det;
-            dO = (a11 * go - a12 * ga) / det;
-            const double c2 = cost_of(A + dA, o + dO);
-            if (c2 <= cost) {
-                A += dA;
-                o += dO;
-                cost = c2;
-                lambda = fmax(lambda * 0.1, 1e-15);
-                accepted = true;
-            } else {
-                lambda *= 10;
-            }
-        }
-        if (!accepted) break;
-        if (fabs(dO) < 1e-11 && fabs(dA) <= 1e-11 * fabs(A)) break;
-    }
-    return o;
-}
-
 __global__ __launch_bounds__(64) void k_fit(int n_blocks, DevCfg cfg,
                                             const CarStats* __restrict__ stats,
                                             const long long* __restrict__ block_idx,
@@ -446,8 +293,8 @@ __global__ __launch_bounds__(64) void k_fit(int n_blocks, DevCfg cfg,
     // the fit is group-uniform only if `detected` is; it is (same inputs in all 8 lanes)
     if (detected) {
         flags |= THR_FLAG_CARRIER;
-        offset = dirichlet_fit8(st->nb[j < 7 ? j : 6], st->nb[3], j, double(n),
-                                double(cfg.carrier_len));
+        offset = lmdif_dirichlet8(st->nb[j < 7 ? j : 6], st->nb[3], j, double(n),
+                                  double(cfg.carrier_len));
 #ifdef THR_DEBUG_FIT
         {
             double lo = offset, hi = offset;
