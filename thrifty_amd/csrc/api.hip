@@ -125,6 +125,7 @@ struct thr_handle {
     int* d_ncompact = nullptr;
     // PreshiftDetector variant (thr_create_preshift): bank of pre-shifted template spectra
     int preshift_num = 0;       // 0 = default detector
+    float2* d_gtw = nullptr;    // optional combined twiddle table (THR_GTW)
     float2* d_bank = nullptr;   // [num][N]; 16384: [k3][k1][k2] gather layout, else natural order
     // .card ingest staging (lazy)
     unsigned char* d_text = nullptr;
@@ -211,6 +212,17 @@ int build_constants(thr_handle* h) {
             tab[1536 + k1 * 32 + mp] = unit_root((long long)k1 * mp, h->lng ? 16384 : n);
     HIP_TRY(hipMalloc(&h->d_tables, tab.size() * sizeof(float2)));
     HIP_TRY(hipMemcpy(h->d_tables, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice));
+    // --- pass-1 / pass-B twiddles W_16384^(k1 q) of k_correlate as one L2-resident table in
+    //     global memory (THR_GTW=0: the factored LDS tables A[k1][n2] * Bt[k1][m'] instead)
+    h->dev.gtw = nullptr;
+    if (h->fast && !h->w16 && !(getenv("THR_GTW") && atoi(getenv("THR_GTW")) == 0)) {
+        std::vector<float2> g(16 * 1024);
+        for (int k1 = 0; k1 < 16; ++k1)
+            for (int q = 0; q < 1024; ++q) g[k1 * 1024 + q] = unit_root((long long)k1 * q, 16384);
+        HIP_TRY(hipMalloc(&h->d_gtw, g.size() * sizeof(float2)));
+        HIP_TRY(hipMemcpy(h->d_gtw, g.data(), g.size() * sizeof(float2), hipMemcpyHostToDevice));
+        h->dev.gtw = h->d_gtw;
+    }
     // --- full-length root table for the shift phasor
     std::vector<float2> tw(n);
     for (int j = 0; j < n; ++j) tw[j] = unit_root(j, n);
@@ -693,7 +705,7 @@ void thr_destroy(thr_handle* h) {
         hipEventDestroy(e.a);
         hipEventDestroy(e.b);
     }
-    void* bufs[] = {h->d_tables, h->d_twn, h->d_tspec, h->d_stats, h->d_shifts, h->d_corr_stats, h->d_text, h->d_payload_off, h->d_bad, h->d_gen_scratch, h->d_tspec_nat, h->d_bank, h->d_win_pow, h->d_partial, h->d_partial_x2, h->d_dsub, h->d_work_list,
+    void* bufs[] = {h->d_tables, h->d_twn, h->d_tspec, h->d_stats, h->d_shifts, h->d_corr_stats, h->d_text, h->d_payload_off, h->d_bad, h->d_gen_scratch, h->d_tspec_nat, h->d_bank, h->d_gtw, h->d_win_pow, h->d_partial, h->d_partial_x2, h->d_dsub, h->d_work_list,
                     h->d_work_count, h->d_xhat_scratch, h->d_ncompact, h->d_in, h->d_idx, h->d_rec};
     for (void* b : bufs)
         if (b) hipFree(b);

@@ -2,6 +2,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// (Measured, not adopted: `__attribute__((amdgpu_waves_per_eu(2, 2)))` on the LDS-resident
+// kernels -- it tells the compiler that only 2 waves per SIMD can ever be resident, which
+// they are, one 512-thread workgroup per CU -- raised k_correlate from 119 to 238 VGPRs but
+// did not make it faster: 0.55 ms per 8192 blocks either way; pruned carrier kernel -2 %,
+// long-block correlate +13 %.)
+
 namespace thr {
 
 // Thread id the optimiser cannot see through: stops LICM from hoisting every

@@ -83,10 +83,14 @@ struct RawSamples<THR_IN_C64> {
 // ------------------------------------------------------------ forward passes
 // Pass 1 (radix 16 over n1, two adjacent m per thread) -> LDS.
 // If PH: pre-rotate x[n1] by rpow[n1] and fold the per-m phasor p0/p1 into the twiddle.
+// gtw (optional): W_16384^(k1 * q), [16][1024], in global memory (L2-resident): the twiddle
+// of output k1 for the thread's two points is ONE coalesced 16-byte load instead of two LDS
+// reads and a complex product A[k1][n2] * Bt[k1][m'].
 template <bool PH, class RAW>
 __device__ __forceinline__ void fwd_pass1(cpx* lds, const RAW& raw,
                                           const float2* __restrict__ rpow, cpx p0, cpx p1,
-                                          float* energy = nullptr) {
+                                          float* energy = nullptr,
+                                          const cpx* __restrict__ gtw = nullptr) {
     const int t = opaque_tid();
     cpx v0[R1], v1[R1];
     float e = 0.f;
@@ -117,10 +121,17 @@ __device__ __forceinline__ void fwd_pass1(cpx* lds, const RAW& raw,
                 y1 = cmul(y1, p1);
             }
         } else {
-            const cpx a = tA[k1 * 32 + n2];
-            const f4 bb = *reinterpret_cast<const f4*>(tB + k1 * 32 + mp);
-            cpx w0 = cmul(a, cpx{bb.x, bb.y});
-            cpx w1 = cmul(a, cpx{bb.z, bb.w});
+            cpx w0, w1;
+            if (gtw != nullptr) {
+                const f4 ww = reinterpret_cast<const f4*>(gtw)[k1 * 512 + t];
+                w0 = cpx{ww.x, ww.y};
+                w1 = cpx{ww.z, ww.w};
+            } else {
+                const cpx a = tA[k1 * 32 + n2];
+                const f4 bb = *reinterpret_cast<const f4*>(tB + k1 * 32 + mp);
+                w0 = cmul(a, cpx{bb.x, bb.y});
+                w1 = cmul(a, cpx{bb.z, bb.w});
+            }
             if constexpr (PH) {
                 w0 = cmul(w0, p0);
                 w1 = cmul(w1, p1);
@@ -192,13 +203,27 @@ __device__ __forceinline__ void inv_passA(cpx* lds, cpx* z) {
 
 // Pass B (radix 32 over k2, in place) -- thread (k1 = t>>5, n3 = t&31);
 // twiddle conj(W_N^(k1*(32*n2 + n3))) = conj(A[k1][n2] * Bt[k1][n3]).
-__device__ __forceinline__ void inv_passB(cpx* lds) {
+__device__ __forceinline__ void inv_passB(cpx* lds, const cpx* __restrict__ gtw = nullptr) {
     const int t = opaque_tid();
     const int k1 = t >> 5, n3 = t & 31;
     cpx* base = lds + k1 * ROW + n3;
     cpx v[R2];
 #pragma unroll
     for (int k2 = 0; k2 < R2; ++k2) v[k2] = base[k2 * CHUNK];
+    if (gtw != nullptr) {
+        // twiddles W_N^(k1 (32 n2 + n3)) straight from the L2-resident table: issued before the
+        // butterfly, consumed after it
+        const cpx* tw = gtw + k1 * 1024 + n3;
+        cpx w[R2];
+#pragma unroll
+        for (int n2 = 0; n2 < R2; ++n2) w[n2] = tw[n2 * 32];
+        dft_dif<R2, +1>(v);
+        static_for<R2>([&](auto K) {
+            constexpr int n2 = decltype(K)::value;
+            base[n2 * CHUNK] = cmulc(v[brev(n2, R2)], w[n2]);
+        });
+        return;
+    }
     dft_dif<R2, +1>(v);
     const cpx b = lds[OFF_B + k1 * 32 + n3];
     const cpx* tA = lds + OFF_A + k1 * 32;
