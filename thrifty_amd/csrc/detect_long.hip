@@ -448,13 +448,14 @@ __global__ __launch_bounds__(NT) void k_correlate_sub(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cpx* lds = reinterpret_cast<cpx*>(smem_raw);
     unsigned char* sc_red = reinterpret_cast<unsigned char*>(lds + OFF_S);
-    float2* sc_rp = reinterpret_cast<float2*>(sc_red + 2 * red_slot_bytes<NT / 64>());
-    float2* sc_g = sc_rp + 16;
+    float2* sc_rp0 = reinterpret_cast<float2*>(sc_red + 2 * red_slot_bytes<NT / 64>());  // 2 x (16 + R0)
 
     load_tables(lds, tables);
     __syncthreads();
     const int NL = R0 * M, nl_mask = NL - 1;
     const size_t blk_bytes = cfg.blk_stride;
+    cpx ph[2] = {cpx{1.f, 0.f}, cpx{1.f, 0.f}};
+    int ph_block = -1;
     // this launch owns work-list slots [slot_base, slot_base + slot_cap): the correlate stage
     // runs in chunks small enough for the d_k0 exchange to stay in the Infinity Cache
     // (`work_list` already points at slot_base)
@@ -472,19 +473,26 @@ __global__ __launch_bounds__(NT) void k_correlate_sub(
         const int b = work_list[slot];
         const int t = opaque_tid();
         const ShiftParams* sp = shifts + b;
-        __syncthreads();
+        // item factors are double-buffered: this item's writers cannot collide with the previous
+        // item's readers, and the buffer written two items ago has barriers in between
+        float2* sc_rp = sc_rp0 + (it & 1) * (16 + R0);
+        float2* sc_g = sc_rp + 16;
         item_factors<R0>(sc_rp, sc_g, sp, twn, k0, nl_mask);
-        // per-thread phasor for m' = 2t, 2t+1: c0 * exp(2 pi i s m'/NL) * W_NL^(m' k0)
+        // per-thread phasor for m' = 2t, 2t+1: c0 * exp(2 pi i s m'/NL) [per block] * W_NL^(m' k0)
+        if (b != ph_block) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int m = 2 * t + e;
+                const int q = int(((long long)sp->si_mod * m) & nl_mask);
+                float sn, cs;
+                sincosf(6.283185307179586f * (sp->sf_over_n * float(m)), &sn, &cs);
+                ph[e] = cmul(cmul(cconj(twn[q]), cpx{cs, sn}), cpx{sp->c0.x, sp->c0.y});
+            }
+            ph_block = b;
+        }
         cpx p[2];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int m = 2 * t + e;
-            const int q = int(((long long)sp->si_mod * m) & nl_mask);
-            float sn, cs;
-            sincosf(6.283185307179586f * (sp->sf_over_n * float(m)), &sn, &cs);
-            const cpx ph = cmul(cmul(cconj(twn[q]), cpx{cs, sn}), cpx{sp->c0.x, sp->c0.y});
-            p[e] = cmul(ph, twn[(m * k0) & nl_mask]);
-        }
+        for (int e = 0; e < 2; ++e) p[e] = cmul(ph[e], twn[((2 * t + e) * k0) & nl_mask]);
         __syncthreads();
         RawLong<FMT, R0, true> raw{static_cast<const unsigned char*>(samples) + size_t(b) * blk_bytes,
                                    sc_g, t, k0};
@@ -511,26 +519,19 @@ __global__ __launch_bounds__(NT) void k_correlate_sub(
         block_reduce<1, NT / 64>(sums, tot, dummy, sc_red, parity);
         parity ^= 1;
         if (t == 0) partial_x2[size_t(slot) * R0 + k0] = (float)tot[0];
-        // park the spectrum (L2-resident scratch row of this workgroup): every template reuses it
-        f4* park = xhat_scratch + size_t(blockIdx.x) * (M / 2) + t;
-        static_for<R3 / 2>([&](auto J) {
-            constexpr int j = decltype(J)::value;
-            park[j * NT] = f4{xh[brev(2 * j, R3)].x, xh[brev(2 * j, R3)].y,
-                              xh[brev(2 * j + 1, R3)].x, xh[brev(2 * j + 1, R3)].y};
-        });
+        // the spectrum stays in registers across templates (64 VGPRs; parking it in an L2
+        // scratch row between templates measured slower, as in k_correlate)
         for (int tpl = 0; tpl < T; ++tpl) {
             const int t = opaque_tid();
-            park = xhat_scratch + size_t(blockIdx.x) * (M / 2) + t;
             const f4* ts = tspec + (size_t(tpl) * R0 + k0) * (M / 2) + t;
             cpx z[R3];
             static_for<R3 / 2>([&](auto J) {
                 constexpr int j = decltype(J)::value;
                 const f4 q = ts[j * NT];
-                const f4 xx = park[j * NT];
-                z[brev(2 * j, R3)] = cmul(cpx{xx.x, xx.y}, cpx{q.x, q.y});
-                z[brev(2 * j + 1, R3)] = cmul(cpx{xx.z, xx.w}, cpx{q.z, q.w});
+                z[brev(2 * j, R3)] = cmul(xh[brev(2 * j, R3)], cpx{q.x, q.y});
+                z[brev(2 * j + 1, R3)] = cmul(xh[brev(2 * j + 1, R3)], cpx{q.z, q.w});
             });
-            __syncthreads();  // tpl > 0: the previous pass-C reads of other waves are done
+            if (tpl > 0) __syncthreads();  // the previous template's pass-C reads of other waves are done
             inv_passA(lds, z);
             __builtin_amdgcn_sched_barrier(0);
             inv_passB(lds);
