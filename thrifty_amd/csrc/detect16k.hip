@@ -459,7 +459,9 @@ __global__ __launch_bounds__(NT) void k_correlate(
 
         THR_STAMP(1);
         // (the previous block's pass-C LDS reads all precede its reduction barrier)
-        fwd_pass1<true>(lds, cur, sp->rpow, p[0], p[1], nullptr, static_cast<const cpx*>(cfg.gtw));
+        // (multi-template: 64 more live VGPRs for the spectrum -- the L2-table path would spill)
+        const cpx* gtw = MULTI ? nullptr : static_cast<const cpx*>(cfg.gtw);
+        fwd_pass1<true>(lds, cur, sp->rpow, p[0], p[1], nullptr, gtw);
         cur = nxt;
         THR_STAMP(2);
         // The next block's phasor (root-table gather + sincosf, ~1 k cycles).  The older half of
@@ -564,7 +566,7 @@ __global__ __launch_bounds__(NT) void k_correlate(
             __builtin_amdgcn_sched_barrier(0);
             THR_STAMP(7);
             THR_ABLATE_AT(14, { __syncthreads(); continue; });
-            inv_passB(lds, static_cast<const cpx*>(cfg.gtw));
+            inv_passB(lds, gtw);
             THR_STAMP(8);
             __syncthreads();
             THR_STAMP(9);
