@@ -88,87 +88,123 @@ __device__ __forceinline__ double residual(const Point& p, double amp, double of
     return amp * fabs(d) - p.y;
 }
 
-// qrsolv for n = 2 (R upper triangular as r00 r01 r11, column permutation ipvt, diagonal
-// d[], right-hand side qtb[]): returns x[] and sdiag[] and the strict lower part s10.
-__device__ __forceinline__ void qrsolv2(double r00, double r01, double r11, const int* ipvt,
-                                        const double* d, const double* qtb, double* x,
-                                        double* sdiag, double& s10) {
+// Two-element vectors indexed by a run-time 0/1 (the column permutation): a select instead of
+// an indexed private array, which the compiler would place in scratch memory.
+struct V2 {
+    double a, b;
+    __device__ __forceinline__ double get(int i) const { return i ? b : a; }
+};
+
+// qrsolv for n = 2 (R upper triangular as r00 r01 r11, column permutation p0 -> {p0, 1 - p0},
+// diagonal d, right-hand side qtb): returns x, sdiag and the strict lower part s10.
+__device__ __forceinline__ void qrsolv2(double r00, double r01, double r11, int p0, V2 d, V2 qtb,
+                                        V2& x, V2& sdiag, double& s10) {
 #pragma clang fp contract(off)
-    // copy R^T into the lower triangle (r[i][j] = r[j][i]); save the diagonal in x
-    double rr[2][2] = {{r00, r01}, {r01, r11}};
-    double wa[2] = {qtb[0], qtb[1]};
-    x[0] = rr[0][0];
-    x[1] = rr[1][1];
-    for (int j = 0; j < 2; ++j) {
-        const int l = ipvt[j];
-        if (d[l] != 0.0) {
-            for (int k = j; k < 2; ++k) sdiag[k] = 0.0;
-            sdiag[j] = d[l];
-            double qtbpj = 0.0;
-            for (int k = j; k < 2; ++k) {
-                if (sdiag[k] == 0.0) continue;
+    // MINPACK copies R^T into the lower triangle, saves the diagonal, then eliminates the
+    // diagonal matrix D row by row with Givens rotations.  Written out for n = 2.
+    double rkk0 = r00, rkk1 = r11, r10 = r01;   // r[0][0], r[1][1], r[1][0] (= r[0][1] transposed)
+    double wa0 = qtb.a, wa1 = qtb.b;
+    const double x0 = r00, x1 = r11;
+    // MINPACK's two branches (cotangent / tangent form) do the same arithmetic on swapped
+    // roles; written with selects so that cs / sn stay in registers
+    auto givens = [](double rkk, double sd, double& cs, double& sn) {
+        const bool small = fabs(rkk) < fabs(sd);
+        const double ratio = small ? rkk / sd : sd / rkk;
+        const double first = 0.5 / sqrt(0.25 + 0.25 * (ratio * ratio));
+        const double second = first * ratio;
+        sn = small ? first : second;
+        cs = small ? second : first;
+    };
+    double sd0 = 0.0, sd1 = 0.0;
+    // ---- j = 0: l = ipvt[0]
+    {
+        const double dl = d.get(p0);
+        if (dl != 0.0) {
+            double s0 = dl, s1 = 0.0, qtbpj = 0.0;
+            // k = 0
+            if (s0 != 0.0) {
                 double cs, sn;
-                if (fabs(rr[k][k]) < fabs(sdiag[k])) {
-                    const double cotan = rr[k][k] / sdiag[k];
-                    sn = 0.5 / sqrt(0.25 + 0.25 * (cotan * cotan));
-                    cs = sn * cotan;
-                } else {
-                    const double tn = sdiag[k] / rr[k][k];
-                    cs = 0.5 / sqrt(0.25 + 0.25 * (tn * tn));
-                    sn = cs * tn;
-                }
-                rr[k][k] = cs * rr[k][k] + sn * sdiag[k];
-                const double temp = cs * wa[k] + sn * qtbpj;
-                qtbpj = -sn * wa[k] + cs * qtbpj;
-                wa[k] = temp;
-                for (int i = k + 1; i < 2; ++i) {
-                    const double t2 = cs * rr[i][k] + sn * sdiag[i];
-                    sdiag[i] = -sn * rr[i][k] + cs * sdiag[i];
-                    rr[i][k] = t2;
-                }
+                givens(rkk0, s0, cs, sn);
+                rkk0 = cs * rkk0 + sn * s0;
+                const double temp = cs * wa0 + sn * qtbpj;
+                qtbpj = -sn * wa0 + cs * qtbpj;
+                wa0 = temp;
+                const double t2 = cs * r10 + sn * s1;
+                s1 = -sn * r10 + cs * s1;
+                r10 = t2;
+            }
+            // k = 1
+            if (s1 != 0.0) {
+                double cs, sn;
+                givens(rkk1, s1, cs, sn);
+                rkk1 = cs * rkk1 + sn * s1;
+                const double temp = cs * wa1 + sn * qtbpj;
+                qtbpj = -sn * wa1 + cs * qtbpj;
+                wa1 = temp;
             }
         }
-        sdiag[j] = rr[j][j];
-        rr[j][j] = x[j];
+        sd0 = rkk0;
+        rkk0 = x0;
     }
+    // ---- j = 1: l = ipvt[1]
+    {
+        const double dl = d.get(1 - p0);
+        if (dl != 0.0) {
+            double s1 = dl, qtbpj = 0.0;
+            if (s1 != 0.0) {
+                double cs, sn;
+                givens(rkk1, s1, cs, sn);
+                rkk1 = cs * rkk1 + sn * s1;
+                const double temp = cs * wa1 + sn * qtbpj;
+                qtbpj = -sn * wa1 + cs * qtbpj;
+                wa1 = temp;
+            }
+        }
+        sd1 = rkk1;
+        rkk1 = x1;
+    }
+    (void)rkk0;
+    (void)rkk1;
     int nsing = 2;
-    for (int j = 0; j < 2; ++j) {
-        if (sdiag[j] == 0.0 && nsing == 2) nsing = j;
-        if (nsing < 2) wa[j] = 0.0;
+    if (sd0 == 0.0) nsing = 0;
+    if (nsing < 2) wa0 = 0.0;
+    if (sd1 == 0.0 && nsing == 2) nsing = 1;
+    if (nsing < 2) wa1 = 0.0;
+    // back substitution on the nsing x nsing leading block (lower part r10 holds s[1][0])
+    if (nsing == 2) {
+        wa1 = (wa1 - 0.0) / sd1;
+        wa0 = (wa0 - r10 * wa1) / sd0;
+    } else if (nsing == 1) {
+        wa0 = (wa0 - 0.0) / sd0;
     }
-    for (int k = 0; k < nsing; ++k) {
-        const int j = nsing - k - 1;
-        double sum = 0.0;
-        for (int i = j + 1; i < nsing; ++i) sum += rr[i][j] * wa[i];
-        wa[j] = (wa[j] - sum) / sdiag[j];
-    }
-    for (int j = 0; j < 2; ++j) x[ipvt[j]] = wa[j];
-    s10 = rr[1][0];
+    x = V2{p0 ? wa1 : wa0, p0 ? wa0 : wa1};   // x[ipvt[j]] = wa[j]
+    sdiag = V2{sd0, sd1};
+    s10 = r10;
 }
 
-// lmpar for n = 2: Levenberg-Marquardt parameter and step x[] for trust radius delta
-__device__ __forceinline__ void lmpar2(double r00, double r01, double r11, const int* ipvt,
-                                       const double* diag, const double* qtb, double delta,
-                                       double& par, double* x) {
+// lmpar for n = 2: Levenberg-Marquardt parameter and step x for trust radius delta
+__device__ __forceinline__ void lmpar2(double r00, double r01, double r11, int p0, V2 diag, V2 qtb,
+                                       double delta, double& par, V2& x) {
 #pragma clang fp contract(off)
-    const double r[2][2] = {{r00, r01}, {0.0, r11}};
-    double wa1[2], wa2[2], sdiag[2] = {0.0, 0.0};
+    const int p1 = 1 - p0;
+    // Gauss-Newton direction (rank-deficient R handled as MINPACK does)
+    double wa0 = qtb.a, wa1 = qtb.b;
     int nsing = 2;
-    for (int j = 0; j < 2; ++j) {
-        wa1[j] = qtb[j];
-        if (r[j][j] == 0.0 && nsing == 2) nsing = j;
-        if (nsing < 2) wa1[j] = 0.0;
+    if (r00 == 0.0) nsing = 0;
+    if (nsing < 2) wa0 = 0.0;
+    if (r11 == 0.0 && nsing == 2) nsing = 1;
+    if (nsing < 2) wa1 = 0.0;
+    if (nsing == 2) {
+        wa1 /= r11;
+        wa0 -= r01 * wa1;
+        wa0 /= r00;
+    } else if (nsing == 1) {
+        wa0 /= r00;
     }
-    for (int k = 0; k < nsing; ++k) {
-        const int j = nsing - k - 1;
-        wa1[j] /= r[j][j];
-        const double temp = wa1[j];
-        for (int i = 0; i < j; ++i) wa1[i] -= r[i][j] * temp;
-    }
-    for (int j = 0; j < 2; ++j) x[ipvt[j]] = wa1[j];
+    x = V2{p0 ? wa1 : wa0, p0 ? wa0 : wa1};   // x[ipvt[j]] = wa1[j]
     int iter = 0;
-    for (int j = 0; j < 2; ++j) wa2[j] = diag[j] * x[j];
-    double dxnorm = enorm2(wa2[0], wa2[1]);
+    V2 wa2{diag.a * x.a, diag.b * x.b};
+    double dxnorm = enorm2(wa2.a, wa2.b);
     double fp = dxnorm - delta;
     if (fp <= 0.1 * delta) {
         par = 0.0;   // iter == 0
@@ -176,24 +212,15 @@ __device__ __forceinline__ void lmpar2(double r00, double r01, double r11, const
     }
     double parl = 0.0;
     if (nsing >= 2) {
-        for (int j = 0; j < 2; ++j) {
-            const int l = ipvt[j];
-            wa1[j] = diag[l] * (wa2[l] / dxnorm);
-        }
-        for (int j = 0; j < 2; ++j) {
-            double sum = 0.0;
-            for (int i = 0; i < j; ++i) sum += r[i][j] * wa1[i];
-            wa1[j] = (wa1[j] - sum) / r[j][j];
-        }
-        const double temp = enorm2(wa1[0], wa1[1]);
+        double u0 = diag.get(p0) * (wa2.get(p0) / dxnorm), u1 = diag.get(p1) * (wa2.get(p1) / dxnorm);
+        u0 = (u0 - 0.0) / r00;
+        u1 = (u1 - r01 * u0) / r11;
+        const double temp = enorm2(u0, u1);
         parl = ((fp / delta) / temp) / temp;
     }
-    for (int j = 0; j < 2; ++j) {
-        double sum = 0.0;
-        for (int i = 0; i <= j; ++i) sum += r[i][j] * qtb[i];
-        wa1[j] = sum / diag[ipvt[j]];
-    }
-    const double gnorm = enorm2(wa1[0], wa1[1]);
+    const double g0 = (r00 * qtb.a) / diag.get(p0);
+    const double g1 = (r01 * qtb.a + r11 * qtb.b) / diag.get(p1);
+    const double gnorm = enorm2(g0, g1);
     double paru = gnorm / delta;
     if (paru == 0.0) paru = DWARF / fmin(delta, 0.1);
     par = fmax(par, parl);
@@ -203,23 +230,20 @@ __device__ __forceinline__ void lmpar2(double r00, double r01, double r11, const
         ++iter;
         if (par == 0.0) par = fmax(DWARF, 0.001 * paru);
         double temp = sqrt(par);
-        for (int j = 0; j < 2; ++j) wa1[j] = temp * diag[j];
+        const V2 dd{temp * diag.a, temp * diag.b};
+        V2 sdiag;
         double s10;
-        qrsolv2(r00, r01, r11, ipvt, wa1, qtb, x, sdiag, s10);
-        for (int j = 0; j < 2; ++j) wa2[j] = diag[j] * x[j];
-        dxnorm = enorm2(wa2[0], wa2[1]);
+        qrsolv2(r00, r01, r11, p0, dd, qtb, x, sdiag, s10);
+        wa2 = V2{diag.a * x.a, diag.b * x.b};
+        dxnorm = enorm2(wa2.a, wa2.b);
         temp = fp;
         fp = dxnorm - delta;
         if (fabs(fp) <= 0.1 * delta || (parl == 0.0 && fp <= temp && temp < 0.0) || iter == 10) break;
-        for (int j = 0; j < 2; ++j) {
-            const int l = ipvt[j];
-            wa1[j] = diag[l] * (wa2[l] / dxnorm);
-        }
-        // solve with the lower-triangular S^T: s00 = sdiag[0], s10, s11 = sdiag[1]
-        wa1[0] /= sdiag[0];
-        wa1[1] -= s10 * wa1[0];
-        wa1[1] /= sdiag[1];
-        temp = enorm2(wa1[0], wa1[1]);
+        double u0 = diag.get(p0) * (wa2.get(p0) / dxnorm), u1 = diag.get(p1) * (wa2.get(p1) / dxnorm);
+        u0 /= sdiag.a;
+        u1 -= s10 * u0;
+        u1 /= sdiag.b;
+        temp = enorm2(u0, u1);
         const double parc = ((fp / delta) / temp) / temp;
         if (fp > 0.0) parl = fmax(parl, par);
         if (fp < 0.0) paru = fmin(paru, par);
@@ -230,123 +254,128 @@ __device__ __forceinline__ void lmpar2(double r00, double r01, double r11, const
 }  // namespace lm
 
 // curve_fit(model, x = -3..3, y, p0 = (y[3], 0)) -> fitted offset.  `j` = this lane's point.
+// (Everything indexed by the column permutation is a V2 / an explicit pair: no private arrays
+// with run-time indices, which would live in scratch memory.)
 __device__ inline double lmdif_dirichlet8(float yj, float y_peak, int j, double n, double w) {
 #pragma clang fp contract(off)
     using namespace lm;
     const double ftol = 1.49012e-8, xtol = 1.49012e-8, factor = 100.0;
     const int maxfev = 600;   // 200 * (n + 1)
     Point pt{double(j - 3), double(yj), j < 7, n, w};
-    double x[2] = {double(y_peak), 0.0};
-    double fvec = residual(pt, x[0], x[1]);
+    V2 x{double(y_peak), 0.0};   // (amplitude, offset)
+    double fvec = residual(pt, x.a, x.b);
     int nfev = 1;
     double fnorm = enorm_lanes(fvec);
     double par = 0.0, delta = 0.0, xnorm = 0.0;
-    double diag[2] = {0.0, 0.0};
+    V2 diag{0.0, 0.0};
     int iter = 1, info = 0;
     const double eps = sqrt(EPSMCH);   // epsfcn = machine epsilon
     for (;;) {
-        // ---- fdjac2: forward differences, one column per parameter
-        double a[2];   // this lane's Jacobian row
-        for (int c = 0; c < 2; ++c) {
-            const double temp = x[c];
-            double h = eps * fabs(temp);
+        // ---- fdjac2: forward differences, one column per parameter (this lane's Jacobian row)
+        double a0, a1;
+        {
+            double h = eps * fabs(x.a);
             if (h == 0.0) h = eps;
-            x[c] = temp + h;
-            const double wa = residual(pt, x[0], x[1]);
-            x[c] = temp;
-            a[c] = (wa - fvec) / h;
+            a0 = (residual(pt, x.a + h, x.b) - fvec) / h;
+            h = eps * fabs(x.b);
+            if (h == 0.0) h = eps;
+            a1 = (residual(pt, x.a, x.b + h) - fvec) / h;
         }
         nfev += 2;
-        // ---- qrfac with column pivoting (rows = lanes)
-        int ipvt[2] = {0, 1};
-        double acnorm[2] = {enorm_lanes(a[0]), enorm_lanes(a[1])};
-        double rdiag[2] = {acnorm[0], acnorm[1]}, wa_n[2] = {acnorm[0], acnorm[1]};
-        const double acn[2] = {acnorm[0], acnorm[1]};   // wa2 of lmdif: norms in ORIGINAL column order
-        for (int c = 0; c < 2; ++c) {
-            int kmax = c;
-            for (int k = c; k < 2; ++k)
-                if (rdiag[k] > rdiag[kmax]) kmax = k;
-            if (kmax != c) {   // (only c == 0, kmax == 1 can happen)
-                const double t = a[c];
-                a[c] = a[kmax];
-                a[kmax] = t;
-                rdiag[kmax] = rdiag[c];
-                wa_n[kmax] = wa_n[c];
-                const int ti = ipvt[c];
-                ipvt[c] = ipvt[kmax];
-                ipvt[kmax] = ti;
-            }
-            const bool in_rows = j >= c;   // Householder acts on rows c..m-1
-            double ajnorm = enorm_lanes(in_rows ? a[c] : 0.0);
+        // ---- qrfac with column pivoting (rows = lanes); acn = column norms in ORIGINAL order
+        const double acn0 = enorm_lanes(a0), acn1 = enorm_lanes(a1);
+        double rd0, rd1 = acn1, wn1 = acn1;
+        int p0 = 0;   // ipvt = {p0, 1 - p0}
+        if (acn1 > acn0) {
+            const double t = a0;
+            a0 = a1;
+            a1 = t;
+            rd1 = acn0;
+            wn1 = acn0;
+            p0 = 1;
+        }
+        {   // column 0: Householder over rows 0..6, applied to column 1
+            double ajnorm = enorm_lanes(a0);
             if (ajnorm != 0.0) {
-                const double ajj = group8_get(a[c], c);
-                if (ajj < 0.0) ajnorm = -ajnorm;
-                if (in_rows) a[c] /= ajnorm;
-                if (j == c) a[c] += 1.0;
-                for (int k = c + 1; k < 2; ++k) {
-                    const double sum = group8_sum(in_rows ? a[c] * a[k] : 0.0);
-                    const double temp = sum / group8_get(a[c], c);
-                    if (in_rows) a[k] -= temp * a[c];
-                    if (rdiag[k] != 0.0) {
-                        const double t2 = group8_get(a[k], c) / rdiag[k];
-                        rdiag[k] *= sqrt(fmax(0.0, 1.0 - t2 * t2));
-                        const double q = rdiag[k] / wa_n[k];
-                        if (0.05 * (q * q) <= EPSMCH) {
-                            rdiag[k] = enorm_lanes(j > c ? a[k] : 0.0);
-                            wa_n[k] = rdiag[k];
-                        }
+                if (group8_get(a0, 0) < 0.0) ajnorm = -ajnorm;
+                a0 /= ajnorm;
+                if (j == 0) a0 += 1.0;
+                const double sum = group8_sum(a0 * a1);
+                const double temp = sum / group8_get(a0, 0);
+                a1 -= temp * a0;
+                if (rd1 != 0.0) {
+                    const double t2 = group8_get(a1, 0) / rd1;
+                    rd1 *= sqrt(fmax(0.0, 1.0 - t2 * t2));
+                    const double q = rd1 / wn1;
+                    if (0.05 * (q * q) <= EPSMCH) {
+                        rd1 = enorm_lanes(j > 0 ? a1 : 0.0);
+                        wn1 = rd1;
                     }
                 }
             }
-            rdiag[c] = -ajnorm;
+            rd0 = -ajnorm;
+        }
+        {   // column 1: Householder over rows 1..6
+            double ajnorm = enorm_lanes(j >= 1 ? a1 : 0.0);
+            if (ajnorm != 0.0) {
+                if (group8_get(a1, 1) < 0.0) ajnorm = -ajnorm;
+                if (j >= 1) a1 /= ajnorm;
+                if (j == 1) a1 += 1.0;
+            }
+            rd1 = -ajnorm;
         }
         // ---- first iteration: scaling and trust radius
         if (iter == 1) {
-            for (int c = 0; c < 2; ++c) diag[c] = acn[c] != 0.0 ? acn[c] : 1.0;
-            xnorm = enorm2(diag[0] * x[0], diag[1] * x[1]);
+            diag = V2{acn0 != 0.0 ? acn0 : 1.0, acn1 != 0.0 ? acn1 : 1.0};
+            xnorm = enorm2(diag.a * x.a, diag.b * x.b);
             delta = factor * xnorm;
             if (delta == 0.0) delta = factor;
         }
         // ---- (Q^T fvec)[0..1], R
-        double wa4 = fvec, qtf[2];
-        for (int c = 0; c < 2; ++c) {
-            const double acc = group8_get(a[c], c);
+        double wa4 = fvec;
+        V2 qtf;
+        {
+            const double acc = group8_get(a0, 0);
             if (acc != 0.0) {
-                const double sum = group8_sum(j >= c ? a[c] * wa4 : 0.0);
+                const double sum = group8_sum(a0 * wa4);
                 const double temp = -sum / acc;
-                if (j >= c) wa4 += a[c] * temp;
+                wa4 += a0 * temp;
             }
-            qtf[c] = group8_get(wa4, c);
+            qtf.a = group8_get(wa4, 0);
         }
-        const double r00 = rdiag[0], r01 = group8_get(a[1], 0), r11 = rdiag[1];
+        {
+            const double acc = group8_get(a1, 1);
+            if (acc != 0.0) {
+                const double sum = group8_sum(j >= 1 ? a1 * wa4 : 0.0);
+                const double temp = -sum / acc;
+                if (j >= 1) wa4 += a1 * temp;
+            }
+            qtf.b = group8_get(wa4, 1);
+        }
+        const double r00 = rd0, r01 = group8_get(a1, 0), r11 = rd1;
         // ---- scaled gradient norm
+        const double acn_p0 = p0 ? acn1 : acn0, acn_p1 = p0 ? acn0 : acn1;
         double gnorm = 0.0;
         if (fnorm != 0.0) {
-            for (int c = 0; c < 2; ++c) {
-                const int l = ipvt[c];
-                if (acn[l] != 0.0) {
-                    double sum = 0.0;
-                    if (c == 0) sum = r00 * (qtf[0] / fnorm);
-                    else sum = r01 * (qtf[0] / fnorm) + r11 * (qtf[1] / fnorm);
-                    gnorm = fmax(gnorm, fabs(sum / acn[l]));
-                }
-            }
+            if (acn_p0 != 0.0) gnorm = fmax(gnorm, fabs((r00 * (qtf.a / fnorm)) / acn_p0));
+            if (acn_p1 != 0.0)
+                gnorm = fmax(gnorm, fabs((r01 * (qtf.a / fnorm) + r11 * (qtf.b / fnorm)) / acn_p1));
         }
         if (gnorm <= 0.0) {   // gtol = 0
             info = 4;
             break;
         }
-        for (int c = 0; c < 2; ++c) diag[c] = fmax(diag[c], acn[c]);
+        diag = V2{fmax(diag.a, acn0), fmax(diag.b, acn1)};
         // ---- inner loop: step, ratio, trust-region update
         double ratio = 0.0;
         do {
-            double p[2];
-            lmpar2(r00, r01, r11, ipvt, diag, qtf, delta, par, p);
-            const double wa1[2] = {-p[0], -p[1]};
-            const double wa2[2] = {x[0] + wa1[0], x[1] + wa1[1]};
-            const double pnorm = enorm2(diag[0] * wa1[0], diag[1] * wa1[1]);
+            V2 p;
+            lmpar2(r00, r01, r11, p0, diag, qtf, delta, par, p);
+            const V2 wa1{-p.a, -p.b};
+            const V2 wa2{x.a + wa1.a, x.b + wa1.b};
+            const double pnorm = enorm2(diag.a * wa1.a, diag.b * wa1.b);
             if (iter == 1) delta = fmin(delta, pnorm);
-            const double fnew = residual(pt, wa2[0], wa2[1]);
+            const double fnew = residual(pt, wa2.a, wa2.b);
             ++nfev;
             const double fnorm1 = enorm_lanes(fnew);
             double actred = -1.0;
@@ -355,16 +384,9 @@ __device__ inline double lmdif_dirichlet8(float yj, float y_peak, int j, double 
                 actred = 1.0 - q * q;
             }
             // predicted reduction: R * P^T * step
-            double wa3[2] = {0.0, 0.0};
-            for (int c = 0; c < 2; ++c) {
-                const double temp = wa1[ipvt[c]];
-                if (c == 0) wa3[0] += r00 * temp;
-                else {
-                    wa3[0] += r01 * temp;
-                    wa3[1] += r11 * temp;
-                }
-            }
-            const double temp1 = enorm2(wa3[0], wa3[1]) / fnorm;
+            const double s0 = wa1.get(p0), s1 = wa1.get(1 - p0);
+            const double w30 = (0.0 + r00 * s0) + r01 * s1, w31 = r11 * s1;
+            const double temp1 = enorm2(w30, w31) / fnorm;
             const double temp2 = (sqrt(par) * pnorm) / fnorm;
             const double prered = temp1 * temp1 + (temp2 * temp2) / 0.5;
             const double dirder = -(temp1 * temp1 + temp2 * temp2);
@@ -379,10 +401,9 @@ __device__ inline double lmdif_dirichlet8(float yj, float y_peak, int j, double 
                 par = 0.5 * par;
             }
             if (ratio >= 1e-4) {
-                x[0] = wa2[0];
-                x[1] = wa2[1];
+                x = wa2;
                 fvec = fnew;
-                xnorm = enorm2(diag[0] * x[0], diag[1] * x[1]);
+                xnorm = enorm2(diag.a * x.a, diag.b * x.b);
                 fnorm = fnorm1;
                 ++iter;
             }
@@ -399,7 +420,7 @@ __device__ inline double lmdif_dirichlet8(float yj, float y_peak, int j, double 
         } while (ratio < 1e-4);
         if (info != 0) break;
     }
-    return x[1];
+    return x.b;
 }
 
 }  // namespace thr
