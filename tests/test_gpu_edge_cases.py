@@ -97,3 +97,39 @@ def test_constant_threshold_only(golden):
     eng = F.Engine(N, H, g["template"], cthr, (7, 110), (150.0 ** 2, 0.0, 0.0), max_batch=32)
     orc = onp.OracleDetector(N, H, g["template"], cthr, (7, 110), (150.0 ** 2, 0.0, 0.0))
     compare(eng.detect(g["blocks"])[:, 0], g["blocks"], orc)
+
+
+@pytest.mark.parametrize("n,bits,sps", [
+    (64, 4, 1.0),            # the smallest block the engine accepts (template 15 chips)
+    (1 << 20, 12, 8.0),      # the largest: 1 Mi samples per block, 32 760-sample template
+])
+def test_block_length_limits(n, bits, sps):
+    """thr_create's documented range [64, 2^20] at both ends, against the oracle."""
+    # (the Gold tables cover 5..11 bits: build +-1 codes of the wanted length directly)
+    tpl = np.repeat(np.sign(np.random.default_rng(bits).normal(0, 1, (1 << bits) - 1)), int(sps))
+    h = len(tpl) + 8
+    win = onp.unique_window(n, h, len(tpl))
+    rng = np.random.default_rng(n)
+    lo, hi = (3.2, 12.0) if n == 64 else (10.0, 100.0)
+    cwin = (2, 14) if n == 64 else (7, 110)
+    blocks, _ = synth.synth_blocks(rng, 3, n, tpl, win, signal_frac=1.0, carrier_bins=(lo, hi))
+    eng = F.Engine(n, h, tpl, (0, 8, 0), cwin, (0, 8, 0), max_batch=2)
+    rec = eng.detect(blocks, np.arange(3))[:, 0]
+    orc = onp.OracleDetector(n, h, tpl, (0, 8, 0), cwin, (0, 8, 0))
+    hits = 0
+    for i in range(3):
+        try:
+            (res,) = orc.detect_u8(i, blocks[i])
+        except IndexError:
+            assert rec[i]["flags"] & F.FLAG_INDEX_ERROR
+            continue
+        assert rec[i]["carrier_bin"] == res.carrier.bin
+        assert bool(rec[i]["flags"] & F.FLAG_CARRIER) == res.carrier.detected
+        if res.carrier.detected:
+            assert rec[i]["corr_sample"] == res.corr.sample
+            assert bool(rec[i]["flags"] & F.FLAG_CORR) == res.corr.detected
+            np.testing.assert_allclose(rec[i]["corr_energy"], res.corr.energy, rtol=2e-4)
+            hits += res.corr.detected
+    assert hits >= 1
+    with pytest.raises(F.NativeError):
+        F.Engine(n * 2 if n > 64 else 32, 8, np.ones(4), (0, 8, 0), (1, 3), (0, 8, 0))
