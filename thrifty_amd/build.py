@@ -12,8 +12,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libthriftyhip.so")
-SOURCES = ["api.hip", "detect16k.hip", "detect16k_w16.hip", "detect16k_preshift.hip", "detect_long.hip", "generic.hip", "card_ingest.hip", "identify.hip"]
-HEADERS = ["detect_common.hpp", "fft_regs.hpp", "kernel_util.hpp", "passes_w8.hpp", os.path.join("..", "..", "include", "thrifty_hip.h")]
+SOURCES = ["api.hip", "detect16k.hip", "detect16k_carrier.hip", "detect16k_w16.hip", "detect16k_preshift.hip", "detect_long.hip", "generic.hip", "card_ingest.hip", "identify.hip"]
+HEADERS = ["detect_common.hpp", "fft_regs.hpp", "kernel_util.hpp", "lmdif8.hpp", "passes_w8.hpp", os.path.join("..", "..", "include", "thrifty_hip.h")]
+# per-file code-generation flags (measured on MI355X, see csrc/detect16k_carrier.hip)
+PER_FILE_FLAGS = {"detect16k_carrier.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
 
 def _hipcc():
@@ -42,7 +44,8 @@ def build_native(force=False, verbose=False):
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
-               "-fno-slp-vectorize"] + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
+               "-fno-slp-vectorize"] + PER_FILE_FLAGS.get(src, []) + extra + [
+                   "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         jobs.append((subprocess.Popen(cmd), cmd, obj))   # the translation units build in parallel

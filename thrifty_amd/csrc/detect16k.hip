@@ -20,357 +20,11 @@
 #include "detect_common.hpp"
 #include "fft_regs.hpp"
 #include "kernel_util.hpp"
-#include "lmdif8.hpp"
 #include "passes_w8.hpp"
 
 namespace thr {
 
 using namespace k16;
-
-// =========================================================================
-// K_A: carrier stage
-// =========================================================================
-template <int FMT, bool WANT_STD, bool DUMP>
-__global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples, int n_blocks,
-                                                DevCfg cfg, const cpx* __restrict__ tables,
-                                                CarStats* __restrict__ stats,
-                                                cpx* __restrict__ dump_fft) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cpx* lds = reinterpret_cast<cpx*>(smem_raw);
-    unsigned char* sc_red = reinterpret_cast<unsigned char*>(lds + OFF_S);
-
-    load_tables(lds, tables);
-    __syncthreads();
-    // dev knob (THR_PRIO): waves w and w+4 share a SIMD and the older one finishes every phase
-    // ~35 % earlier; raising either half's priority was measured to change nothing here
-    if (cfg.prio_mode == 1 && threadIdx.x >= NT / 2) __builtin_amdgcn_s_setprio(1);
-    if (cfg.prio_mode == 2 && threadIdx.x < NT / 2) __builtin_amdgcn_s_setprio(1);
-    const size_t blk_bytes = cfg.blk_stride;  // dense: N * sample size; raw streams: 2 (N - H)
-    int parity = 0;
-
-    RawSamples<FMT> cur;
-    if (int(blockIdx.x) < n_blocks)
-        cur.load(static_cast<const unsigned char*>(samples) + size_t(blockIdx.x) * blk_bytes,
-                 opaque_tid());
-    for (int b = blockIdx.x; b < n_blocks; b += gridDim.x) {
-        // next block's samples: issued now, consumed one iteration later
-        RawSamples<FMT> nxt = cur;
-        if (b + int(gridDim.x) < n_blocks)
-            nxt.load(static_cast<const unsigned char*>(samples) + size_t(b + gridDim.x) * blk_bytes,
-                     opaque_tid());
-        // (previous block's pass-3 LDS reads all precede its reduction barrier)
-        fwd_pass1<false>(lds, cur, nullptr, cpx{}, cpx{});
-        cur = nxt;
-        __syncthreads();
-        THR_ABLATE_AT(1, continue);
-        // passes 2 and 3 of row k1 are done by the same half-wave: no barrier between them
-        fwd_pass2(lds);
-        __builtin_amdgcn_sched_barrier(0);  // keep the passes' register working sets apart
-        THR_ABLATE_AT(2, { __syncthreads(); continue; });
-        cpx v[R3];
-        fwd_pass3(lds, v);
-#ifdef THR_DEV_ABLATE
-        if (cfg.ablate == 3) {
-            float acc = 0;
-#pragma unroll
-            for (int i = 0; i < R3; ++i) acc += v[i].x + v[i].y;
-            if (acc == 1.2345f) stats[b].pad = 1;  // keep pass 3 alive
-            __syncthreads();
-            continue;
-        }
-#endif
-
-        // ---- statistics over the spectrum held in registers
-        const int t = opaque_tid();
-        const int kbase = (t >> 5) + 16 * (t & 31);
-        float sums[2] = {0.f, 0.f};
-        float pw[R3];
-        // first-max inside the (wrapping) window: lowest window index wins ties, and this
-        // thread's bins are visited in increasing k, which is increasing window index except
-        // across the wrap -- so compare (p, wi) lexicographically via '>' / '==' + '<'
-        float bestp = -1.0f;
-        unsigned bestwi = 0;
-        static_for<R3>([&](auto K) {
-            constexpr int k3 = decltype(K)::value;
-            const float p = cnorm(v[brev(k3, R3)]);
-            pw[k3] = p;
-            sums[0] += p;
-            if constexpr (WANT_STD) sums[1] += __builtin_amdgcn_sqrtf(p);
-            const unsigned wi = unsigned(kbase + 512 * k3 - cfg.win_lo) & unsigned(N - 1);
-            const bool take = wi < unsigned(cfg.win_count) &&
-                              (p > bestp || (p == bestp && wi < bestwi));
-            bestp = take ? p : bestp;
-            bestwi = take ? wi : bestwi;
-        });
-        unsigned long long best =
-            bestp < 0.f ? 0ull
-                        : ((unsigned long long)__float_as_uint(bestp) << 32) | (0xFFFFFFFFu - bestwi);
-        double tot[2];
-        block_reduce<WANT_STD ? 2 : 1, NT / 64>(reinterpret_cast<float(&)[WANT_STD ? 2 : 1]>(sums),
-                                       reinterpret_cast<double(&)[WANT_STD ? 2 : 1]>(tot), best,
-                                       sc_red, parity);
-        parity ^= 1;
-        const unsigned wi = 0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu);
-        int peak_idx = int(wi) + cfg.win_lo;
-        if (peak_idx > N) peak_idx -= N;  // sic: '>' (carrier_detect.py:151)
-        // 7-bin neighbourhood |X[peak-3..peak+3]| (indices wrap here; K_fit flags the cases
-        // where the reference would raise IndexError).  This thread's bins are
-        // kbase + 512*k3, so it holds neighbour d iff (kbase - peak + 3) mod 512 == d < 7,
-        // at k3 = -((kbase - peak + 3) >> 9) mod 32: exactly seven threads store one float.
-        CarStats* st = stats + b;
-        {
-            const unsigned u = unsigned(kbase - peak_idx + 3) & unsigned(N - 1);
-            const unsigned r = u & 511u, k3s = (32u - (u >> 9)) & 31u;
-            float val = 0.f;
-            static_for<R3>([&](auto K) {
-                constexpr int k3 = decltype(K)::value;
-                val = (k3s == unsigned(k3)) ? pw[k3] : val;
-            });
-            if (r < 7u) st->nb[r] = sqrtf(val);
-        }
-        if constexpr (DUMP) {
-            cpx* out = dump_fft + size_t(b) * N;
-            static_for<R3>([&](auto K) {
-                constexpr int k3 = decltype(K)::value;
-                out[kbase + 512 * k3] = v[brev(k3, R3)];
-            });
-        }
-        if (t == 0) {
-            st->sum_mag2 = (float)tot[0];
-            st->sum_mag = WANT_STD ? (float)tot[1] : 0.f;
-            st->peak_mag = sqrtf(__uint_as_float(unsigned(best >> 32)));
-            st->peak_idx = peak_idx;
-            st->pad = 0;
-        }
-    }
-}
-
-// =========================================================================
-// K_A, pruned: carrier window (plus the 3-bin fit margin) of at most 128 bins
-// =========================================================================
-// The carrier stage only ever looks at the bins of the window, +-3 neighbours for the
-// fit, and at sum |X|^2.  With the window inside [0,128) the needed bins are
-// k = k1 + 16*k2 with k2 < 8 and k3 = 0: pass 2 keeps 8 of its 32 outputs, pass 3
-// degenerates to a 32-term sum in 128 threads, and sum |X|^2 = N * sum |x|^2 (Parseval)
-// comes from the samples pass 1 already holds.  (Not usable with a stddev threshold
-// term, which needs every |X|: the launcher then picks the full kernel.)
-constexpr int PRUNE_K2 = 8;
-constexpr int PRUNE_BINS = R1 * PRUNE_K2;  // 128
-
-// SHIFTED: the window does not start near bin 0 -- multiply the samples by
-// exp(-2 pi i base n / N), base = win_lo - 3 (exact: an integer shift through the root
-// table), which moves spectrum bin `base + k'` to k'; the window then occupies
-// k' = 3 .. 3 + count - 1 and the same pruned transform applies to ANY window of at most
-// 122 bins (negative bins, wrap-around windows included).
-template <int FMT, bool SHIFTED>
-__global__ __launch_bounds__(NT) void k_carrier_pruned(const void* __restrict__ samples,
-                                                       int n_blocks, DevCfg cfg,
-                                                       const cpx* __restrict__ tables,
-                                                       const cpx* __restrict__ twn,
-                                                       CarStats* __restrict__ stats) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cpx* lds = reinterpret_cast<cpx*>(smem_raw);
-    unsigned char* sc_red = reinterpret_cast<unsigned char*>(lds + OFF_S);
-    float* sc_bins = reinterpret_cast<float*>(sc_red + 2 * red_slot_bytes<NT / 64>());  // [128] |X[k']|^2
-    float2* sc_rp = reinterpret_cast<float2*>(sc_bins + PRUNE_BINS);                     // [16]
-
-    load_tables(lds, tables);
-    // block-invariant shift factors: per sub-sequence n1 (LDS) and per thread (registers)
-    const int base = SHIFTED ? ((cfg.win_lo - 3) & (N - 1)) : 0;
-    const int win_off = SHIFTED ? 3 : cfg.win_lo;  // window start in the pruned bin domain
-    cpx ph[2] = {cpx{1.f, 0.f}, cpx{1.f, 0.f}};
-    if constexpr (SHIFTED) {
-        if (threadIdx.x < 16) {
-            const cpx r = twn[(threadIdx.x * 1024 * base) & (N - 1)];
-            sc_rp[threadIdx.x] = float2{r.x, r.y};
-        }
-#pragma unroll
-        for (int e = 0; e < 2; ++e) ph[e] = twn[((2 * int(threadIdx.x) + e) * base) & (N - 1)];
-    }
-    __syncthreads();
-    // dev knob (THR_PRIO): see k_carrier
-    if (cfg.prio_mode == 1 && threadIdx.x >= NT / 2) __builtin_amdgcn_s_setprio(1);
-    if (cfg.prio_mode == 2 && threadIdx.x < NT / 2) __builtin_amdgcn_s_setprio(1);
-    const size_t blk_bytes = cfg.blk_stride;  // dense: N * sample size; raw streams: 2 (N - H)
-    int parity = 0;
-
-    RawSamples<FMT> cur;
-    if (int(blockIdx.x) < n_blocks)
-        cur.load(static_cast<const unsigned char*>(samples) + size_t(blockIdx.x) * blk_bytes,
-                 opaque_tid());
-    for (int b = blockIdx.x; b < n_blocks; b += gridDim.x) {
-        RawSamples<FMT> nxt = cur;
-        if (b + int(gridDim.x) < n_blocks)
-            nxt.load(static_cast<const unsigned char*>(samples) + size_t(b + gridDim.x) * blk_bytes,
-                     opaque_tid());
-        float sums[1];
-        if constexpr (SHIFTED) {
-            cpx p0 = ph[0], p1 = ph[1];
-            asm volatile("" : "+v"(p0), "+v"(p1));  // keep the loop body free of hoisted products
-            fwd_pass1<true>(lds, cur, sc_rp, p0, p1, &sums[0]);
-        } else {
-            fwd_pass1<false>(lds, cur, nullptr, cpx{}, cpx{}, &sums[0]);
-        }
-        cur = nxt;
-        __syncthreads();
-        fwd_pass2<PRUNE_K2>(lds);
-        __builtin_amdgcn_sched_barrier(0);
-        // pass 3, output k3 = 0 only: the plain sum of the chunk; threads with k2 < 8
-        const int t = opaque_tid();
-        const int k2 = t & 31;
-        const int k = (t >> 5) + 16 * k2;  // pruned-domain bin (valid when k2 < PRUNE_K2)
-        unsigned long long best = 0;
-        if (k2 < PRUNE_K2) {
-            const f4* src = reinterpret_cast<const f4*>(lds + (t >> 5) * ROW + k2 * CHUNK);
-            f4 acc = src[0];
-#pragma unroll
-            for (int j = 1; j < R3 / 2; ++j) acc += src[j];
-            const cpx x = cpx{acc.x + acc.z, acc.y + acc.w};
-            const float p = cnorm(x);
-            sc_bins[k] = p;
-            const unsigned wi = unsigned(k - win_off) & unsigned(N - 1);
-            // the key carries |X| (not |X|^2): the reference takes argmax over float32 magnitudes,
-            // where powers an ulp apart can collide -- the first bin then wins, here as there
-            if (wi < unsigned(cfg.win_count))
-                best = ((unsigned long long)__float_as_uint(sqrtf(p)) << 32) | (0xFFFFFFFFu - wi);
-        }
-        double tot[1];
-        block_reduce<1, NT / 64>(sums, tot, best, sc_red, parity);
-        parity ^= 1;
-        const int wi = int(0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu));
-        int peak_idx = wi + cfg.win_lo;
-        if (peak_idx > N) peak_idx -= N;  // sic: '>' (carrier_detect.py:151)
-        CarStats* st = stats + b;
-        if (t < 7) st->nb[t] = sqrtf(sc_bins[wi + win_off - 3 + t]);
-        if (t == 0) {
-            st->sum_mag2 = (float)(tot[0] * double(N));  // Parseval
-            st->sum_mag = 0.f;
-            st->peak_mag = __uint_as_float(unsigned(best >> 32));
-            st->peak_idx = peak_idx;
-            st->pad = 0;
-        }
-    }
-}
-
-// =========================================================================
-// K_fit: 8 lanes per block (one per fitted point, lane 7 idles in the sums).  The fit itself
-// is MINPACK's lmdif as SciPy's curve_fit drives it (lmdif8.hpp).
-// =========================================================================
-__global__ __launch_bounds__(64) void k_fit(int n_blocks, DevCfg cfg,
-                                            const CarStats* __restrict__ stats,
-                                            const long long* __restrict__ block_idx,
-                                            ShiftParams* __restrict__ shifts,
-                                            int* __restrict__ work_list,
-                                            int* __restrict__ work_count,
-                                            thr_record* __restrict__ records) {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = gid & 7;
-    int b = gid >> 3;
-    const bool valid = b < n_blocks;
-    if (!valid) b = n_blocks - 1;  // keep the whole group in the shuffles
-    const CarStats* st = stats + b;
-    const int n = cfg.block_len;
-    const float peak_mag = st->peak_mag, sum_mag2 = st->sum_mag2;
-    const int peak_idx = st->peak_idx;
-    // float32 arithmetic on purpose: the reference's carrier statistics are
-    // float32 under NumPy >= 2 (carrier_detect.py:99-115)
-    const float peak_pow = peak_mag * peak_mag;
-    const float noise_pow = (sum_mag2 - 2.0f * peak_pow) / float(n - 1);
-    const float noise_rms = sqrtf(noise_pow);
-    float thr = cfg.car_thr[0] + cfg.car_thr[1] * (noise_rms * noise_rms);
-    if (cfg.car_want_std) {
-        const double m1 = double(st->sum_mag) / n, m2 = double(sum_mag2) / n;
-        thr += cfg.car_thr[2] * float(m2 - m1 * m1);
-    }
-    thr = sqrtf(thr);
-    bool detected = peak_mag > thr;
-    unsigned flags = 0;
-    double offset = 0.0;
-    if (detected && peak_idx + 3 >= n) {
-        flags |= THR_FLAG_INDEX_ERROR;  // carrier_sync.py:187 raises here
-        detected = false;
-    }
-    // the fit is group-uniform only if `detected` is; it is (same inputs in all 8 lanes)
-    if (detected) {
-        flags |= THR_FLAG_CARRIER;
-        offset = lmdif_dirichlet8(st->nb[j < 7 ? j : 6], st->nb[3], j, double(n),
-                                  double(cfg.carrier_len));
-#ifdef THR_DEBUG_FIT
-        {
-            double lo = offset, hi = offset;
-            for (int m = 1; m < 8; m <<= 1) {
-                lo = fmin(lo, __shfl_xor(lo, m, 64));
-                hi = fmax(hi, __shfl_xor(hi, m, 64));
-            }
-            if (hi != lo && j == 0) printf("fit disagreement blk %d: lo %.17g hi %.17g\n", b, lo, hi);
-        }
-#endif
-        // shift = -(bin + offset)  (carrier_sync.py:71)
-        const double s = -(double(peak_idx) + offset);
-        const double si = rint(s);
-        const int r1 = n >= 1024 ? n / 1024 : 1;  // first-pass radix of the LDS path (unused otherwise)
-        ShiftParams* sp = shifts + b;
-        if (valid) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int jj = 2 * j + q;
-                double a = s * double(jj) / double(r1);
-                a -= rint(a);
-                double sn, cs;
-                sincospi(2.0 * a, &sn, &cs);
-                sp->rpow[jj] = float2{float(cs), float(sn)};
-            }
-            if (j < 4 && n > 16384) {  // long blocks: phasor step between the R0 leading sub-sequences
-                double a = s * double(j) / double(n / 16384);
-                a -= rint(a);
-                double sn, cs;
-                sincospi(2.0 * a, &sn, &cs);
-                sp->r0pow[j] = float2{float(cs), float(sn)};
-            }
-            if (j == 0) {
-                double a = -0.5 * s;  // exp(2 pi i * s * (-1/2))
-                a -= rint(a);
-                double sn, cs;
-                sincospi(2.0 * a, &sn, &cs);
-                sp->c0 = float2{float(cs), float(sn)};
-                long long sim = (long long)si % n;
-                if (sim < 0) sim += n;
-                sp->si_mod = int(sim);
-                sp->sf_over_n = float((s - si) / double(n));
-            }
-        }
-    }
-    // work-list append, one atomic per wave (8 blocks) instead of one per block: 8192
-    // same-address atomics serialise in L2 and were most of this kernel's 30 us
-    {
-        const bool push = detected && valid && j == 0;
-        const unsigned long long m = __ballot(push);
-        if (m != 0) {
-            const int lane = threadIdx.x & 63;
-            const int leader = __ffsll((long long)m) - 1;
-            int base = 0;
-            if (lane == leader) base = atomicAdd(work_count, __popcll(m));
-            base = __shfl(base, leader, 64);
-            if (push) work_list[base + __popcll(m & ((1ull << lane) - 1ull))] = b;
-        }
-    }
-    if (valid && j < cfg.n_templates) {
-        thr_record r;
-        r.block_idx = block_idx ? block_idx[b] : (long long)b;
-        r.flags = flags;
-        r.template_id = j;
-        r.carrier_bin = peak_idx;
-        r.corr_sample = -1;
-        r.carrier_offset = offset;
-        r.corr_offset = 0.0;
-        r.carrier_energy = peak_mag;
-        r.carrier_noise = noise_rms;
-        r.corr_energy = 0.f;
-        r.corr_noise = 0.f;
-        r.reserved = 0;
-        records[size_t(b) * cfg.n_templates + j] = r;
-    }
-}
 
 // =========================================================================
 // K_B: shift + FFT#2 + matched filter + SoA
@@ -663,136 +317,19 @@ __global__ __launch_bounds__(NT) void k_correlate(
     }
 }
 
-// =========================================================================
-// K_finish: one lane per (block, template) -- noise, threshold verdict, sub-sample
-// offset (soa_estimator.py:108-170; float64 like the reference).  Kept out of
-// k_correlate so that no workgroup ever waits on one thread's log()/sqrt() chain.
-// =========================================================================
-__global__ __launch_bounds__(256) void k_finish(int n_records, DevCfg cfg,
-                                                const CorrStats* __restrict__ corr_stats,
-                                                thr_record* __restrict__ records,
-                                                int* __restrict__ work_count) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) {  // k_correlate is done with them: re-arm for the next batch
-        work_count[0] = 0;
-        work_count[1] = 0;  // dynamic-scheduling counter
-    }
-    if (i >= n_records) return;
-    thr_record* r = records + i;
-    if (!(r->flags & THR_FLAG_CARRIER)) return;
-    const int tpl = i % cfg.n_templates;
-    const CorrStats cs = corr_stats[i];
-    if (cfg.variant == 2) {
-        // fastdet-compatible verdict (fastdet/corr_detector.cpp:103-175): float32, power domain,
-        // noise clamped at 0 and -- sic -- computed from the peak power truncated to an integer
-        // (estimate_noise takes it as size_t); Gaussian offset on log sqrt(power), clipped +-0.5.
-#pragma clang fp contract(off)
-        const float peak_power = cs.pm2;
-        const float signal_energy = cs.sum_x2 / float(cfg.block_len);
-        const float signal_corr_energy = signal_energy * cfg.tmpl_energy[0];
-        float noise_power =
-            (signal_corr_energy - float((unsigned long long)peak_power)) / float(cfg.block_len);
-        if (noise_power < 0) noise_power = 0;
-        const float threshold = cfg.cor_thr[0] + cfg.cor_thr[1] * noise_power;
-        const bool hit = peak_power > threshold;
-        double o = 0.0;
-        if (hit && cs.pk != 0 && cs.pk != cfg.corr_len - 1) {
-            const double a = log(sqrt(double(cs.m2[0]))), b = log(sqrt(double(cs.m2[1]))),
-                         c = log(sqrt(double(cs.m2[2])));
-            o = (c - a) / (4 * b - 2 * a - 2 * c);
-            o = o < -0.5 ? -0.5 : o > 0.5 ? 0.5 : o;
-        }
-        r->corr_sample = cs.pk;
-        r->corr_offset = o;
-        r->corr_energy = sqrtf(peak_power);
-        r->corr_noise = sqrtf(noise_power);
-        if (hit) r->flags |= THR_FLAG_CORR;
-        return;
-    }
-    const double n = double(cfg.block_len);
-    const double xenergy = double(corr_stats[i - tpl].sum_x2) / n;  // mean |X^|^2
-    const double pm2 = double(cs.pm2);
-    const double peak_mag = sqrt(pm2);
-    const double noise_pow = (xenergy * double(cfg.tmpl_energy[tpl]) - pm2) / n;
-    const double noise_rms = sqrt(noise_pow);
-    double th = cfg.cor_thr[0] + cfg.cor_thr[1] * (noise_rms * noise_rms);
-    if (cfg.cor_want_std) {
-        const double m1 = double(cs.sum_mag) / cfg.corr_len, m2 = double(cs.sum_mag2) / cfg.corr_len;
-        th += cfg.cor_thr[2] * (m2 - m1 * m1);
-    }
-    th = sqrt(th);
-    const bool det = peak_mag > th;
-    double off = 0.0;
-    if (det && cs.pk != 0 && cs.pk != cfg.corr_len - 1) {
-        // log-parabola on magnitudes == the same formula on log |.|^2
-        const double la = log(double(cs.m2[0])), lb = log(double(cs.m2[1])),
-                     lc = log(double(cs.m2[2]));
-        off = 0.5 * (lc - la) / (2 * lb - la - lc);
-        off = off < -0.6 ? -0.6 : off > 0.6 ? 0.6 : off;
-    }
-    r->corr_sample = cs.pk;
-    r->corr_offset = off;
-    r->corr_energy = (float)peak_mag;
-    r->corr_noise = (float)noise_rms;
-    if (det) r->flags |= THR_FLAG_CORR;
-}
-
-// =========================================================================
-// K7: order-preserving compaction of detected records (single workgroup scan)
-// =========================================================================
-__global__ __launch_bounds__(1024) void k_compact(const thr_record* __restrict__ in, int n,
-                                                  thr_record* __restrict__ out,
-                                                  int* __restrict__ n_out) {
-    __shared__ int wsum[16];
-    __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + threadIdx.x;
-        const bool keep = i < n && (in[i].flags & THR_FLAG_CORR);
-        const unsigned long long mask = __ballot(keep);
-        const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
-        if (lane == 0) wsum[wv] = __popcll(mask);
-        __syncthreads();
-        int woff = 0, total = 0;
-        for (int w = 0; w < 16; ++w) {
-            if (w < wv) woff += wsum[w];
-            total += wsum[w];
-        }
-        const int c = carry;
-        if (keep) out[c + woff + prefix] = in[i];
-        __syncthreads();
-        if (threadIdx.x == 0) carry = c + total;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *n_out = carry;
-}
-
 // ------------------------------------------------------------------ launchers
 size_t lds_bytes_16k() { return LDS_BYTES; }
 
 namespace {
-typedef void (*carrier_fn)(const void*, int, DevCfg, const cpx*, CarStats*, cpx*);
 typedef void (*correlate_fn)(const void*, DevCfg, const cpx*, const cpx*, const f4*,
                              const ShiftParams*, const int*, const int*, CorrStats*, thr_record*,
                              f4*, cpx*, cpx*, int);
 
 #ifdef THR_DEV_MINIMAL  // compile-time experiments only: one variant each, fast rebuilds
-carrier_fn carrier_variant(int, bool, bool) { return &k_carrier<THR_IN_U8, false, false>; }
 correlate_fn correlate_variant(int, bool, bool, bool) {
     return &k_correlate<THR_IN_U8, false, false, false>;
 }
 #else
-template <int FMT, bool STD>
-carrier_fn pick_carrier(bool dump) {
-    return dump ? &k_carrier<FMT, STD, true> : &k_carrier<FMT, STD, false>;
-}
-carrier_fn carrier_variant(int fmt, bool want_std, bool dump) {
-    if (fmt == THR_IN_U8)
-        return want_std ? pick_carrier<THR_IN_U8, true>(dump) : pick_carrier<THR_IN_U8, false>(dump);
-    return want_std ? pick_carrier<THR_IN_C64, true>(dump) : pick_carrier<THR_IN_C64, false>(dump);
-}
 template <int FMT, bool STD, bool MULTI>
 correlate_fn pick_correlate(bool dump) {
     return dump ? &k_correlate<FMT, STD, MULTI, true> : &k_correlate<FMT, STD, MULTI, false>;
@@ -810,57 +347,22 @@ correlate_fn correlate_variant(int fmt, bool want_std, bool multi, bool dump) {
 #endif
 }  // namespace
 
+hipError_t prepare_16k_carrier();   // detect16k_carrier.hip
+
 hipError_t prepare_16k() {
     // > 64 KiB of dynamic LDS must be opted into, per device and per kernel variant
-    for (const void* f : {reinterpret_cast<const void*>(&k_carrier_pruned<THR_IN_U8, false>),
-                          reinterpret_cast<const void*>(&k_carrier_pruned<THR_IN_U8, true>),
-                          reinterpret_cast<const void*>(&k_carrier_pruned<THR_IN_C64, false>),
-                          reinterpret_cast<const void*>(&k_carrier_pruned<THR_IN_C64, true>)}) {
-        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-        if (e != hipSuccess) return e;
-    }
+    hipError_t e = prepare_16k_carrier();
+    if (e != hipSuccess) return e;
     for (int fmt = 0; fmt < 2; ++fmt)
         for (int st = 0; st < 2; ++st)
-            for (int d = 0; d < 2; ++d) {
-                hipError_t e = hipFuncSetAttribute(
-                    reinterpret_cast<const void*>(carrier_variant(fmt, st, d)),
-                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-                if (e != hipSuccess) return e;
+            for (int d = 0; d < 2; ++d)
                 for (int m = 0; m < 2; ++m) {
                     e = hipFuncSetAttribute(
                         reinterpret_cast<const void*>(correlate_variant(fmt, st, m, d)),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
                     if (e != hipSuccess) return e;
                 }
-            }
     return hipSuccess;
-}
-
-hipError_t launch_carrier_16k(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,
-                              const float2* tables, const float2* twn, CarStats* stats,
-                              float2* dump_fft, int grid, hipStream_t stream) {
-    if (cfg.car_prune && dump_fft == nullptr) {
-        typedef void (*pruned_fn)(const void*, int, DevCfg, const cpx*, const cpx*, CarStats*);
-        const bool shifted = cfg.car_prune == 2;
-        pruned_fn fn = fmt == THR_IN_U8
-                           ? (shifted ? &k_carrier_pruned<THR_IN_U8, true> : &k_carrier_pruned<THR_IN_U8, false>)
-                           : (shifted ? &k_carrier_pruned<THR_IN_C64, true> : &k_carrier_pruned<THR_IN_C64, false>);
-        hipLaunchKernelGGL(fn, dim3(grid), dim3(NT), LDS_BYTES, stream, samples, n_blocks, cfg,
-                           reinterpret_cast<const cpx*>(tables), reinterpret_cast<const cpx*>(twn), stats);
-        return hipGetLastError();
-    }
-    carrier_fn fn = carrier_variant(fmt, cfg.car_want_std != 0, dump_fft != nullptr);
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(NT), LDS_BYTES, stream, samples, n_blocks, cfg,
-                       reinterpret_cast<const cpx*>(tables), stats, reinterpret_cast<cpx*>(dump_fft));
-    return hipGetLastError();
-}
-
-hipError_t launch_fit(int n_blocks, const DevCfg& cfg, const CarStats* stats,
-                      const long long* block_idx, ShiftParams* shifts, int* work_list,
-                      int* work_count, thr_record* records, hipStream_t stream) {
-    hipLaunchKernelGGL(k_fit, dim3((n_blocks * 8 + 63) / 64), dim3(64), 0, stream, n_blocks, cfg,
-                       stats, block_idx, shifts, work_list, work_count, records);
-    return hipGetLastError();
 }
 
 hipError_t launch_correlate_16k(int fmt, const void* samples, const DevCfg& cfg,
@@ -878,19 +380,6 @@ hipError_t launch_correlate_16k(int fmt, const void* samples, const DevCfg& cfg,
                        corr_stats, records,
                        reinterpret_cast<f4*>(xhat_scratch), reinterpret_cast<cpx*>(dump_xhat),
                        reinterpret_cast<cpx*>(dump_corr), dump_template);
-    return hipGetLastError();
-}
-
-hipError_t launch_finish(int n_records, const DevCfg& cfg, const CorrStats* corr_stats,
-                         thr_record* records, int* work_count, hipStream_t stream) {
-    hipLaunchKernelGGL(k_finish, dim3((n_records + 255) / 256), dim3(256), 0, stream, n_records,
-                       cfg, corr_stats, records, work_count);
-    return hipGetLastError();
-}
-
-hipError_t launch_compact(const thr_record* in, int n, thr_record* out, int* n_out,
-                          hipStream_t stream) {
-    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, stream, in, n, out, n_out);
     return hipGetLastError();
 }
 
