@@ -160,15 +160,15 @@ struct ProfScope {
                 ev = h->free_events.back();
                 h->free_events.pop_back();
             } else {
-                hipEventCreate(&ev.a);
-                hipEventCreate(&ev.b);
+                (void)hipEventCreate(&ev.a);
+                (void)hipEventCreate(&ev.b);
             }
-            hipEventRecord(ev.a, h->stream);
+            (void)hipEventRecord(ev.a, h->stream);
         }
     }
     ~ProfScope() {
         if (on) {
-            hipEventRecord(ev.b, h->stream);
+            (void)hipEventRecord(ev.b, h->stream);
             h->pending[slot].push_back(ev);
         }
     }
@@ -320,7 +320,7 @@ int build_preshift_bank(thr_handle* h) {
 int ensure_staging(thr_handle* h, int format) {
     const size_t need = size_t(h->cfg.max_batch) * h->cfg.block_len * (format == THR_IN_U8 ? 2 : 8);
     if (h->d_in_bytes < need) {
-        if (h->d_in) hipFree(h->d_in);
+        if (h->d_in) (void)hipFree(h->d_in);
         h->d_in = nullptr;
         h->d_in_bytes = 0;
         HIP_TRY(hipMalloc(&h->d_in, need));
@@ -697,19 +697,19 @@ static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out
 
 void thr_destroy(thr_handle* h) {
     if (!h) return;
-    hipSetDevice(h->device);
-    if (h->own_stream) hipStreamSynchronize(h->own_stream);
+    (void)hipSetDevice(h->device);
+    if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     for (auto& v : h->pending)
         for (auto& e : v) h->free_events.push_back(e);
     for (auto& e : h->free_events) {
-        hipEventDestroy(e.a);
-        hipEventDestroy(e.b);
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
     }
     void* bufs[] = {h->d_tables, h->d_twn, h->d_tspec, h->d_stats, h->d_shifts, h->d_corr_stats, h->d_text, h->d_payload_off, h->d_bad, h->d_gen_scratch, h->d_tspec_nat, h->d_bank, h->d_gtw, h->d_win_pow, h->d_partial, h->d_partial_x2, h->d_dsub, h->d_work_list,
                     h->d_work_count, h->d_xhat_scratch, h->d_ncompact, h->d_in, h->d_idx, h->d_rec};
     for (void* b : bufs)
-        if (b) hipFree(b);
-    if (h->own_stream) hipStreamDestroy(h->own_stream);
+        if (b) (void)hipFree(b);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
 
@@ -866,7 +866,7 @@ int thr_detect_card(thr_handle* h, const char* text, size_t text_len, const int6
         }
         const size_t span = size_t(hi - lo) + chars;
         if (h->d_text_bytes < span) {
-            if (h->d_text) hipFree(h->d_text);
+            if (h->d_text) (void)hipFree(h->d_text);
             h->d_text = nullptr;
             h->d_text_bytes = 0;
             HIP_TRY(hipMalloc(&h->d_text, span + (span >> 2)));
@@ -981,7 +981,7 @@ int thr_debug_fft(thr_handle* h, const void* samples, int format, size_t n_block
             break;
         }
     } while (0);
-    hipFree(d_dump);
+    (void)hipFree(d_dump);
     return rc;
 }
 
@@ -1000,7 +1000,7 @@ int thr_debug_stage(thr_handle* h, const void* samples, int format, size_t n_blo
     float2 *d_x = nullptr, *d_c = nullptr;
     HIP_TRY(hipMalloc(&d_x, dump_bytes));
     if (hipMalloc(&d_c, dump_bytes) != hipSuccess) {
-        hipFree(d_x);
+        (void)hipFree(d_x);
         return fail(THR_ERR_DEVICE, "hipMalloc failed");
     }
     rc = THR_OK;
@@ -1030,8 +1030,8 @@ int thr_debug_stage(thr_handle* h, const void* samples, int format, size_t n_blo
             break;
         }
     } while (0);
-    hipFree(d_x);
-    hipFree(d_c);
+    (void)hipFree(d_x);
+    (void)hipFree(d_c);
     return rc;
 }
 
