@@ -59,5 +59,5 @@ if acc:
             f = sum(acc[k]["FETCH_SIZE"]) / len(acc[k]["FETCH_SIZE"])
             w = sum(acc[k]["WRITE_SIZE"]) / len(acc[k]["WRITE_SIZE"])
             traffic[k] = {"fetch_kib_raw": f, "write_kib": w,
-                          "bytes_per_launch_at_batch": {"8192": int((2 * f + w) * 1024)}}
+                          "bytes_per_launch_at_batch": {os.environ.get("THR_PROFILE_BATCH", "32768"): int((2 * f + w) * 1024)}}
     json.dump(traffic, open(os.path.join(root, "hbm_traffic.json"), "w"), indent=1)
