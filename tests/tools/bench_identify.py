@@ -1,7 +1,7 @@
 """Dev/aux: `identify` (classification + duplicate filter + output order) on n detections:
 thr_identify on the GPU (host columns in, host columns out) vs the NumPy oracle."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle import thrifty_np as onp
 from thrifty_amd import _native as F

@@ -2,7 +2,7 @@
 full window), re-run SciPy on the magnitudes the GPU saw: the deviation is the fit's sensitivity
 to one-ulp differences of its float32 inputs, not the solver."""
 import sys, numpy as np
-sys.path.insert(0,'/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 from oracle import thrifty_np as onp
 from thrifty_amd import _native as F, synth
 from scipy.optimize import curve_fit

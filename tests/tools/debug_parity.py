@@ -1,6 +1,6 @@
 """Dev aid: run N seeded blocks through HIP engine and oracle, print mismatching fields."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle import thrifty_np as onp
 from thrifty_amd import _native as F, synth

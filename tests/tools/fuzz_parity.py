@@ -2,7 +2,7 @@
 carrier window / thresholds / batch split, a few blocks each, GPU vs oracle.
 Usage: fuzz_parity.py [n_configs] [seed]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle import thrifty_np as onp
 from thrifty_amd import _native as F, synth

@@ -1,7 +1,7 @@
 """Dev/aux: large parity soak -- GPU records vs the CPU oracle over many synthetic blocks,
 the oracle spread over worker processes.  Usage: soak_parity.py [n_blocks] [procs] [variant]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import multiprocessing as mp
 import numpy as np
 
