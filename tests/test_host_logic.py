@@ -258,15 +258,22 @@ def test_card_stream_rejects_malformed_lines():
 
 # ---------------------------------------------------------------- the product never touches the oracle
 def test_product_package_does_not_import_the_oracle():
-    pkg = os.path.join(ROOT, "thrifty_amd")
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/:
+    nothing in the package, the C sources, the headers or the helper scripts does."""
     offenders = []
-    for dirpath, _, files in os.walk(pkg):
-        for f in files:
-            if f.endswith((".py", ".hip", ".hpp", ".h")):
-                text = open(os.path.join(dirpath, f), encoding="utf-8", errors="replace").read()
-                if re.search(r"^\s*(from|import)\s+oracle\b", text, re.M) or "oracle/" in text:
-                    offenders.append(os.path.join(dirpath, f))
+    for top in ("thrifty_amd", "include", "scripts"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".hpp", ".h", ".sh")):
+                    text = open(os.path.join(dirpath, f), encoding="utf-8", errors="replace").read()
+                    if re.search(r"^\s*(from|import)\s+oracle\b", text, re.M) or "oracle/" in text:
+                        offenders.append(os.path.join(dirpath, f))
     assert offenders == []
+    # bench.py: the oracle appears only inside the CPU-baseline functions
+    bench_src = open(os.path.join(ROOT, "bench.py")).read()
+    for m in re.finditer(r"^\s*from oracle import", bench_src, re.M):
+        enclosing = re.findall(r"^def (\w+)\(", bench_src[:m.start()], re.M)[-1]
+        assert enclosing in ("cpu_baseline", "_oracle_worker"), enclosing
     header = open(os.path.join(ROOT, "oracle", "thrifty_np.py")).read()
     assert "TEST INFRASTRUCTURE ONLY" in header and "PINNED" in header
 
