@@ -23,7 +23,9 @@
 extern "C" {
 #endif
 
-#define THR_ABI_VERSION 1
+/* 2: + thr_create_preshift / thr_create_fastdet, thr_detect_stream[_device], thr_detect_card,
+ *    thr_identify (additions only: every version-1 entry point is unchanged) */
+#define THR_ABI_VERSION 2
 
 /* status codes */
 #define THR_OK 0

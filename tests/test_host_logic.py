@@ -199,7 +199,7 @@ def test_library_exports_every_declared_symbol():
     for sym in declared:
         assert (" T " + sym) in out, sym
     lib = _native.load_library()
-    assert lib.thr_abi_version() == 1
+    assert lib.thr_abi_version() == 2
     assert _native.RECORD_DTYPE.itemsize == 64
 
 

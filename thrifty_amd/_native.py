@@ -20,6 +20,8 @@ FLAG_CORR = 2
 FLAG_INDEX_ERROR = 4
 N_KERNEL_SLOTS = 4
 
+ABI_VERSION = 2     # THR_ABI_VERSION of include/thrifty_hip.h
+
 EXPORTS = [
     "thr_abi_version", "thr_last_error", "thr_create", "thr_destroy", "thr_detect",
     "thr_create_preshift", "thr_create_fastdet", "thr_detect_card", "thr_detect_stream", "thr_detect_stream_device", "thr_detect_device", "thr_sync", "thr_set_stream", "thr_compact_device",
@@ -97,6 +99,9 @@ def load_library():
     lib = C.CDLL(LIB_PATH)
     vp, i64p = C.c_void_p, C.POINTER(C.c_int64)
     lib.thr_abi_version.restype = C.c_int
+    if lib.thr_abi_version() != ABI_VERSION:
+        raise NativeError("%s has ABI version %d, this package needs %d: rebuild it with "
+                          "`python -m thrifty_amd.build --force`" % (LIB_PATH, lib.thr_abi_version(), ABI_VERSION))
     lib.thr_last_error.restype = C.c_char_p
     lib.thr_kernel_name.restype = C.c_char_p
     lib.thr_kernel_name.argtypes = [C.c_int]
