@@ -49,13 +49,28 @@ struct RawLong {
     const void* blk;
     const float2* g;  // [R0]
     int t, k0;
+    // u8: the quantiser's affine map (v - 127.4)/128 is applied AFTER the radix-R0 combination
+    // (it is linear): y = sum g[n0] (sc u + of (1+i)) = sc * sum g[n0] u + of (1+i) sum g[n0]
+    // -- one packed fma per output instead of one fma per byte.
+    cpx kadd = cpx{0.f, 0.f};
+    __device__ __forceinline__ void prepare() {
+        if constexpr (FMT == THR_IN_U8) {
+            constexpr float of = -127.4f / 128.0f;
+            cpx gs = cpx{1.f, 0.f};
+#pragma unroll
+            for (int n0 = 1; n0 < R0; ++n0) {
+                if constexpr (GEN) gs += cpx{g[n0].x, g[n0].y};
+                else gs += rot_quarter_neg(cpx{1.f, 0.f}, (n0 * k0 * (4 / R0)) & 3);
+            }
+            kadd = cpx{of * (gs.x - gs.y), of * (gs.x + gs.y)};
+        }
+    }
     __device__ __forceinline__ void pair(int n0, int n1, cpx& a, cpx& b) const {
         const size_t idx = size_t(n0) * (M / 2) + size_t(n1) * (S1 / 2) + t;
         if constexpr (FMT == THR_IN_U8) {
             const unsigned w = reinterpret_cast<const unsigned*>(blk)[idx];
-            constexpr float sc = 1.0f / 128.0f, of = -127.4f / 128.0f;
-            a = cpx{fmaf(float(w & 0xffu), sc, of), fmaf(float((w >> 8) & 0xffu), sc, of)};
-            b = cpx{fmaf(float((w >> 16) & 0xffu), sc, of), fmaf(float(w >> 24), sc, of)};
+            a = cpx{float(w & 0xffu), float((w >> 8) & 0xffu)};      // raw bytes: see prepare()
+            b = cpx{float((w >> 16) & 0xffu), float(w >> 24)};
         } else {
             const f4 w = reinterpret_cast<const f4*>(blk)[idx];
             a = cpx{w.x, w.y};
@@ -77,6 +92,11 @@ struct RawLong {
                 a += rot_quarter_neg(x, q);
                 b += rot_quarter_neg(y, q);
             }
+        }
+        if constexpr (FMT == THR_IN_U8) {
+            constexpr float sc = 1.0f / 128.0f;
+            a = __builtin_elementwise_fma(a, cpx{sc, sc}, kadd);
+            b = __builtin_elementwise_fma(b, cpx{sc, sc}, kadd);
         }
         // complex64 input: R0 x 16 float4 loads would all be hoisted (256 VGPRs) -- fence per n1
         if constexpr (FMT == THR_IN_C64) __builtin_amdgcn_sched_barrier(0);
@@ -145,6 +165,7 @@ __global__ __launch_bounds__(NT) void k_carrier_sub(const void* __restrict__ sam
         // R0 x 16 hoisted float4 loads spills ~150 VGPRs)
         RawLong<FMT, R0, FMT == THR_IN_C64> raw{
             static_cast<const unsigned char*>(samples) + size_t(b) * blk_bytes, sc_g, t, k0};
+        raw.prepare();
         fwd_pass1<true>(lds, raw, sc_rp, p[0], p[1]);
         __syncthreads();
         fwd_pass2(lds);
@@ -218,6 +239,7 @@ __global__ __launch_bounds__(NT) void k_carrier_sub_pruned(const void* __restric
         __syncthreads();
         RawLong<FMT, R0, FMT == THR_IN_C64> raw{
             static_cast<const unsigned char*>(samples) + size_t(b) * blk_bytes, sc_g, t, k0};
+        raw.prepare();
         float sums[1];
         fwd_pass1<true>(lds, raw, sc_rp, p[0], p[1], &sums[0]);
         __syncthreads();
@@ -496,6 +518,7 @@ __global__ __launch_bounds__(NT) void k_correlate_sub(
         __syncthreads();
         RawLong<FMT, R0, true> raw{static_cast<const unsigned char*>(samples) + size_t(b) * blk_bytes,
                                    sc_g, t, k0};
+        raw.prepare();
         fwd_pass1<true>(lds, raw, sc_rp, p[0], p[1]);
         __syncthreads();
         fwd_pass2(lds);
