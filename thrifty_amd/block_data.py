@@ -11,6 +11,7 @@ from __future__ import annotations
 import base64
 import mmap
 import os
+import select
 import stat
 import time
 
@@ -119,6 +120,40 @@ def _map_regular_file(stream):
         return None, 0
 
 
+def _readable_within(stream, seconds):
+    """True if `stream`'s descriptor has data (or EOF) pending within `seconds`; streams
+    without a descriptor (BytesIO, wrappers) read as 'nothing more pending'."""
+    try:
+        return bool(select.select([stream.fileno()], [], [], seconds)[0])
+    except (AttributeError, OSError, ValueError):
+        return False
+
+
+def _read_arrived(stream, view, grace=0.002):
+    """Fill `view` with what HAS ARRIVED: block for the first bytes (or EOF), then keep taking
+    whatever shows up within `grace` seconds of the previous read.  -> bytes read (0 = EOF).
+
+    `readinto` on a BufferedReader (sys.stdin.buffer) blocks until the whole view is full, so
+    `fastcard ... | thrifty detect -` would emit nothing until 64 MiB had accumulated; the
+    reference's readers return per line / per block.  A fast producer (`cat rx.card |`) keeps the
+    descriptor readable, so its batches still fill up."""
+    one = getattr(stream, "readinto1", None)
+    if one is None:
+        if hasattr(stream, "readinto"):
+            return stream.readinto(view) or 0
+        more = stream.read(len(view))
+        if isinstance(more, str):
+            more = more.encode("ascii")
+        view[:len(more)] = more
+        return len(more)
+    got = one(view) or 0
+    total = got
+    while got and total < len(view) and _readable_within(stream, grace):
+        got = one(view[total:]) or 0
+        total += got
+    return total
+
+
 class CardStream(object):
     """Batch-oriented .card reader for the GPU engine.
 
@@ -159,14 +194,8 @@ class CardStream(object):
             self._buf.extend(bytes(len(self._buf)))
             room = len(self._buf) - self._end
         view = memoryview(self._buf)[self._end:self._end + room]
-        if hasattr(self.stream, "readinto"):
-            got = self.stream.readinto(view) or 0
-        else:
-            more = self.stream.read(room)
-            if isinstance(more, str):
-                more = more.encode("ascii")
-            got = len(more)
-            view[:got] = more
+        got = _read_arrived(self.stream, view)
+        del view
         if got == 0:
             self._eof = True
         self._end += got
@@ -261,6 +290,7 @@ class RawStream(object):
         self._have = 2 * self.history
         self._consumed = 0      # bytes of the previous u8 batch still to be slid out
         self._eof = False
+        self._arrivals = []     # (valid bytes after the read, time.time()) of this batch's reads
         # regular file: overlapping blocks are plain slices of the mapping (no carry, no copy)
         self._map, self._off = _map_regular_file(stream)
         self._origin = self._off    # stream byte 0 (the caller may have consumed a header)
@@ -274,16 +304,24 @@ class RawStream(object):
             self._buf.extend(bytes(want_end - len(self._buf)))
         while self._have < need_end and not self._eof:
             view = memoryview(self._buf)[self._have:want_end]
-            if hasattr(self.stream, "readinto"):
-                got = self.stream.readinto(view) or 0
-            else:
-                more = self.stream.read(want_end - self._have)
-                got = len(more)
-                view[:got] = more
+            got = _read_arrived(self.stream, view)
             del view
             if got == 0:
                 self._eof = True
             self._have += got
+            self._arrivals.append((self._have, time.time()))
+
+    def _stamps(self, ends):
+        """Arrival time of each block's last byte (the reference's block_reader stamps a block
+        when its read returns, block_data.py:86-98): `ends` = buffer offsets one past each block."""
+        if not self._arrivals:      # everything was already buffered
+            return [time.time()] * len(ends)
+        out, k = [], 0
+        for e in ends:
+            while k + 1 < len(self._arrivals) and self._arrivals[k][0] < e:
+                k += 1
+            out.append(self._arrivals[k][1])
+        return out
 
     def _slide(self, used):
         """Drop `used` consumed bytes: the bytes before the new position become the carry."""
@@ -302,11 +340,13 @@ class RawStream(object):
         self._slide(self._consumed)
         self._consumed = 0
         if self._next_idx < self._n_lead:
-            blocks, idxs = [], []
+            blocks, idxs, stamps = [], [], []
             while len(blocks) < max_blocks and self._next_idx < self._n_lead:
+                self._arrivals = []
                 self._read_upto(carry + step)
                 if self._have < carry + step:
                     break                                   # short tail: dropped, like the reference
+                stamps.append(time.time())
                 chunk = np.frombuffer(self._buf, dtype=np.uint8, count=step, offset=carry)
                 self._lead = np.concatenate([self._lead[self.new:], raw_to_complex(chunk)])
                 del chunk
@@ -316,7 +356,8 @@ class RawStream(object):
                 self._slide(step)
             if not blocks:
                 return None
-            return "c64", [time.time()] * len(blocks), np.asarray(idxs, dtype=np.int64), np.stack(blocks)
+            return "c64", stamps, np.asarray(idxs, dtype=np.int64), np.stack(blocks)
+        self._arrivals = []
         self._read_upto(carry + max_blocks * step, need_end=carry + step)
         n = (self._have - carry) // step
         if n <= 0:
@@ -324,7 +365,8 @@ class RawStream(object):
         idxs = np.arange(self._next_idx, self._next_idx + n, dtype=np.int64)
         self._next_idx += n
         self._consumed = n * step
-        return "u8", [time.time()] * n, idxs, memoryview(self._buf)[:carry + n * step]
+        stamps = self._stamps([carry + (i + 1) * step for i in range(n)])
+        return "u8", stamps, idxs, memoryview(self._buf)[:carry + n * step]
 
     def _next_batch_mapped(self, max_blocks, step, carry):
         m, size = self._map, len(self._map)
@@ -357,7 +399,6 @@ class RawStream(object):
 
 def card_line(timestamp, block_idx, raw):
     """Format one .card line (fastcard_cli.c:187-192: "%ld.%06ld %PRId64 %s\\n")."""
-    sec = int(timestamp)
-    usec = int(round((timestamp - sec) * 1e6))
+    sec, usec = divmod(int(round(timestamp * 1e6)), 1000000)   # (a fraction >= .9999995 carries)
     return "%d.%06d %d %s\n" % (sec, usec, block_idx,
                                 base64.b64encode(np.asarray(raw, np.uint8).tobytes()).decode())

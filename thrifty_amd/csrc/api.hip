@@ -98,7 +98,6 @@ struct thr_handle {
     int device = 0;
     int n_cu = 0;
     bool fast = false;       // LDS-resident 16384 kernels; else the generic multi-pass path
-    bool w16 = false;        // fast path geometry: 16 waves x 16 elements (else 8 waves x 32)
     bool lng = false;        // block_len = 2 or 4 x 16384: R0 LDS sub-transforms per block
     int long_batch = 0;      // long path: blocks per internal sub-batch
     int long_chunk = 0;      // long path: work-list slots per correlate-stage chunk (sizes d_dsub)
@@ -123,6 +122,8 @@ struct thr_handle {
     int* d_work_count = nullptr;
     float4* d_xhat_scratch = nullptr;
     int* d_ncompact = nullptr;
+    int* d_compact_tiles = nullptr;   // per-tile counts / offsets of thr_compact_device (lazy)
+    int compact_tiles_cap = 0;
     // PreshiftDetector variant (thr_create_preshift): bank of pre-shifted template spectra
     int preshift_num = 0;       // 0 = default detector
     float2* d_gtw = nullptr;    // optional combined twiddle table (THR_GTW)
@@ -193,18 +194,9 @@ int window_indices(int start, int stop, int n, int* lo, int* count) {
 int build_constants(thr_handle* h) {
     const int n = h->cfg.block_len;
     // --- LDS twiddle tables (forward sign): C[32][32], A[16][32], Bt[16][32]  (fast path)
-    std::vector<float2> tab(2048 + 64);
-    if (h->w16) {
-        // T2[k2][m2] = W_1024^(m2 k2), A[k1][mh] = W_512^(mh k1), B[k1][ml] = W_N^(ml k1),
-        // T3[k3][n4] = W_64^(n4 k3)
-        for (int k2 = 0; k2 < 16; ++k2)
-            for (int m2 = 0; m2 < 64; ++m2) tab[k2 * 64 + m2] = unit_root((long long)k2 * m2, 1024);
-        for (int k3 = 0; k3 < 4; ++k3)
-            for (int n4 = 0; n4 < 16; ++n4) tab[2048 + k3 * 16 + n4] = unit_root((long long)k3 * n4, 64);
-    } else {
-        for (int a = 0; a < 32; ++a)
-            for (int b = 0; b < 32; ++b) tab[a * 32 + b] = unit_root((long long)a * b, 1024);
-    }
+    std::vector<float2> tab(2048);
+    for (int a = 0; a < 32; ++a)
+        for (int b = 0; b < 32; ++b) tab[a * 32 + b] = unit_root((long long)a * b, 1024);
     for (int k1 = 0; k1 < 16; ++k1)
         for (int n2 = 0; n2 < 32; ++n2) tab[1024 + k1 * 32 + n2] = unit_root((long long)k1 * n2, 512);
     for (int k1 = 0; k1 < 16; ++k1)
@@ -215,7 +207,7 @@ int build_constants(thr_handle* h) {
     // --- pass-1 / pass-B twiddles W_16384^(k1 q) of k_correlate as one L2-resident table in
     //     global memory (THR_GTW=0: the factored LDS tables A[k1][n2] * Bt[k1][m'] instead)
     h->dev.gtw = nullptr;
-    if (h->fast && !h->w16 && !(getenv("THR_GTW") && atoi(getenv("THR_GTW")) == 0)) {
+    if (h->fast && !(getenv("THR_GTW") && atoi(getenv("THR_GTW")) == 0)) {
         std::vector<float2> g(16 * 1024);
         for (int k1 = 0; k1 < 16; ++k1)
             for (int q = 0; q < 1024; ++q) g[k1 * 1024 + q] = unit_root((long long)k1 * q, 16384);
@@ -254,16 +246,6 @@ int build_constants(thr_handle* h) {
                         out[size_t(k0) * 16384 + ((k3 >> 1) * 512 + tid) * 2 + (k3 & 1)] =
                             float2{float(c.real()), float(c.imag())};
                     }
-        } else if (h->fast && h->w16) {
-            // thread t holds bins kb + 1024*k4, kb = (t>>6) + 16*((t>>2)&15) + 256*(t&3);
-            // float4 j of the thread = k4 in {2j, 2j+1}, stored [j][t] for coalescing
-            for (int tid = 0; tid < 1024; ++tid)
-                for (int k4 = 0; k4 < 16; ++k4) {
-                    const int k = (tid >> 6) + 16 * ((tid >> 2) & 15) + 256 * (tid & 3) + 1024 * k4;
-                    const std::complex<double> c = std::conj(buf[k]) / double(n);
-                    out[((k4 >> 1) * 1024 + tid) * 2 + (k4 & 1)] =
-                        float2{float(c.real()), float(c.imag())};
-                }
         } else if (h->fast) {
             for (int tid = 0; tid < 512; ++tid)
                 for (int k3 = 0; k3 < 32; ++k3) {
@@ -354,7 +336,7 @@ int run_batch_fast(thr_handle* h, const void* d_samples, int format,
     }
     {
         ProfScope p(h, 0);
-        HIP_TRY((h->w16 ? thr::launch_carrier_16k_w16 : thr::launch_carrier_16k)(
+        HIP_TRY(thr::launch_carrier_16k(
             format, d_samples, n_blocks, h->dev, h->d_tables, h->d_twn, h->d_stats, dump_fft, grid,
             h->stream));
     }
@@ -366,7 +348,7 @@ int run_batch_fast(thr_handle* h, const void* d_samples, int format,
     }
     {
         ProfScope p(h, 2);
-        HIP_TRY((h->w16 ? thr::launch_correlate_16k_w16 : thr::launch_correlate_16k)(
+        HIP_TRY(thr::launch_correlate_16k(
             format, d_samples, h->dev, h->d_tables, h->d_twn, h->d_tspec, h->d_shifts, h->d_work_list,
             h->d_work_count, h->d_corr_stats, d_out, h->d_xhat_scratch, dump_xhat, dump_corr,
             dump_template, grid, h->stream));
@@ -568,10 +550,6 @@ static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out
     h->fast = (n == 16384) && getenv("THR_FORCE_GENERIC") == nullptr;
     // the preshift variant has a fused kernel for 16384 only; other lengths use the multi-pass pipeline
     h->lng = thr::long_supported(n) && getenv("THR_FORCE_GENERIC") == nullptr && !preshift_num;
-    {
-        const char* g = getenv("THR_GEOMETRY");  // "w8" | "w16": A/B of the two workgroup shapes
-        h->w16 = g != nullptr && std::string(g) == "w16" && !preshift_num;
-    }
     int rc = THR_OK;
     do {
         if (hipSetDevice(h->device) != hipSuccess) {
@@ -585,7 +563,7 @@ static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out
         }
         h->n_cu = prop.multiProcessorCount;
         if ((h->fast || h->lng) && size_t(prop.maxSharedMemoryPerMultiProcessor) <
-                           std::max(thr::lds_bytes_16k(), thr::lds_bytes_16k_w16())) {
+                           thr::lds_bytes_16k()) {
             rc = fail(THR_ERR_DEVICE, "device has %zu B LDS per CU, need %zu",
                       size_t(prop.maxSharedMemoryPerMultiProcessor), thr::lds_bytes_16k());
             break;
@@ -609,8 +587,8 @@ static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out
             break;
         }
         for (int i = 0; i < 3; ++i) {
-            d.car_thr[i] = float(s->carrier_thresh[i]);
-            d.cor_thr[i] = float(s->corr_thresh[i]);
+            d.car_thr[i] = s->carrier_thresh[i];
+            d.cor_thr[i] = s->corr_thresh[i];
         }
         d.timeline = nullptr;
 #ifdef THR_TIMELINE
@@ -645,7 +623,7 @@ static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out
         rc = fail(THR_ERR_DEVICE, "%s failed (%s)", #expr, hipGetErrorString(hipGetLastError())); \
         break;                                                                        \
     }
-        if (h->fast) CREATE_TRY(h->w16 ? thr::prepare_16k_w16() : thr::prepare_16k());
+        if (h->fast) CREATE_TRY(thr::prepare_16k());
         if (h->fast && preshift_num) CREATE_TRY(thr::prepare_preshift_16k());
         if (h->lng) {
             CREATE_TRY(thr::prepare_long(n));
@@ -706,7 +684,7 @@ void thr_destroy(thr_handle* h) {
         (void)hipEventDestroy(e.b);
     }
     void* bufs[] = {h->d_tables, h->d_twn, h->d_tspec, h->d_stats, h->d_shifts, h->d_corr_stats, h->d_text, h->d_payload_off, h->d_bad, h->d_gen_scratch, h->d_tspec_nat, h->d_bank, h->d_gtw, h->d_win_pow, h->d_partial, h->d_partial_x2, h->d_dsub, h->d_work_list,
-                    h->d_work_count, h->d_xhat_scratch, h->d_ncompact, h->d_in, h->d_idx, h->d_rec};
+                    h->d_work_count, h->d_xhat_scratch, h->d_ncompact, h->d_compact_tiles, h->d_in, h->d_idx, h->d_rec};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -905,7 +883,16 @@ int thr_compact_device(thr_handle* h, const thr_record* d_in, size_t n_records, 
     if (!h || !d_in || !d_out || !n_kept) return fail(THR_ERR_ARG, "thr_compact_device: null argument");
     HIP_TRY(hipSetDevice(h->device));
     if (n_records > size_t(1) << 30) return fail(THR_ERR_ARG, "too many records");
-    HIP_TRY(thr::launch_compact(d_in, int(n_records), d_out, h->d_ncompact, h->stream));
+    const int tiles = thr::compact_tiles(int(n_records));
+    if (tiles > h->compact_tiles_cap) {
+        if (h->d_compact_tiles) (void)hipFree(h->d_compact_tiles);
+        h->d_compact_tiles = nullptr;
+        h->compact_tiles_cap = 0;
+        HIP_TRY(hipMalloc(&h->d_compact_tiles, size_t(tiles) * sizeof(int)));
+        h->compact_tiles_cap = tiles;
+    }
+    HIP_TRY(thr::launch_compact(d_in, int(n_records), d_out, h->d_ncompact, h->d_compact_tiles,
+                                h->stream));
     int n = 0;
     HIP_TRY(hipMemcpyAsync(&n, h->d_ncompact, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));

@@ -8,7 +8,7 @@
 //   k_fit       : noise/threshold verdict + Dirichlet fit (MINPACK lmdif) + shift phasors
 //                 (carrier_detect.py:61-115, carrier_sync.py:150-196)
 //   k_finish    : correlation noise, threshold verdict, log-parabola (soa_estimator.py:108-170)
-//   k_compact   : order-preserving compaction of detected records
+//   k_compact_* : order-preserving compaction of detected records (count / scan / scatter)
 #include <hip/hip_runtime.h>
 
 #include "detect_common.hpp"
@@ -79,26 +79,29 @@ __global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples
         const int kbase = (t >> 5) + 16 * (t & 31);
         float sums[2] = {0.f, 0.f};
         float pw[R3];
-        // first-max inside the (wrapping) window: lowest window index wins ties, and this
-        // thread's bins are visited in increasing k, which is increasing window index except
-        // across the wrap -- so compare (p, wi) lexicographically via '>' / '==' + '<'
-        float bestp = -1.0f;
+        // first-max inside the (wrapping) window over float32 MAGNITUDES, as the reference takes
+        // it (np.argmax of np.abs, carrier_detect.py:146): powers an ulp apart can round to the
+        // same |X|, and then the lowest window index wins.  This thread's bins are visited in
+        // increasing k, which is increasing window index except across the wrap -- so compare
+        // (|X|, wi) lexicographically via '>' / '==' + '<'
+        float bestm = -1.0f;
         unsigned bestwi = 0;
         static_for<R3>([&](auto K) {
             constexpr int k3 = decltype(K)::value;
             const float p = cnorm(v[brev(k3, R3)]);
-            pw[k3] = p;
+            const float m = sqrtf(p);
+            pw[k3] = m;
             sums[0] += p;
-            if constexpr (WANT_STD) sums[1] += __builtin_amdgcn_sqrtf(p);
+            if constexpr (WANT_STD) sums[1] += m;
             const unsigned wi = unsigned(kbase + 512 * k3 - cfg.win_lo) & unsigned(N - 1);
             const bool take = wi < unsigned(cfg.win_count) &&
-                              (p > bestp || (p == bestp && wi < bestwi));
-            bestp = take ? p : bestp;
+                              (m > bestm || (m == bestm && wi < bestwi));
+            bestm = take ? m : bestm;
             bestwi = take ? wi : bestwi;
         });
         unsigned long long best =
-            bestp < 0.f ? 0ull
-                        : ((unsigned long long)__float_as_uint(bestp) << 32) | (0xFFFFFFFFu - bestwi);
+            bestm < 0.f ? 0ull
+                        : ((unsigned long long)__float_as_uint(bestm) << 32) | (0xFFFFFFFFu - bestwi);
         double tot[2];
         block_reduce<WANT_STD ? 2 : 1, NT / 64>(reinterpret_cast<float(&)[WANT_STD ? 2 : 1]>(sums),
                                        reinterpret_cast<double(&)[WANT_STD ? 2 : 1]>(tot), best,
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples
                 constexpr int k3 = decltype(K)::value;
                 val = (k3s == unsigned(k3)) ? pw[k3] : val;
             });
-            if (r < 7u) st->nb[r] = sqrtf(val);
+            if (r < 7u) st->nb[r] = val;
         }
         if constexpr (DUMP) {
             cpx* out = dump_fft + size_t(b) * N;
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples
         if (t == 0) {
             st->sum_mag2 = (float)tot[0];
             st->sum_mag = WANT_STD ? (float)tot[1] : 0.f;
-            st->peak_mag = sqrtf(__uint_as_float(unsigned(best >> 32)));
+            st->peak_mag = __uint_as_float(unsigned(best >> 32));
             st->peak_idx = peak_idx;
             st->pad = 0;
         }
@@ -271,10 +274,11 @@ __global__ __launch_bounds__(64) void k_fit(int n_blocks, DevCfg cfg,
     const float peak_pow = peak_mag * peak_mag;
     const float noise_pow = (sum_mag2 - 2.0f * peak_pow) / float(n - 1);
     const float noise_rms = sqrtf(noise_pow);
-    float thr = cfg.car_thr[0] + cfg.car_thr[1] * (noise_rms * noise_rms);
+    // (Python-float coefficient x np.float32 statistic: NEP 50 rounds the coefficient to float32)
+    float thr = float(cfg.car_thr[0]) + float(cfg.car_thr[1]) * (noise_rms * noise_rms);
     if (cfg.car_want_std) {
         const double m1 = double(st->sum_mag) / n, m2 = double(sum_mag2) / n;
-        thr += cfg.car_thr[2] * float(m2 - m1 * m1);
+        thr += float(cfg.car_thr[2]) * float(m2 - m1 * m1);
     }
     thr = sqrtf(thr);
     bool detected = peak_mag > thr;
@@ -396,7 +400,7 @@ __global__ __launch_bounds__(256) void k_finish(int n_records, DevCfg cfg,
         float noise_power =
             (signal_corr_energy - float((unsigned long long)peak_power)) / float(cfg.block_len);
         if (noise_power < 0) noise_power = 0;
-        const float threshold = cfg.cor_thr[0] + cfg.cor_thr[1] * noise_power;
+        const float threshold = float(cfg.cor_thr[0]) + float(cfg.cor_thr[1]) * noise_power;  // C floats there
         const bool hit = peak_power > threshold;
         double o = 0.0;
         if (hit && cs.pk != 0 && cs.pk != cfg.corr_len - 1) {
@@ -441,30 +445,57 @@ __global__ __launch_bounds__(256) void k_finish(int n_records, DevCfg cfg,
 }
 
 // =========================================================================
-// K7: order-preserving compaction of detected records (single workgroup scan)
+// K7: order-preserving compaction of detected records, three small launches:
+//   k_compact_count   one workgroup per tile of 2048 records -> kept records per tile
+//   k_compact_scan    one workgroup: exclusive scan of the tile counts (+ total)
+//   k_compact_scatter one workgroup per tile: ballot prefix inside the tile, 64-byte copies
+// (HBM-bound byte work: 64 B read + <= 64 B written per record; the single-workgroup scan it
+// replaces took 4.25 ms per 1 Mi records.)
 // =========================================================================
-__global__ __launch_bounds__(1024) void k_compact(const thr_record* __restrict__ in, int n,
-                                                  thr_record* __restrict__ out,
-                                                  int* __restrict__ n_out) {
+constexpr int CMP_T = 256, CMP_PER = 8, CMP_TILE = CMP_T * CMP_PER;
+
+__device__ __forceinline__ bool compact_keep(const thr_record* __restrict__ in, int n, int i) {
+    return i < n && (in[i].flags & THR_FLAG_CORR);
+}
+
+__global__ __launch_bounds__(CMP_T) void k_compact_count(const thr_record* __restrict__ in, int n,
+                                                         int* __restrict__ tile_counts) {
+    __shared__ int wcnt[CMP_T / 64];
+    const int base = blockIdx.x * CMP_TILE + threadIdx.x;
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < CMP_PER; ++j) c += __popcll(__ballot(compact_keep(in, n, base + j * CMP_T)));
+    if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_counts[blockIdx.x] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+}
+
+__global__ __launch_bounds__(1024) void k_compact_scan(int* __restrict__ tile_counts, int n_tiles,
+                                                       int* __restrict__ n_out) {
     __shared__ int wsum[16];
     __shared__ int carry;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int base = 0; base < n; base += 1024) {
+    for (int base = 0; base < n_tiles; base += 1024) {
         const int i = base + threadIdx.x;
-        const bool keep = i < n && (in[i].flags & THR_FLAG_CORR);
-        const unsigned long long mask = __ballot(keep);
-        const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
-        if (lane == 0) wsum[wv] = __popcll(mask);
+        const int v = i < n_tiles ? tile_counts[i] : 0;
+        int incl = v;  // inclusive scan inside the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int u = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += u;
+        }
+        if (lane == 63) wsum[wv] = incl;
         __syncthreads();
         int woff = 0, total = 0;
+#pragma unroll
         for (int w = 0; w < 16; ++w) {
             if (w < wv) woff += wsum[w];
             total += wsum[w];
         }
         const int c = carry;
-        if (keep) out[c + woff + prefix] = in[i];
+        if (i < n_tiles) tile_counts[i] = c + woff + incl - v;  // exclusive offset of tile i
         __syncthreads();
         if (threadIdx.x == 0) carry = c + total;
         __syncthreads();
@@ -472,7 +503,44 @@ __global__ __launch_bounds__(1024) void k_compact(const thr_record* __restrict__
     if (threadIdx.x == 0) *n_out = carry;
 }
 
-// ------------------------------------------------------------------ launchers
+__global__ __launch_bounds__(CMP_T) void k_compact_scatter(const thr_record* __restrict__ in, int n,
+                                                           const int* __restrict__ tile_offs,
+                                                           thr_record* __restrict__ out) {
+    __shared__ int wcnt[CMP_PER][CMP_T / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int base = blockIdx.x * CMP_TILE + threadIdx.x;
+    bool keep[CMP_PER];
+    int pre[CMP_PER];
+#pragma unroll
+    for (int j = 0; j < CMP_PER; ++j) {
+        keep[j] = compact_keep(in, n, base + j * CMP_T);
+        const unsigned long long m = __ballot(keep[j]);
+        pre[j] = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wcnt[j][wv] = __popcll(m);
+    }
+    __syncthreads();
+    int off = tile_offs[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < CMP_PER; ++j) {
+        int before = 0, row = 0;
+#pragma unroll
+        for (int w = 0; w < CMP_T / 64; ++w) {
+            if (w < wv) before += wcnt[j][w];
+            row += wcnt[j][w];
+        }
+        if (keep[j]) {
+            const float4* src = reinterpret_cast<const float4*>(in + base + j * CMP_T);
+            float4* dst = reinterpret_cast<float4*>(out + off + before + pre[j]);
+            const float4 a = src[0], b = src[1], c = src[2], d = src[3];
+            dst[0] = a;
+            dst[1] = b;
+            dst[2] = c;
+            dst[3] = d;
+        }
+        off += row;
+    }
+}
+
 // ------------------------------------------------------------------ launchers
 namespace {
 typedef void (*carrier_fn)(const void*, int, DevCfg, const cpx*, CarStats*, cpx*);
@@ -546,9 +614,17 @@ hipError_t launch_finish(int n_records, const DevCfg& cfg, const CorrStats* corr
     return hipGetLastError();
 }
 
+int compact_tiles(int n) { return (n + CMP_TILE - 1) / CMP_TILE; }
+
 hipError_t launch_compact(const thr_record* in, int n, thr_record* out, int* n_out,
-                          hipStream_t stream) {
-    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, stream, in, n, out, n_out);
+                          int* tile_scratch, hipStream_t stream) {
+    const int tiles = compact_tiles(n);
+    if (tiles > 0)
+        hipLaunchKernelGGL(k_compact_count, dim3(tiles), dim3(CMP_T), 0, stream, in, n, tile_scratch);
+    hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, stream, tile_scratch, tiles, n_out);
+    if (tiles > 0)
+        hipLaunchKernelGGL(k_compact_scatter, dim3(tiles), dim3(CMP_T), 0, stream, in, n,
+                           tile_scratch, out);
     return hipGetLastError();
 }
 

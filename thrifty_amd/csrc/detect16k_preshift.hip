@@ -63,7 +63,7 @@ __device__ __forceinline__ PreshiftVerdict fastdet_verdict(const DevCfg& cfg, fl
     const int n = cfg.block_len;
     float noise_power = 0.f;
     if (sum_pow != 0.f) noise_power = (sum_pow - 2.0f * peak_pow) / float(n - 1);
-    const float thr = cfg.car_thr[0] + cfg.car_thr[1] * noise_power;
+    const float thr = float(cfg.car_thr[0]) + float(cfg.car_thr[1]) * noise_power;
     v.carrier = peak_pow > thr;
     v.index_error = false;
     v.peak_mag = sqrtf(peak_pow);
@@ -92,10 +92,10 @@ __device__ __forceinline__ PreshiftVerdict preshift_verdict(const DevCfg& cfg, f
     const float peak_pow = peak_mag * peak_mag;
     const float noise_pow = (sum_mag2 - 2.0f * peak_pow) / float(n - 1);   // carrier_detect.py:99-107
     const float noise_rms = sqrtf(noise_pow);
-    float thr = cfg.car_thr[0] + cfg.car_thr[1] * (noise_rms * noise_rms);
+    float thr = float(cfg.car_thr[0]) + float(cfg.car_thr[1]) * (noise_rms * noise_rms);
     if (cfg.car_want_std) {
         const double m1 = double(sum_mag) / n, m2 = double(sum_mag2) / n;
-        thr += cfg.car_thr[2] * float(m2 - m1 * m1);
+        thr += float(cfg.car_thr[2]) * float(m2 - m1 * m1);
     }
     thr = sqrtf(thr);
     v.carrier = peak_mag > thr;

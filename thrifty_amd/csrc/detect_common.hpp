@@ -21,8 +21,12 @@ struct DevCfg {
     int corr_len;      // block_len - template_len + 1
     int car_want_std;  // carrier threshold has a stddev term
     int cor_want_std;  // correlation threshold has a stddev term
-    float car_thr[3];
-    float cor_thr[3];
+    // threshold coefficients (constant, snr, stddev) exactly as given (Python floats = double).
+    // The correlation verdict is float64 arithmetic in the reference (soa_estimator.py:127-134);
+    // the carrier verdict combines them with float32 statistics, where NumPy >= 2 (NEP 50)
+    // first rounds the Python float to float32 -- the kernels narrow at that point, not here.
+    double car_thr[3];
+    double cor_thr[3];
     float tmpl_energy[kMaxTemplates];  // sum t^2 (soa_estimator.py:65)
     unsigned long long blk_stride;  // bytes from one block's first sample to the next one's: N * sample
                                     // size for packed blocks, 2 (N - H) for raw-stream framing
@@ -97,23 +101,9 @@ hipError_t launch_correlate_16k(int fmt, const void* samples, const DevCfg& cfg,
                                 hipStream_t stream);
 hipError_t launch_finish(int n_records, const DevCfg& cfg, const CorrStats* corr_stats,
                          thr_record* records, int* work_count, hipStream_t stream);
+int compact_tiles(int n_records);   // ints of tile scratch launch_compact needs
 hipError_t launch_compact(const thr_record* in, int n, thr_record* out, int* n_out,
-                          hipStream_t stream);
-
-// detect16k_w16.hip (same contract, 1024-thread / 16-wave geometry)
-hipError_t prepare_16k_w16();
-size_t lds_bytes_16k_w16();
-int table_cpx_16k_w16();
-hipError_t launch_carrier_16k_w16(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,
-                                  const float2* tables, const float2* twn, CarStats* stats,
-                                  float2* dump_fft, int grid, hipStream_t stream);
-hipError_t launch_correlate_16k_w16(int fmt, const void* samples, const DevCfg& cfg,
-                                    const float2* tables, const float2* twn, const float4* tspec,
-                                    const ShiftParams* shifts, const int* work_list,
-                                    const int* work_count, CorrStats* corr_stats,
-                                    thr_record* records, float4* xhat_scratch, float2* dump_xhat,
-                                    float2* dump_corr, int dump_template, int grid,
-                                    hipStream_t stream);
+                          int* tile_scratch, hipStream_t stream);
 
 // detect_long.hip (block_len = 2 or 4 x 16384: R0 LDS-resident sub-transforms per block)
 bool long_supported(int block_len);

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import argparse
 import sys
+import time
 from collections import deque, namedtuple
 from types import SimpleNamespace
 
@@ -27,6 +28,9 @@ DetectorSettings = namedtuple("DetectorSettings", [
     "template", "corr_thresh"])
 
 
+_SLOW_SOURCE_S = 0.002   # inter-arrival time above which Detector stops filling a batch
+
+
 def unique_window(block_len, history_len, template_len):
     """Half-open range of correlation lags owned by one block (reference
     soa_estimator.py:20-39)."""
@@ -34,6 +38,14 @@ def unique_window(block_len, history_len, template_len):
     corr_len = block_len - template_len + 1
     pad = history_len - template_len + 1
     return pad // 2, corr_len - (pad - pad // 2)
+
+
+class _Deferred(object):
+    """An exception that belongs to one position of a batch: raised when that position is
+    reached, after the results before it have been delivered."""
+
+    def __init__(self, exc):
+        self.exc = exc
 
 
 class Detector(object):
@@ -118,10 +130,19 @@ class Detector(object):
 
     def _results(self, stamps, idxs, recs):
         """Vectorised re-hydration of a batch of records (one .tolist() per column instead of
-        ten numpy-scalar look-ups per block)."""
+        ten numpy-scalar look-ups per block).  A block on which the reference raises IndexError
+        (carrier_sync.py:187) ends the list with a `_Deferred` exception: the results of the
+        blocks before it are still handed out, as the reference's per-block loop does."""
         flags = recs["flags"]
-        if np.any(flags & _native.FLAG_INDEX_ERROR) :
-            return [self._result(stamps[i], int(idxs[i]), recs[i]) for i in range(len(recs))]
+        bad = np.flatnonzero(flags & _native.FLAG_INDEX_ERROR)
+        if len(bad):
+            k = int(bad[0])
+            out = self._results(stamps[:k], idxs[:k], recs[:k])
+            try:
+                self._result(stamps[k], int(idxs[k]), recs[k])
+            except IndexError as exc:
+                out.append(_Deferred(exc))
+            return out
         fl = flags.tolist()
         cbin = recs["carrier_bin"].tolist()
         coff = (recs["carrier_offset"].tolist() if self._offset_type is float
@@ -151,7 +172,10 @@ class Detector(object):
         arr = self._stack([it[2] for it in items])
         idx = np.array([int(it[1]) for it in items], dtype=np.int64)
         recs = self._engine.detect(arr, idx)[:, 0]
-        return self._results([it[0] for it in items], idx, recs)
+        out = self._results([it[0] for it in items], idx, recs)
+        if out and isinstance(out[-1], _Deferred):
+            raise out[-1].exc
+        return out
 
     def detect(self, timestamp, block_idx, block):
         """Process one block (reference detect.py:60-78)."""
@@ -191,14 +215,22 @@ class Detector(object):
             return
         items = []
         while len(items) < self.batch_size and not self._exhausted:
+            t0 = time.perf_counter()
             try:
                 items.append(next(self.blocks))
             except StopIteration:
                 self._exhausted = True
+            # a source slower than ~500 blocks/s (a live receiver delivers ~200) gains nothing
+            # from batching: process what has arrived instead of waiting for a full batch
+            if time.perf_counter() - t0 > _SLOW_SOURCE_S:
+                break
         if self.yield_data:
             self._ready.extend(self.detect(*it) for it in items)
-        else:
-            self._ready.extend(self.detect_batch(items))
+        elif items:
+            arr = self._stack([it[2] for it in items])
+            idx = np.array([int(it[1]) for it in items], dtype=np.int64)
+            recs = self._engine.detect(arr, idx)[:, 0]
+            self._ready.extend(self._results([it[0] for it in items], idx, recs))
 
     def _emit(self, stamps, idxs, recs):
         if self.only_detections:
@@ -215,7 +247,12 @@ class Detector(object):
             self._refill()      # (a batch may contribute nothing under only_detections)
         if not self._ready:
             raise StopIteration
-        return self._ready.popleft()
+        item = self._ready.popleft()
+        if isinstance(item, _Deferred):
+            self._ready.clear()
+            self._exhausted = True      # the reference's loop died here
+            raise item.exc
+        return item
 
     def __call__(self, timestamp, block_idx, block):
         self.detect(timestamp, block_idx, block)
@@ -248,33 +285,6 @@ class MultiTemplateDetector(object):
         self._single = Detector.__new__(Detector)  # reuse record re-hydration
         self._single.settings, self._single.rxid, self._single.new_len = settings, rxid, self.new_len
         self._ready = deque()
-
-    def _results(self, stamps, idxs, recs):
-        """Vectorised re-hydration of a batch of records (one .tolist() per column instead of
-        ten numpy-scalar look-ups per block)."""
-        flags = recs["flags"]
-        if np.any(flags & _native.FLAG_INDEX_ERROR) :
-            return [self._result(stamps[i], int(idxs[i]), recs[i]) for i in range(len(recs))]
-        fl = flags.tolist()
-        cbin = recs["carrier_bin"].tolist()
-        coff = recs["carrier_offset"].tolist()
-        cen, cno = recs["carrier_energy"], recs["carrier_noise"]     # stay np.float32
-        samp = recs["corr_sample"].tolist()
-        soff = recs["corr_offset"].tolist()
-        en = recs["corr_energy"].astype(np.float64).tolist()
-        no = recs["corr_noise"].astype(np.float64).tolist()
-        out = []
-        Car, Cor, Res = toads_data.CarrierSyncInfo, toads_data.CorrDetectionInfo, toads_data.DetectionResult
-        for i in range(len(fl)):
-            f, bi = fl[i], int(idxs[i])
-            if not f & _native.FLAG_CARRIER:
-                out.append((False, Res(stamps[i], bi, None, Car(cbin[i], 0, cen[i], cno[i]), None, self.rxid)))
-                continue
-            det = bool(f & _native.FLAG_CORR)
-            cor = Cor(samp[i], soff[i] if det else 0, en[i], no[i])
-            out.append((det, Res(stamps[i], bi, self.new_len * bi + cor.sample + cor.offset,
-                                 Car(cbin[i], coff[i], cen[i], cno[i]), cor, self.rxid)))
-        return out
 
     def detect_batch(self, items):
         if not items:

@@ -50,8 +50,7 @@ def save_tpl(path, template):
 def fastdet_line(result):
     """One .toad line the way fastdet prints it (fastdet.cpp:188-206)."""
     cor, car = result.corr_info, result.carrier_info
-    sec = int(result.timestamp)
-    usec = int(round((result.timestamp - sec) * 1e6))
+    sec, usec = divmod(int(round(result.timestamp * 1e6)), 1000000)   # (carries into the seconds)
     return "%d %d.%06d %d %.8f %u %.12f %f %f %u %f %f %f" % (
         result.rxid, sec, usec, result.block, result.soa, cor.sample, cor.offset, cor.energy,
         cor.noise, car.bin, car.offset, car.energy, car.noise)
