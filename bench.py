@@ -1,15 +1,20 @@
 #!/usr/bin/env python3
 """Benchmark of the `thrifty detect` hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--mix dense|sparse]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3] [--templates T]
+                    [--batch B] [--mix dense|sparse]
 
 One "step" = one pass of the hot path (FFT -> carrier detect -> fit -> shift ->
 FFT -> x conj(T) -> IFFT -> SoA) over one batch of B synthetic IQ blocks that
-are already resident in HBM.  Workload = BASELINE.json configs[1]:
-block_len 16384, history 4096, 1023-chip Gold template, K*B (default
-128 * 8192 = 1 Mi) blocks per GPU.  Metric: IQ blocks/s, whole job.
+are already resident in HBM.  Workloads (BASELINE.json `configs`):
 
-For N > 1 launch with
+  --config c2 (default, the headline): configs[1] -- block_len 16384, history 4096,
+      1023-chip Gold template, K*B (default 32 * 32768 = 1 Mi) blocks per GPU
+  --config c2 --templates 4: configs[4] in its 1-GPU form -- 4 TX Gold templates per block
+  --config c3: configs[2] -- block_len 65536, history 4096, 2047-chip Gold code at 2 samples
+      per chip (W = 4094), the long-FFT regime (a block does not fit the LDS)
+
+Metric: IQ blocks/s, whole job.  For N > 1 launch with
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 Blocks are sharded by contiguous block-index ranges (weak scaling: K*B blocks
@@ -28,11 +33,20 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_BLOCK = 16384
-HISTORY = 4096
-SEED = 20260928 + 2
-RESIDENT_BLOCKS = 2 << 20
+SEED = 20260928
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X packed-fp32 VALU peak (MI355X_MICROARCH.md)
+WINDOW_BINS = (7, 110)
+THRESH = (0, 15, 0)
+
+# name -> (block_len, history, Gold register bits, samples per chip, default batch, resident blocks,
+#          BASELINE config index, handles per GPU)
+CONFIGS = {
+    "c2": dict(n=16384, h=4096, bits=10, sps=1.0, batch=32768, resident=2 << 20, idx=1, streams=2,
+               label="block_len=16384 history=4096 1023-chip Gold template (10-bit, 1 sample/chip)"),
+    "c3": dict(n=65536, h=4096, bits=11, sps=2.0, batch=4096, resident=1 << 18, idx=2, streams=1,
+               label="block_len=65536 history=4096 2047-chip Gold code at 2 samples/chip (W=4094)"),
+}
 
 
 def parse_args():
@@ -40,13 +54,16 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--batch", type=int, default=32768,
-                    help="blocks per step (per GPU); the default x 32 steps = BASELINE's 1 Mi blocks")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="blocks per step (per GPU); default per config (c2: 32768 x 32 steps = "
+                         "BASELINE's 1 Mi blocks)")
     ap.add_argument("--mix", choices=["dense", "sparse"], default="dense",
                     help="dense: every block carries a signal; sparse: 10%% do")
     ap.add_argument("--templates", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=2,
-                    help="engine handles (each with its own HIP stream) the steps alternate over")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="engine handles (each with its own HIP stream) the steps alternate over "
+                         "(default per config)")
     ap.add_argument("--profile-kernels", type=int, default=16,
                     help="n > 0: HIP events around the kernels of every n-th step of the timed "
                          "region (roofline leg; 1 = every step, costs ~4%%); 0 = off")
@@ -54,22 +71,24 @@ def parse_args():
                     help="default: reference Detector (the headline); preshift: the reference's "
                          "experimental PreshiftDetector (one fused kernel per block)")
     ap.add_argument("--preshift-num", type=int, default=21, help="bank size of --variant preshift")
-    ap.add_argument("--cpu-procs", type=int, default=0,
-                    help="n > 0: also time the CPU oracle on n worker processes (spawned; adds "
-                         "cpu_baseline.all_cores; off by default to keep the default run short)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0,
-                    help="wall budget of the CPU baseline leg (0 disables)")
+    ap.add_argument("--cpu-procs", type=int, default=-1,
+                    help="worker processes of the all-cores CPU leg (-1: one per physical core, "
+                         "0: skip the leg)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0,
+                    help="wall budget of the single-core CPU baseline leg (0 disables every CPU leg)")
+    ap.add_argument("--card-blocks", type=int, default=1024,
+                    help="blocks of the config-#1 .card -> .toad plumbing leg (0 skips it)")
     return ap.parse_args()
 
 
-def synth_on_device(torch, dev, gen, n_blocks, template, window, signal_frac, chunk=2048,
-                    truth=None):
+def synth_on_device(torch, dev, gen, n_blocks, n, template, window, signal_frac, chunk=0, truth=None):
     """SURVEY.md 8(d) generator, on the GPU: OOK burst 0.3*(t+1)/2 at a uniform lag in
     the unique window, carrier bin ~ U(10,100), AWGN sigma 0.02, u8 quantiser
     (x*128 + 127.4, truncating).  Returns uint8 [n_blocks, 2N]; if `truth` is a dict it
     receives the drawn lag / carrier bin / has-signal tensors (tests/test_gpu_fullsize.py)."""
-    n, w = N_BLOCK, len(template)
+    w = len(template)
     lo, hi = window
+    chunk = chunk or max(1, (2048 * 16384) // n)
     out = torch.empty((n_blocks, 2 * n), dtype=torch.uint8, device=dev)
     ook = torch.as_tensor(0.3 * (template + 1) / 2, dtype=torch.float32, device=dev)
     ar = torch.arange(w, device=dev)
@@ -95,17 +114,19 @@ def synth_on_device(torch, dev, gen, n_blocks, template, window, signal_frac, ch
     return out
 
 
-def cpu_baseline(blocks_u8, idx, template, budget_s, gpu_rec, n_templates, preshift_num=0):
-    """Oracle (oracle/thrifty_np.py, a NumPy port of the reference algorithm) timed on
-    host cores over a bounded sample of the same blocks; also spot-checks parity."""
+def make_oracle(n, h, template, preshift_num=0):
     from oracle import thrifty_np as onp
+    if preshift_num:
+        return onp.OraclePreshiftDetector(n, h, template, THRESH, WINDOW_BINS, THRESH, num=preshift_num)
+    return onp.OracleDetector(n, h, template, THRESH, WINDOW_BINS, THRESH)
+
+
+def cpu_baseline(n, h, blocks_u8, idx, template, budget_s, gpu_rec, preshift_num=0):
+    """Oracle (oracle/thrifty_np.py, a NumPy port of the reference algorithm) timed on ONE
+    host core over a bounded sample of the same blocks; also spot-checks parity."""
     from thrifty_amd import _native as F
     os.environ.setdefault("OMP_NUM_THREADS", "1")
-    if preshift_num:
-        orc = onp.OraclePreshiftDetector(N_BLOCK, HISTORY, template, (0, 15, 0), (7, 110), (0, 15, 0),
-                                         num=preshift_num)
-    else:
-        orc = onp.OracleDetector(N_BLOCK, HISTORY, template, (0, 15, 0), (7, 110), (0, 15, 0))
+    orc = make_oracle(n, h, template, preshift_num)
     done, mism = 0, 0
     t0 = time.perf_counter()
     for i in range(len(blocks_u8)):
@@ -122,29 +143,26 @@ def cpu_baseline(blocks_u8, idx, template, budget_s, gpu_rec, n_templates, presh
                   abs(r["corr_offset"] - res.corr.offset) <= 1e-4 + 1e-4 * abs(res.corr.offset))
         mism += 0 if ok else 1
         done += 1
-        if time.perf_counter() - t0 > budget_s and done >= 64:
+        if time.perf_counter() - t0 > budget_s and done >= 32:
             break
     dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "blocks/s", "cores": 1, "kind": "port",
-            "sample": "%d of the benchmark's own u8 blocks (single-template) through "
+            "sample": "%d of the benchmark's own u8 blocks (template 0) through "
                       "oracle/thrifty_np.py (NumPy %s pocketfft + SciPy curve_fit), 1 thread, %.1f s"
                       % (done, np.__version__, dt),
             "parity_checked": done, "parity_mismatches": mism}
 
 
-FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X packed-fp32 VALU peak (MI355X_MICROARCH.md)
-
-
-def _compute_view(kernel, n_templates, blocks_per_launch, avg_ms):
+def _compute_view(kernel, n, n_templates, blocks_per_launch, avg_ms):
     """Nominal flop of the dominant kernel per block -> achieved TFLOP/s vs the VALU peak."""
-    fft = 5.0 * N_BLOCK * np.log2(N_BLOCK)
-    point = 6.0 * N_BLOCK
-    if kernel == "k_correlate":      # shift, FFT#2, then per template: product, IFFT, |.|^2
-        flop = point + fft + n_templates * (point + fft + 3.0 * N_BLOCK)
+    fft = 5.0 * n * np.log2(n)
+    point = 6.0 * n
+    if kernel in ("k_correlate", "k_correlate_sub"):  # shift, FFT#2, then per template: product, IFFT, |.|^2
+        flop = point + fft + n_templates * (point + fft + 3.0 * n)
     elif kernel == "k_preshift":     # FFT#1, |X|^2, product, IFFT, |.|^2
-        flop = fft + 3.0 * N_BLOCK + point + fft + 3.0 * N_BLOCK
+        flop = fft + 3.0 * n + point + fft + 3.0 * n
     else:                            # carrier stage: FFT#1 (pruned variants do less) + |X|^2
-        flop = fft + 3.0 * N_BLOCK
+        flop = fft + 3.0 * n
     tflops = flop * blocks_per_launch / (avg_ms * 1e-3) / 1e12
     return {"flop_per_block_nominal": flop, "achieved_tflops": tflops,
             "peak_tflops": FP32_VECTOR_PEAK_TFLOPS, "frac": tflops / FP32_VECTOR_PEAK_TFLOPS}
@@ -153,27 +171,115 @@ def _compute_view(kernel, n_templates, blocks_per_launch, avg_ms):
 def _oracle_worker(job):
     """(spawned process) run the oracle over a slab of blocks; returns (n, seconds)."""
     os.environ["OMP_NUM_THREADS"] = "1"
-    blocks, template = job
-    from oracle import thrifty_np as onp
-    orc = onp.OracleDetector(N_BLOCK, HISTORY, template, (0, 15, 0), (7, 110), (0, 15, 0))
+    n, h, blocks, template = job
+    orc = make_oracle(n, h, template)
     t0 = time.perf_counter()
     for i in range(len(blocks)):
         orc.detect_u8(i, blocks[i])
     return len(blocks), time.perf_counter() - t0
 
 
-def cpu_all_cores(blocks_u8, template, procs, per_proc=384):
-    """Oracle throughput with `procs` spawned workers, each over its own slab of the blocks."""
+def physical_cores():
+    """(worker count, how it was derived): one per physical core of the CPUs this process may use."""
+    avail = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    cores = set()
+    for c in avail:
+        try:
+            with open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c) as f:
+                cores.add(f.read().strip())
+        except OSError:
+            cores.add(str(c))
+    return max(1, len(cores)), "%d logical CPUs available, %d distinct SMT sibling sets" % (len(avail), len(cores))
+
+
+def cpu_all_cores(n, h, blocks_u8, template, procs, single_rate, seconds=6.0):
+    """Oracle throughput with `procs` spawned workers (one per physical core), each over its own
+    slab of the blocks, sized from the single-core rate so the leg takes ~`seconds`."""
     import multiprocessing as mp
-    jobs = [(blocks_u8[(i * per_proc) % len(blocks_u8):][:per_proc], template) for i in range(procs)]
+    per_proc = int(max(4, min(len(blocks_u8), single_rate * seconds * 0.8)))
+    jobs = [(n, h, blocks_u8[(i * per_proc) % max(1, len(blocks_u8) - per_proc + 1):][:per_proc], template)
+            for i in range(procs)]
     ctx = mp.get_context("spawn")
     with ctx.Pool(procs) as pool:
-        pool.map(_oracle_worker, [(j[0][:4], template) for j in jobs])   # warm imports
+        pool.map(_oracle_worker, [(n, h, j[2][:2], template) for j in jobs])   # warm imports
         t0 = time.perf_counter()
         done = pool.map(_oracle_worker, jobs)
         dt = time.perf_counter() - t0
-    n = sum(d[0] for d in done)
-    return {"value": n / dt, "unit": "blocks/s", "procs": procs, "blocks": n, "seconds": dt}
+    nb = sum(d[0] for d in done)
+    return {"value": nb / dt, "unit": "blocks/s", "procs": procs, "blocks": nb, "seconds": dt}
+
+
+def card_to_toad_leg(n_card):
+    """BASELINE configs[0]: example detector.cfg + example template on a synthetic .card stream,
+    the whole plumbing path text -> parse -> detect -> .toad text.  CPU = the oracle (what the
+    reference does per line: base64 decode, (u8 - 127.4)/128, Detector.detect, serialize), one
+    core; GPU = thrifty_amd's `thrifty detect --quiet -o` path (CardStream framing, on-device
+    base64 decode, batched engine, column-wise .toad formatting).  The example template is a
+    data fixture (tests/golden/c1.npz holds it together with the example settings)."""
+    import base64
+    import io
+    from oracle import thrifty_np as onp
+    from thrifty_amd import block_data, synth
+    from thrifty_amd.detect import Detector, DetectorSettings
+    g = np.load(os.path.join(ROOT, "tests", "golden", "c1.npz"), allow_pickle=False)
+    n, h, tpl = int(g["block_len"]), int(g["history_len"]), g["template"]
+    cthr, cwin, xthr = tuple(g["carrier_thresh"]), tuple(int(v) for v in g["carrier_window"]), tuple(g["corr_thresh"])
+    rng = np.random.default_rng(SEED + 1)
+    ook = (tpl - tpl.min()) / (tpl.max() - tpl.min()) * 2 - 1     # synth draws 0.3 * (t + 1) / 2
+    seed_blocks, _ = synth.synth_blocks(rng, 64, n, ook, onp.unique_window(n, h, len(tpl)))
+    text = "".join(block_data.card_line(1000.0 + 0.005 * i, i, seed_blocks[i % 64]) for i in range(n_card)).encode()
+    # --- CPU: one core, the reference's per-line loop
+    orc = onp.OracleDetector(n, h, tpl, cthr, cwin, xthr)
+    n_cpu = min(n_card, 256)
+    lines = text.split(b"\n")[:n_cpu]
+    t0 = time.perf_counter()
+    cpu_out = []
+    for ln in lines:
+        ts, idx, enc = ln.decode("ascii").split(" ")
+        raw = np.frombuffer(base64.b64decode(enc), dtype=np.uint8)
+        (res,) = orc.detect_u8(int(idx), raw)
+        if res.detected:
+            cpu_out.append(onp.toad_line(0, float(ts), int(idx), res))
+    t_cpu = time.perf_counter() - t0
+    # --- GPU: the CLI's quiet path
+    st = DetectorSettings(n, h, len(tpl), cthr, cwin, tpl, xthr)
+    det = Detector(st, block_data.CardStream(io.BytesIO(text), n), rxid=0, batch_size=1024)
+    t0 = time.perf_counter()
+    gpu_out = [ln for lines_ in det.iter_toad_lines() for ln in lines_]
+    t_gpu = time.perf_counter() - t0
+    same = [a.split()[:3] + [a.split()[4], a.split()[8]] for a in gpu_out[:len(cpu_out)]] == \
+           [b.split()[:3] + [b.split()[4], b.split()[8]] for b in cpu_out]
+    return {"config": "BASELINE configs[0]: example detector.cfg settings (block 16384, history %d, %d-sample "
+                      "template, window bins %d..%d) on a synthetic .card stream" % (h, len(tpl), cwin[0], cwin[1]),
+            "cpu_blocks_per_s": n_cpu / t_cpu, "cpu_blocks": n_cpu, "cpu_cores": 1,
+            "gpu_blocks_per_s": n_card / t_gpu, "gpu_blocks": n_card,
+            "gpu_includes": "host framing, H2D of the base64 text (pageable), device decode, detection, D2H, .toad text",
+            "detections_cpu": len(cpu_out), "detections_gpu": len(gpu_out),
+            "first_lines_agree_on_rxid_time_block_sample_bin": bool(same)}
+
+
+def preflight(torch, dist, dev, rank, world, local, total, first):
+    """Fail early and legibly if the process group is not what the launch line says: RCCL sees
+    `world` ranks, every rank has its own device, and the block ranges tile [0, world * total)."""
+    one = torch.ones(1, dtype=torch.int64, device=dev)
+    dist.all_reduce(one)
+    if int(one.item()) != world:
+        raise SystemExit("pre-flight: all_reduce over %s counted %d ranks, expected %d"
+                         % (dist.get_backend(), int(one.item()), world))
+    mine = {"rank": rank, "local_rank": local, "device": torch.cuda.get_device_name(dev),
+            "pci": getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None),
+            "blocks": [first, first + total], "pid": os.getpid()}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    if rank == 0:
+        spans = sorted(e["blocks"] for e in everyone)
+        ok = spans[0][0] == 0 and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        if not ok or len({e["local_rank"] for e in everyone}) != world:
+            raise SystemExit("pre-flight: ranks do not tile the block range / share a device: %r" % (everyone,))
+        print("pre-flight ok: backend %s, %d rank(s); per-rank blocks: %s" % (
+            dist.get_backend(), world, ", ".join("r%d@cuda:%d [%d, %d)" % (
+                e["rank"], e["local_rank"], e["blocks"][0], e["blocks"][1]) for e in everyone)),
+            file=sys.stderr)
 
 
 def main():
@@ -184,6 +290,8 @@ def main():
     from thrifty_amd import _native as F
     from thrifty_amd import parallel, synth
 
+    cfg = CONFIGS[args.config]
+    n, h = cfg["n"], cfg["h"]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -199,33 +307,36 @@ def main():
     if use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
-    B, K, W = args.batch, args.steps, args.warmup
-    T = args.templates
-    tpls = np.stack([synth.gold_template(10, 2 + i) for i in range(T)]).astype(np.float64)
+    B = args.batch or cfg["batch"]
+    K, W, T = args.steps, args.warmup, args.templates
+    tpls = np.stack([synth.gold_template(cfg["bits"], 2 + i, cfg["sps"]) for i in range(T)]).astype(np.float64)
     wlen = tpls.shape[1]
-    pad = HISTORY - wlen + 1
-    window = (pad // 2, (N_BLOCK - wlen + 1) - (pad - pad // 2))
+    pad = h - wlen + 1
+    window = (pad // 2, (n - wlen + 1) - (pad - pad // 2))
 
     pnum = args.preshift_num if args.variant == "preshift" else 0
-    engs = [F.Engine(N_BLOCK, HISTORY, tpls, (0, 15, 0), (7, 110), (0, 15, 0), device_id=local,
-                     max_batch=B, preshift_num=pnum) for _ in range(max(1, args.streams))]
+    n_handles = max(1, args.streams or cfg["streams"])
+    engs = [F.Engine(n, h, tpls, THRESH, WINDOW_BINS, THRESH, device_id=local,
+                     max_batch=B, preshift_num=pnum) for _ in range(n_handles)]
     eng = engs[0]
     if len(engs) == 1:
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
 
-    # distinct blocks resident in HBM: every step has its own batch up to RESIDENT_BLOCKS
-    # (2 Mi blocks = 64 GiB of u8); longer runs cycle through them
-    resident_steps = max(1, min(K, RESIDENT_BLOCKS // B))
+    # distinct blocks resident in HBM: every step has its own batch up to the config's resident
+    # limit (c2: 2 Mi blocks = 64 GiB of u8); longer runs cycle through them
+    resident_steps = max(1, min(K, cfg["resident"] // B))
     total = resident_steps * B
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(SEED + rank)
-    frac = 1.0 if args.mix == "dense" else 0.1
-    t_gen = time.perf_counter()
-    data = synth_on_device(torch, dev, gen, total, tpls[0], window, frac)
-    torch.cuda.synchronize()
-    t_gen = time.perf_counter() - t_gen
     # contiguous block-index range per rank
     first = rank * total
+    if use_dist:
+        preflight(torch, dist, dev, rank, world, local, total, first)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(SEED + cfg["idx"] + 1 + rank)
+    frac = 1.0 if args.mix == "dense" else 0.1
+    t_gen = time.perf_counter()
+    data = synth_on_device(torch, dev, gen, total, n, tpls[0], window, frac)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
     idx = torch.arange(first, first + total, dtype=torch.int64, device=dev)
     rec = torch.zeros((total * T, 64), dtype=torch.uint8, device=dev)
     kept = torch.zeros_like(rec)
@@ -255,6 +366,7 @@ def main():
     for e in engs:
         e.profile_enable(0 if solo else args.profile_kernels)
         e.profile_read()  # reset accumulators
+    profiled_steps = 0
     t0 = time.perf_counter()
     for i in range(K):
         if solo and i % args.profile_kernels == 0:
@@ -264,7 +376,10 @@ def main():
             step(i)
             e.sync()
             e.profile_enable(0)
+            profiled_steps += 1
         else:
+            if not solo and args.profile_kernels > 0 and (i // len(engs)) % args.profile_kernels == 0:
+                profiled_steps += 1      # (the handle brackets every n-th of ITS batches)
             step(i)
     if len(engs) > 1:
         sync_engines()
@@ -290,56 +405,79 @@ def main():
     if rank == 0:
         blocks_total = world * K * B
         value = blocks_total / dt
-        bytes_per_block = 2 * N_BLOCK + 64 * T
+        bytes_per_block = 2 * n + 64 * T
+        rename = {}
         if pnum:   # the fused kernel is timed in k_correlate's event slot
-            prof = {("k_preshift" if k == "k_correlate" else k): v for k, v in prof.items()}
-        dom = max(prof, key=lambda k: prof[k][0])
-        dom_ms, dom_cnt = prof[dom]
+            rename["k_correlate"] = "k_preshift"
+        if n > 16384:   # long blocks: the correlate slot times the sub-transform kernel, per chunk
+            rename.update({"k_correlate": "k_correlate_sub", "k_carrier": "k_carrier_dit+k_select_dit"})
+        prof = {rename.get(k, k): v for k, v in prof.items() if v[1] > 0}
+        dom = max(prof, key=lambda k: prof[k][0]) if prof else None
+        dom_ms, dom_cnt = prof[dom] if prof else (0.0, 0)
         if dom_cnt == 0:  # --profile-kernels 0: fall back to the whole step
-            dom, avg_ms = "all kernels of one step", dt / K * 1e3
+            dom, avg_ms, units = "all kernels of one step", dt / K * 1e3, float(B)
         else:
             avg_ms = dom_ms / dom_cnt
-        achieved = bytes_per_block * B / (avg_ms * 1e-3) / 1e9
+            # blocks one launch of the dominant kernel processes (dense mix: every block reaches
+            # it); the long-block correlate stage launches once per chunk of work-list slots
+            units = B * max(profiled_steps, 1) / dom_cnt
+        achieved = bytes_per_block * units / (avg_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom, {}).get("bytes_per_launch_at_batch", {}).get(str(B))
+                key = args.config + ("_t%d" % T if T > 1 else "")
+                traffic = json.load(open(tpath)).get(key, {}).get(dom, {}).get("bytes_per_launch")
             except Exception:
                 traffic = None
+        metric = ("IQ blocks/sec (16384-sample, 1024-chip template)" if n == 16384
+                  else "IQ blocks/sec (%d-sample, %d-sample template)" % (n, wlen))
         line = {
-            "metric": "IQ blocks/sec (16384-sample, 1024-chip template)",
+            "metric": metric,
             "value": value, "unit": "blocks/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: block_len=16384 history=4096 "
-                                   "1023-chip Gold template (10-bit, 1 sample/chip), %s mix, "
-                                   "%d blocks per GPU resident in HBM as u8 IQ" % (args.mix, total),
+            "config": {"workload": "BASELINE configs[%d]: %s, %s mix, %d blocks per GPU resident in HBM "
+                                   "as u8 IQ" % (4 if (T > 1 and n == 16384) else cfg["idx"], cfg["label"],
+                                                 args.mix, total),
+                       "name": args.config,
                        "variant": args.variant if not pnum else "preshift(num=%d)" % pnum,
                        "blocks_per_step_per_gpu": B, "templates": T,
-                       "carrier_window": [7, 110], "thresholds": "15*snr",
+                       "carrier_window": list(WINDOW_BINS), "thresholds": "15*snr",
                        "parallelism": "block-shard x%d" % world,
                        "handles_per_gpu": len(engs),
                        "detections_gathered": int(gathered.shape[0])},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches": dom_cnt,
-                         "algorithmic_bytes_per_launch": bytes_per_block * B,
+                         "blocks_per_launch": units,
+                         "algorithmic_bytes_per_block": bytes_per_block,
+                         "algorithmic_bytes_per_launch": bytes_per_block * units,
                          "all_kernels_ms": {k: v[0] / max(v[1], 1) for k, v in prof.items()},
+                         "all_kernels_launches_per_step": {k: v[1] / max(profiled_steps, 1) for k, v in prof.items()},
                          # the kernel is VALU/LDS-bound, so the honest secondary view:
                          # nominal 5 N log2 N flop per transform done by THIS kernel (+ 6N per
                          # pointwise product) against the fp32 vector peak
-                         "compute": _compute_view(dom, T, B, avg_ms)},
+                         "compute": _compute_view(dom, n, T, units, avg_ms)},
             "data_gen_s": t_gen,
         }
         if world == 1 and args.cpu_seconds > 0:
-            ns = min(total, 16384)
+            ns = min(total, 16384 if n == 16384 else 2048)
+            host_blocks = data[:ns].cpu().numpy()
             line["cpu_baseline"] = cpu_baseline(
-                data[:ns].cpu().numpy(), np.arange(first, first + ns), tpls[0], args.cpu_seconds,
-                rec.view(total, T, 64)[:ns, 0].cpu().numpy().view(F.RECORD_DTYPE).reshape(-1), T, pnum)
-            if args.cpu_procs > 0 and not pnum:
-                line["cpu_baseline"]["all_cores"] = cpu_all_cores(
-                    data[:ns].cpu().numpy(), tpls[0], args.cpu_procs)
+                n, h, host_blocks, np.arange(first, first + ns), tpls[0], args.cpu_seconds,
+                rec.view(total, T, 64)[:ns, 0].cpu().numpy().view(F.RECORD_DTYPE).reshape(-1), pnum)
+            procs, how = physical_cores()
+            if args.cpu_procs >= 0:
+                procs, how = args.cpu_procs, "--cpu-procs"
+            if procs > 0 and not pnum:
+                ac = cpu_all_cores(n, h, host_blocks, tpls[0], procs, line["cpu_baseline"]["value"])
+                ac["procs_from"] = how
+                line["cpu_baseline"]["all_cores"] = ac
+            if args.card_blocks > 0 and args.config == "c2" and T == 1 and not pnum:
+                for e in engs:      # free the benchmark's engines before the plumbing leg creates its own
+                    e.close()
+                line["cpu_baseline"]["card_to_toad"] = card_to_toad_leg(args.card_blocks)
         print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()

@@ -25,7 +25,9 @@ extern "C" {
 
 /* 2: + thr_create_preshift / thr_create_fastdet, thr_detect_stream[_device], thr_detect_card,
  *    thr_identify (additions only: every version-1 entry point is unchanged) */
-#define THR_ABI_VERSION 2
+/* 3: THR_N_KERNEL_SLOTS 4 -> 5 (the arrays of thr_profile_read grow; slot 4 = the long-block
+ *    combination kernel); everything else unchanged */
+#define THR_ABI_VERSION 3
 
 /* status codes */
 #define THR_OK 0
@@ -201,7 +203,8 @@ int thr_set_stream(thr_handle* h, void* hip_stream);
 /*
  * K7: keep only records whose THR_FLAG_CORR is set, preserving order -- what
  * detector_cli's `if detected: print(result.serialize())` does (detect.py:217-219).
- * Device pointers; `*n_kept` is written on the host after an internal sync.
+ * Device pointers (`d_in` and `d_out` must not overlap); `*n_kept` is written on the host
+ * after an internal sync.
  */
 int thr_compact_device(thr_handle* h, const thr_record* d_in, size_t n_records,
                        thr_record* d_out, size_t* n_kept);
@@ -212,9 +215,11 @@ int thr_compact_device(thr_handle* h, const thr_record* d_in, size_t n_records,
  * batch with events (n = 1: all; sampling keeps the ~35 us/batch cost of the event
  * packets out of most steps); 0 disables.  thr_profile_read() syncs and returns accumulated
  * milliseconds and launch counts per kernel slot and resets the accumulators.
- * Slots: 0 = carrier (FFT#1 + peak), 1 = fit, 2 = correlate (FFT#2..peak), 3 = finish (SoA).
+ * Slots: 0 = carrier (FFT#1 + peak), 1 = fit, 2 = correlate (FFT#2..peak; long blocks: the
+ * sub-transform kernel, one launch per chunk of work-list slots), 3 = finish (SoA),
+ * 4 = combine (long blocks only: radix-R0 combination + peak, one launch per chunk).
  */
-#define THR_N_KERNEL_SLOTS 4
+#define THR_N_KERNEL_SLOTS 5
 int thr_profile_enable(thr_handle* h, int on);
 int thr_profile_read(thr_handle* h, double ms[THR_N_KERNEL_SLOTS],
                      int64_t launches[THR_N_KERNEL_SLOTS]);

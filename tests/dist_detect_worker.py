@@ -1,0 +1,65 @@
+"""One rank of the multi-GPU parity run (started by tests/test_gpu_distributed.py through
+`python -m torch.distributed.run`): shard_range -> Engine.detect_device -> compact_device ->
+gather_records over the **nccl** (= RCCL) backend; rank 0 saves what it gathered.
+
+All ranks synthesise the same seeded blocks and take their own contiguous range, as
+`bench.py --gpus N` and `thrifty detect --gpus N` do."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def make_blocks(n_blocks, seed):
+    from thrifty_amd import synth
+    from thrifty_amd.detect import unique_window
+    tpl = synth.gold_template(10, 2)
+    rng = np.random.default_rng(seed)
+    blocks, _ = synth.synth_blocks(rng, n_blocks, 16384, tpl, unique_window(16384, 4096, len(tpl)),
+                                   signal_frac=0.6)
+    return tpl, blocks
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--blocks", type=int, default=203)
+    ap.add_argument("--seed", type=int, default=77)
+    ap.add_argument("--out", required=True)
+    args = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+    from thrifty_amd import _native as F
+    from thrifty_amd import parallel
+
+    rank, world, local = parallel.torchrun_env()
+    assert world is not None, "start me with torch.distributed.run"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", device_id=dev)
+    assert dist.get_backend() == "nccl" and dist.get_world_size() == world
+    tpl, blocks = make_blocks(args.blocks, args.seed)
+    lo, hi = parallel.shard_range(args.blocks, rank, world)
+    n = hi - lo
+    eng = F.Engine(16384, 4096, tpl, (0, 15, 0), (7, 110), (0, 15, 0), device_id=local, max_batch=max(n, 1))
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    data = torch.from_numpy(blocks[lo:hi].copy()).to(dev)
+    idx = torch.arange(lo, hi, dtype=torch.int64, device=dev)
+    rec = torch.zeros((max(n, 1), 64), dtype=torch.uint8, device=dev)
+    kept = torch.zeros_like(rec)
+    if n:
+        eng.detect_device(data.data_ptr(), F.THR_IN_U8, n, rec.data_ptr(), idx.data_ptr())
+    n_kept = eng.compact_device(rec.data_ptr(), n, kept.data_ptr())
+    gathered = parallel.gather_records(kept[:n_kept], world, rank, dev, force=True)
+    torch.cuda.synchronize()
+    if rank == 0:
+        np.save(args.out, gathered.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,96 @@
+"""Multi-GPU path on real devices (BASELINE configs[3] / [4]): one process per GPU under
+`torch.distributed.run`, **nccl** (RCCL) backend.  K = 1 always runs (same code path, same
+collectives); K = 2 and 8 run when the box has that many GPUs.  Rank 0's gathered records
+must equal the single-process result byte for byte, ordered by block index."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _world_sizes():
+    try:
+        import torch
+        n = torch.cuda.device_count()
+    except Exception:
+        n = 1
+    return [k for k in (1, 2, 8) if k <= max(n, 1)]
+
+
+def _torchrun(k, target, extra, timeout=600):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(k),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + target + extra
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    return res
+
+
+@pytest.mark.parametrize("k", _world_sizes())
+def test_shard_detect_compact_gather_equals_single_process(tmp_path, k):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dist_detect_worker as w
+    from thrifty_amd import _native as F
+    n_blocks, seed = 203, 77            # not a multiple of 2 or 8: uneven shards
+    out = str(tmp_path / "gathered.npy")
+    _torchrun(k, [os.path.join(ROOT, "tests", "dist_detect_worker.py")],
+              ["--blocks", str(n_blocks), "--seed", str(seed), "--out", out])
+    got = np.load(out).reshape(-1).view(F.RECORD_DTYPE)
+    tpl, blocks = w.make_blocks(n_blocks, seed)
+    eng = F.Engine(16384, 4096, tpl, (0, 15, 0), (7, 110), (0, 15, 0), max_batch=n_blocks)
+    rec = eng.detect(blocks, np.arange(n_blocks))[:, 0]
+    want = rec[(rec["flags"] & F.FLAG_CORR) != 0]
+    assert len(want) > 50
+    assert got.tobytes() == want.tobytes()
+    assert np.all(np.diff(got["block_idx"]) > 0)
+
+
+def _write_case(tmp_path, g, raw=False):
+    from thrifty_amd import block_data
+    np.save(tmp_path / "template.npy", g["template"])
+    (tmp_path / "detector.cfg").write_text(
+        "rxid: 0\nsample_rate: 2.4M\nblock_size: 16384\nblock_history: 4096\n"
+        "carrier_window: 7 - 110\ncarrier_threshold: 15 * snr\ncorr_threshold: 15*snr\n"
+        "template: %s\n" % (tmp_path / "template.npy"))
+    text = "# synthetic\n" + "".join(
+        block_data.card_line(1000.0 + i, int(g["block_idx"][i]), g["blocks"][i])
+        for i in range(len(g["blocks"])))
+    (tmp_path / "rx.card").write_text(text)
+
+
+@pytest.mark.parametrize("k", _world_sizes())
+def test_thrifty_detect_gpus_cli_writes_the_single_process_toad(golden, tmp_path, k):
+    """`python -m thrifty_amd.detect --gpus K rx.card -o rx.toad` (re-launches itself under
+    torch.distributed.run) == the single-process CLI's file, byte for byte; and that file is
+    the reference's .toad within the parity tolerances."""
+    from thrifty_amd.detect import Detector, detector_cli
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_detector_api import assert_toad_close
+    g = golden("c2")
+    _write_case(tmp_path, g)
+    common = [str(tmp_path / "rx.card"), "--quiet", "-c", str(tmp_path / "detector.cfg")]
+    detector_cli(Detector, argv=common + ["-o", str(tmp_path / "one.toad")])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+    res = subprocess.run([sys.executable, "-m", "thrifty_amd.detect", "--gpus", str(k)] + common +
+                         ["-o", str(tmp_path / "many.toad")], env=env, cwd=ROOT, capture_output=True,
+                         text=True, timeout=600)
+    if k == 1:      # --gpus 1 is the plain single-process CLI; also run it as ONE rank under torchrun
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+        _torchrun(1, ["-m", "thrifty_amd.detect"], ["--gpus", "1"] + common + ["-o", str(tmp_path / "rank.toad")])
+        assert (tmp_path / "rank.toad").read_text() == (tmp_path / "one.toad").read_text()
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert (tmp_path / "many.toad").read_text() == (tmp_path / "one.toad").read_text()
+    assert_toad_close((tmp_path / "one.toad").read_text().strip().split("\n"), g["toad"])

@@ -26,7 +26,7 @@ def workload():
     gen = torch.Generator(device=dev)
     gen.manual_seed(bench.SEED)
     truth = {}
-    data = bench.synth_on_device(torch, dev, gen, TOTAL, tpl, window, 0.9, truth=truth)
+    data = bench.synth_on_device(torch, dev, gen, TOTAL, 16384, tpl, window, 0.9, truth=truth)
     truth = {k: torch.cat(v).cpu().numpy() for k, v in truth.items()}
     torch.cuda.synchronize()
     return torch, dev, tpl, window, data, truth

@@ -1,0 +1,49 @@
+"""Large-sample oracle parity inside the suite: thousands of FRESH seeded C2 blocks through each
+carrier kernel (full-spectrum with and without the stddev terms, pruned), GPU records against
+the CPU oracle.  Carrier bin, SoA sample index and both verdicts must match on every block;
+sub-sample offset within 5e-6, energies within 2e-5 relative (BASELINE asks for 1e-4)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import soak_util  # noqa: E402
+from oracle import thrifty_np as onp  # noqa: E402
+from thrifty_amd import _native as F  # noqa: E402
+from thrifty_amd import synth  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+N, H = 16384, 4096
+
+CASES = [
+    # name, blocks, carrier_thresh, carrier_window, corr_thresh, which carrier kernel it exercises
+    ("full_spectrum_window", 4096, (0, 15, 0), (0, -1), (0, 15, 0), "k_carrier<STD=false>"),
+    ("stddev_terms", 4096, (0, 12, 1.5), (0, -1), (0, 12, 0.5), "k_carrier<STD=true>, k_correlate<STD=true>"),
+    ("wide_window", 1024, (0, 15, 0), (-300, 300), (0, 15, 0), "k_carrier, wrapping window of 601 bins"),
+    ("pruned", 1024, (0, 15, 0), (7, 110), (0, 15, 0), "k_carrier_pruned"),
+    ("pruned_shifted", 512, (0, 15, 0), (-40, 60), (0, 15, 0), "k_carrier_pruned<SHIFTED>"),
+]
+
+
+@pytest.mark.parametrize("name,nb,cthr,cwin,xthr,what", CASES, ids=[c[0] for c in CASES])
+def test_fresh_blocks_equal_the_oracle(name, nb, cthr, cwin, xthr, what):
+    rng = np.random.default_rng(4242 + [c[0] for c in CASES].index(name))
+    tpl = synth.gold_template(10, 3).astype(np.float64)
+    win = onp.unique_window(N, H, len(tpl))
+    lo_bin = 10.0 if cwin[0] >= 0 else -35.0       # carriers inside the window (negative bins too)
+    hi_bin = 100.0 if cwin[0] >= 0 else 55.0
+    blocks, _ = synth.synth_blocks(rng, nb, N, tpl, win, signal_frac=0.85, carrier_bins=(lo_bin, hi_bin))
+    eng = F.Engine(N, H, tpl, cthr, cwin, xthr, max_batch=1024)
+    rec = eng.detect(blocks, np.arange(nb))[:, 0]
+    rows = soak_util.run_oracle(blocks, N, H, tpl, cthr, cwin, xthr)
+    mism, worst, ties = soak_util.compare(rec, rows, blocks, F.FLAG_CARRIER, F.FLAG_CORR)
+    n_det = sum(1 for r in rows if r is not None and r[5])
+    assert n_det > 0.5 * nb, (n_det, nb)
+    assert mism == dict(bin=0, carrier=0, sample=0, det=0, index_error=0), (what, mism, worst, ties)
+    assert len(ties) <= 1, ties                     # (1 in ~1e6 blocks in the round-1 soak)
+    assert worst["offset"] <= 5e-6, worst
+    assert worst["energy"] <= 2e-5 and worst["noise"] <= 2e-5 and worst["car_energy"] <= 2e-5, worst
+    assert worst["car_off"] <= 2e-4, worst

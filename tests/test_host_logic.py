@@ -199,7 +199,8 @@ def test_library_exports_every_declared_symbol():
     for sym in declared:
         assert (" T " + sym) in out, sym
     lib = _native.load_library()
-    assert lib.thr_abi_version() == 2
+    m = re.search(r"#define THR_ABI_VERSION (\d+)", header)
+    assert lib.thr_abi_version() == int(m.group(1)) == _native.ABI_VERSION
     assert _native.RECORD_DTYPE.itemsize == 64
 
 
@@ -273,7 +274,11 @@ def test_product_package_does_not_import_the_oracle():
     bench_src = open(os.path.join(ROOT, "bench.py")).read()
     for m in re.finditer(r"^\s*from oracle import", bench_src, re.M):
         enclosing = re.findall(r"^def (\w+)\(", bench_src[:m.start()], re.M)[-1]
-        assert enclosing in ("cpu_baseline", "_oracle_worker"), enclosing
+        assert enclosing in ("make_oracle", "card_to_toad_leg"), enclosing   # the cpu_baseline legs
+    for fn in ("make_oracle", "card_to_toad_leg"):     # ... and only those legs call them
+        users = {re.findall(r"^def (\w+)\(", bench_src[:m.start()], re.M)[-1]
+                 for m in re.finditer(r"\b%s\(" % fn, bench_src) if not bench_src[:m.start()].endswith("def ")}
+        assert users <= {"cpu_baseline", "_oracle_worker", "main"}, (fn, users)
     header = open(os.path.join(ROOT, "oracle", "thrifty_np.py")).read()
     assert "TEST INFRASTRUCTURE ONLY" in header and "PINNED" in header
 
@@ -367,3 +372,39 @@ def test_batch_readers_map_regular_files(tmp_path):
         b, cm = card_collect(f)
         assert isinstance(cm._buf, mmap.mmap)
     assert a == b and len(a) == 9
+
+
+def test_toad_lines_equal_per_record_serialize():
+    """The column-at-a-time .toad formatter writes exactly what building each DetectionResult
+    (as Detector._results does) and calling serialize() writes (reference toads_data.py:47-61)."""
+    rng = np.random.default_rng(11)
+    n = 400
+    recs = np.zeros(n, dtype=_native.RECORD_DTYPE)
+    recs["block_idx"] = rng.integers(0, 1 << 40, n)
+    recs["flags"] = 3
+    recs["carrier_bin"] = rng.integers(0, 16384, n)
+    recs["corr_sample"] = rng.integers(0, 16384, n)
+    scale = 10.0 ** rng.integers(-8, 9, n)
+    recs["corr_offset"] = rng.uniform(-0.6, 0.6, n)
+    recs["carrier_offset"] = rng.normal(0, 2, n)
+    for f in ("corr_energy", "corr_noise", "carrier_energy", "carrier_noise"):
+        recs[f] = (rng.uniform(0.1, 10, n) * scale).astype(np.float32)
+    recs["corr_offset"][:3] = [0.0, -0.0, 1e-5]
+    recs["carrier_energy"][:4] = [1e-4, 9.9e-5, 123456792.0, 1e16]
+    stamps = rng.uniform(1.5e9, 1.6e9, n)
+    new_len = 12288
+    for rxid in (None, 4):
+        for otype in (float, np.float32):
+            want = []
+            for i in range(n):
+                r = recs[i]
+                car = toads_data.CarrierSyncInfo(int(r["carrier_bin"]), otype(r["carrier_offset"]),
+                                                 np.float32(r["carrier_energy"]), np.float32(r["carrier_noise"]))
+                cor = toads_data.CorrDetectionInfo(int(r["corr_sample"]), float(r["corr_offset"]),
+                                                   float(r["corr_energy"]), float(r["corr_noise"]))
+                bi = int(r["block_idx"])
+                want.append(toads_data.DetectionResult(stamps[i], bi, new_len * bi + cor.sample + cor.offset,
+                                                       car, cor, rxid).serialize())
+            got = toads_data.toad_lines(recs, stamps, new_len, rxid=rxid, carrier_offset_type=otype)
+            assert got == want
+    assert toads_data.toad_lines(recs[:0], stamps[:0], new_len) == []

@@ -67,3 +67,170 @@ def test_gather_records_two_ranks(counts):
     idx = got[:, :8].copy().view(np.int64).reshape(-1)
     assert np.array_equal(idx, np.arange(sum(counts)))          # globally ordered
     assert list(got[:, 8]) == [1] * counts[0] + [2] * counts[1]  # rank order
+
+
+# ---------------------------------------------------------------------------------------------
+# `thrifty detect --gpus N` host logic: reader sharding and the sharded run (gloo stands in for
+# RCCL; the engine is replaced by a deterministic record maker -- no GPU here)
+# ---------------------------------------------------------------------------------------------
+def _card_file(tmp_path, n, block_len=64, comments=True):
+    from thrifty_amd import block_data
+    rng = np.random.default_rng(5)
+    path = tmp_path / "rx.card"
+    with open(path, "w") as f:
+        if comments:
+            f.write("# header line\nUsing Volk machine: avx2\n")
+        for i in range(n):
+            if comments and i % 5 == 3:
+                f.write("# note\n\n")
+            f.write(block_data.card_line(100.0 + 0.25 * i, 10 + i, rng.integers(0, 256, 2 * block_len, dtype=np.uint8)))
+    return path
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("n", [0, 1, 7, 40])
+def test_card_stream_shards_partition_the_file_in_order(tmp_path, n, world):
+    from thrifty_amd import block_data
+    path = _card_file(tmp_path, n)
+    with open(path, "rb") as f:
+        full = block_data.CardStream(f, 64).next_batch(10 ** 6)
+    want = [] if full is None else full[1].tolist()
+    got, sizes = [], []
+    for r in range(world):
+        with open(path, "rb") as f:
+            cs = block_data.CardStream(f, 64).shard(r, world)
+            mine = []
+            while True:
+                b = cs.next_batch(3)
+                if b is None:
+                    break
+                stamps, idxs, text, offs = b
+                for ts, i, o in zip(stamps, idxs, offs):        # payloads really are this block's
+                    assert ts == 100.0 + 0.25 * (int(i) - 10)
+                mine.extend(idxs.tolist())
+            sizes.append(len(mine))
+            got.extend(mine)
+    assert got == want
+    if n >= 8 * world:
+        assert max(sizes) - min(sizes) <= 2, sizes
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_raw_stream_shards_partition_the_file_in_order(tmp_path, world):
+    from thrifty_amd import block_data
+    size, hist = 64, 24          # lead-in: ceil(24 / 40) = 1 block
+    data = np.random.default_rng(6).integers(0, 256, 2 * (size - hist) * 23 + 10, dtype=np.uint8)
+    path = tmp_path / "rx.bin"
+    data.tofile(path)
+
+    def collect(rs):
+        out = []
+        while True:
+            b = rs.next_batch(4)
+            if b is None:
+                return out
+            kind, stamps, idxs, payload = b
+            step, carry = 2 * (size - hist), 2 * hist
+            for k, i in enumerate(idxs.tolist()):
+                if kind == "u8":
+                    blk = bytes(payload[k * step:k * step + carry + step])
+                    out.append((i, "u8", blk))
+                else:
+                    out.append((i, "c64", payload[k].tobytes()))
+
+    with open(path, "rb") as f:
+        want = collect(block_data.RawStream(f, size, hist))
+    got = []
+    for r in range(world):
+        with open(path, "rb") as f:
+            got.extend(collect(block_data.RawStream(f, size, hist).shard(r, world)))
+    assert [g[0] for g in got] == list(range(23))
+    assert got == want
+
+
+def test_pipes_cannot_be_sharded():
+    import io
+    from thrifty_amd import block_data
+    with pytest.raises(ValueError):
+        block_data.CardStream(io.BytesIO(b""), 64).shard(1, 2)
+    with pytest.raises(ValueError):
+        block_data.RawStream(io.BytesIO(b""), 64, 16).shard(1, 2)
+
+
+class _FakeDetections(object):
+    """What run_sharded needs of a Detector: records of detected blocks for this rank's range.
+    Record content is a pure function of the global block position, so the sharded result can
+    be compared with a one-rank run."""
+
+    new_len, rxid, _offset_type = 48, 3, float
+
+    def __init__(self, lo, hi, fail_at=None):
+        self.lo, self.hi, self.fail_at = lo, hi, fail_at
+
+    @staticmethod
+    def records(positions):
+        from thrifty_amd import _native
+        r = np.zeros(len(positions), dtype=_native.RECORD_DTYPE)
+        p = np.asarray(positions, dtype=np.int64)
+        r["block_idx"], r["flags"], r["carrier_bin"] = p + 1000, 3, 10 + p % 90
+        r["corr_sample"], r["corr_offset"] = 5 + p % 7, 0.1 * np.sin(p)
+        r["carrier_offset"] = np.cos(p) / 3
+        r["corr_energy"], r["corr_noise"] = 100.0 + p, 1.0 + (p % 3)
+        r["carrier_energy"], r["carrier_noise"] = 50.0 + p / 7.0, 0.5
+        return r
+
+    def iter_detected_records(self):
+        for s in range(self.lo, self.hi, 5):
+            pos = [p for p in range(s, min(s + 5, self.hi)) if p % 3 != 1]      # some blocks undetected
+            if self.fail_at is not None and any(p >= self.fail_at for p in range(s, min(s + 5, self.hi))):
+                pos = [p for p in pos if p < self.fail_at]
+                if pos:
+                    yield 0.5 * np.asarray(pos, dtype=np.float64), self.records(pos)
+                raise IndexError("index 65 is out of bounds for axis 0 with size 64")
+            if pos:
+                yield 0.5 * np.asarray(pos, dtype=np.float64), self.records(pos)
+
+
+def _sharded_worker(rank, world, port, n, fail_at, out_path, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    lo, hi = parallel.shard_range(n, rank, world)
+    det = _FakeDetections(lo, hi, fail_at if fail_at is not None and lo <= fail_at < hi else None)
+    out = open(out_path, "w") if rank == 0 else None
+    try:
+        parallel.run_sharded(det, rank, world, 0, out, backend="gloo")
+        ret.put((rank, None))
+    except IndexError as exc:
+        ret.put((rank, str(exc)))
+    finally:
+        if out is not None:
+            out.close()
+
+
+@pytest.mark.parametrize("fail_at", [None, 13])
+def test_run_sharded_two_ranks_writes_one_ordered_toad(tmp_path, fail_at):
+    import torch.multiprocessing as mp
+    from thrifty_amd import toads_data
+    n, world = 23, 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    out_path = str(tmp_path / "rx.toad")
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, n, fail_at, out_path, ret))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(ret.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # what ONE process over the whole range writes (and where it would have died)
+    stop = n if fail_at is None else fail_at
+    pos = [p for p in range(stop) if p % 3 != 1]
+    want = toads_data.toad_lines(_FakeDetections.records(pos), 0.5 * np.asarray(pos, dtype=np.float64),
+                                 _FakeDetections.new_len, rxid=_FakeDetections.rxid)
+    got = open(out_path).read().split("\n")
+    assert got[-1] == "" and got[:-1] == want
+    if fail_at is None:
+        assert results == {0: None, 1: None}
+    else:       # every rank raises, like the single-process loop
+        assert "out of bounds" in results[1] and "IndexError" in results[0], results

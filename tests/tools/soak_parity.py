@@ -41,7 +41,7 @@ def main():
     window = (pad // 2, (N - len(tpl) + 1) - (pad - pad // 2))
     gen = torch.Generator(device=dev)
     gen.manual_seed(777)
-    data = bench.synth_on_device(torch, dev, gen, total, tpl, window, 0.9)
+    data = bench.synth_on_device(torch, dev, gen, total, N, tpl, window, 0.9)
     eng = F.Engine(N, H, tpl, (0, 15, 0), (7, 110), (0, 15, 0), max_batch=8192,
                    preshift_num=21 if variant == "preshift" else 0)
     rec = torch.zeros((total, 64), dtype=torch.uint8, device=dev)

@@ -18,9 +18,9 @@ THR_IN_C64 = 1
 FLAG_CARRIER = 1
 FLAG_CORR = 2
 FLAG_INDEX_ERROR = 4
-N_KERNEL_SLOTS = 4
+N_KERNEL_SLOTS = 5
 
-ABI_VERSION = 2     # THR_ABI_VERSION of include/thrifty_hip.h
+ABI_VERSION = 3     # THR_ABI_VERSION of include/thrifty_hip.h
 
 EXPORTS = [
     "thr_abi_version", "thr_last_error", "thr_create", "thr_destroy", "thr_detect",

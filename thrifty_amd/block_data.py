@@ -181,6 +181,28 @@ class CardStream(object):
         self._end = 0   # one past the last valid byte
         self._eof = False
 
+    def shard(self, rank, world):
+        """Restrict a mapped .card file to the rank-th of `world` contiguous byte ranges, cut at
+        line starts (a line belongs to the range its first byte lies in).  Lines have one length,
+        so the ranges hold equal block counts to within one, and concatenating the ranks'
+        outputs in rank order reproduces the file's order."""
+        if world <= 1:
+            return self
+        if not isinstance(self._buf, mmap.mmap):
+            raise ValueError("only a regular file can be sharded over GPUs (not a pipe)")
+        start, end = self._pos, self._end
+
+        def line_start(p):
+            if p <= start:
+                return start
+            k = self._buf.find(b"\n", p - 1, end)
+            return end if k < 0 else k + 1
+
+        span = end - start
+        self._pos = line_start(start + span * rank // world)
+        self._end = line_start(start + span * (rank + 1) // world) if rank + 1 < world else end
+        return self
+
     def _fill(self):
         """Compact the unconsumed tail to the front and read more; returns bytes added."""
         if self._eof:
@@ -294,6 +316,28 @@ class RawStream(object):
         # regular file: overlapping blocks are plain slices of the mapping (no carry, no copy)
         self._map, self._off = _map_regular_file(stream)
         self._origin = self._off    # stream byte 0 (the caller may have consumed a header)
+        self._stop_idx = None       # sharded mapped file: one past this rank's last block
+
+    def shard(self, rank, world):
+        """Restrict a mapped raw file to this rank's contiguous block range.  The lead-in blocks
+        (zero initial history) stay with rank 0; the rest is split evenly."""
+        if world <= 1:
+            return self
+        if self._map is None:
+            raise ValueError("only a regular file can be sharded over GPUs (not a pipe)")
+        step = 2 * self.new
+        total = (len(self._map) - self._origin) // step
+        lead = min(self._n_lead, total)
+        base, rem = divmod(total - lead, world)
+        lo = lead + rank * base + min(rank, rem)
+        hi = lo + base + (1 if rank < rem else 0)
+        if rank == 0:
+            lo = 0
+        else:
+            self._next_idx = lo
+            self._off = self._origin + lo * step
+        self._stop_idx = hi
+        return self
 
     def _read_upto(self, want_end, need_end=None):
         """Read until `need_end` valid bytes are buffered (default: want_end) or EOF, never
@@ -372,7 +416,8 @@ class RawStream(object):
         m, size = self._map, len(self._map)
         if self._next_idx < self._n_lead:
             blocks, idxs = [], []
-            while len(blocks) < max_blocks and self._next_idx < self._n_lead and self._off + step <= size:
+            while (len(blocks) < max_blocks and self._next_idx < self._n_lead and self._off + step <= size
+                   and (self._stop_idx is None or self._next_idx < self._stop_idx)):
                 chunk = np.frombuffer(m, dtype=np.uint8, count=step, offset=self._off)
                 self._lead = np.concatenate([self._lead[self.new:], raw_to_complex(chunk)])
                 blocks.append(self._lead)
@@ -383,6 +428,8 @@ class RawStream(object):
                 return None
             return "c64", [time.time()] * len(blocks), np.asarray(idxs, dtype=np.int64), np.stack(blocks)
         n = min(max_blocks, (size - self._off) // step)
+        if self._stop_idx is not None:
+            n = min(n, self._stop_idx - self._next_idx)
         if n <= 0:
             return None
         # block i of the batch starts `carry` bytes before its new samples; the lead-in has

@@ -456,14 +456,23 @@ int run_batch_long(thr_handle* h, const void* d_samples, int format,
             HIP_TRY(thr::launch_fit(nb, h->dev, h->d_stats, d_block_idx ? d_block_idx + off : nullptr,
                                     h->d_shifts, h->d_work_list, h->d_work_count, out, h->stream));
         }
-        {
-            ProfScope p(h, 2);
-            HIP_TRY(thr::launch_correlate_long(
-                format, in, nb, h->dev, h->d_tables, h->d_twn, h->d_tspec, h->d_shifts, h->d_work_list,
-                h->d_work_count, h->d_dsub, h->d_partial_x2, h->d_xhat_scratch, h->d_corr_stats,
-                dump_xhat ? dump_xhat + size_t(off) * n : nullptr,
-                dump_corr ? dump_corr + size_t(off) * n : nullptr, dump_template,
-                std::min(nb * r0, h->n_cu), h->long_chunk, h->stream));
+        // correlate stage in chunks of work-list slots: one chunk's d_k0 exchange stays in the
+        // Infinity Cache between the sub-transform kernel and the combination
+        for (int base = 0; base < nb; base += h->long_chunk) {
+            const int cap = std::min(h->long_chunk, nb - base);
+            {
+                ProfScope p(h, 2);
+                HIP_TRY(thr::launch_correlate_long(
+                    format, in, nb, h->dev, h->d_tables, h->d_twn, h->d_tspec, h->d_shifts,
+                    h->d_work_list, h->d_work_count, h->d_dsub, h->d_partial_x2, h->d_xhat_scratch,
+                    dump_xhat ? dump_xhat + size_t(off) * n : nullptr, std::min(nb * r0, h->n_cu), base,
+                    cap, h->stream));
+            }
+            ProfScope p(h, 4);
+            HIP_TRY(thr::launch_combine_long(h->dev, h->d_twn, h->d_work_list, h->d_work_count,
+                                             h->d_dsub, h->d_partial_x2, h->d_corr_stats,
+                                             dump_corr ? dump_corr + size_t(off) * n : nullptr,
+                                             dump_template, base, cap, h->stream));
         }
         {
             ProfScope p(h, 3);
@@ -493,7 +502,8 @@ int thr_abi_version(void) { return THR_ABI_VERSION; }
 const char* thr_last_error(void) { return g_last_error.c_str(); }
 
 const char* thr_kernel_name(int slot) {
-    static const char* names[THR_N_KERNEL_SLOTS] = {"k_carrier", "k_fit", "k_correlate", "k_finish"};
+    static const char* names[THR_N_KERNEL_SLOTS] = {"k_carrier", "k_fit",    "k_correlate",
+                                                    "k_finish",  "k_combine"};
     return (slot >= 0 && slot < THR_N_KERNEL_SLOTS) ? names[slot] : "";
 }
 

@@ -112,13 +112,17 @@ hipError_t launch_carrier_long(int fmt, const void* samples, int n_blocks, const
                                const float2* tables, const float2* twn, float* win_pow,
                                float* partial, CarStats* stats, float2* dump_fft, int grid,
                                hipStream_t stream);
+// one chunk of work-list slots [base, base + cap): sub-transforms -> dsub, then the combination
 hipError_t launch_correlate_long(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,
                                  const float2* tables, const float2* twn, const float4* tspec,
                                  const ShiftParams* shifts, const int* work_list,
                                  const int* work_count, float2* dsub, float* partial_x2,
-                                 float4* xhat_scratch, CorrStats* corr_stats, float2* dump_xhat,
-                                 float2* dump_corr, int dump_template, int grid, int chunk,
+                                 float4* xhat_scratch, float2* dump_xhat, int grid, int base, int cap,
                                  hipStream_t stream);
+hipError_t launch_combine_long(const DevCfg& cfg, const float2* twn, const int* work_list,
+                               const int* work_count, const float2* dsub, const float* partial_x2,
+                               CorrStats* corr_stats, float2* dump_corr, int dump_template, int base,
+                               int cap, hipStream_t stream);
 int long_chunk_blocks(int block_len, int n_templates);
 
 // card_ingest.hip (.card base64 payloads -> u8 IQ on the device)

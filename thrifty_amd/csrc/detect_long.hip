@@ -727,28 +727,33 @@ template <int R0>
 hipError_t correlate_r0(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,
                         const float2* tables, const float2* twn, const float4* tspec,
                         const ShiftParams* shifts, const int* work_list, const int* work_count,
-                        float2* dsub, float* partial_x2, float4* xhat_scratch,
-                        CorrStats* corr_stats, float2* dump_xhat, float2* dump_corr,
-                        int dump_template, int grid, int chunk, hipStream_t stream) {
+                        float2* dsub, float* partial_x2, float4* xhat_scratch, float2* dump_xhat,
+                        int grid, int base, int cap, hipStream_t stream) {
     typedef void (*fn_t)(const void*, DevCfg, const cpx*, const cpx*, const f4*, const ShiftParams*,
                          const int*, const int*, int, int, f4*, float*, f4*, cpx*);
     const bool dump = dump_xhat != nullptr;
     fn_t fn = fmt == THR_IN_U8
                   ? (dump ? &k_correlate_sub<THR_IN_U8, R0, true> : &k_correlate_sub<THR_IN_U8, R0, false>)
                   : (dump ? &k_correlate_sub<THR_IN_C64, R0, true> : &k_correlate_sub<THR_IN_C64, R0, false>);
-    // slot chunks: dsub / partial_x2 hold ONE chunk (see long_chunk_blocks)
-    for (int base = 0; base < n_blocks; base += chunk) {
-        const int cap = std::min(chunk, n_blocks - base);
-        hipLaunchKernelGGL(fn, dim3(std::min(grid, cap * R0)), dim3(NT), LDS_BYTES, stream, samples, cfg,
-                           reinterpret_cast<const cpx*>(tables), reinterpret_cast<const cpx*>(twn),
-                           reinterpret_cast<const f4*>(tspec), shifts, work_list + base, work_count, base,
-                           cap, reinterpret_cast<f4*>(dsub), partial_x2,
-                           reinterpret_cast<f4*>(xhat_scratch), reinterpret_cast<cpx*>(dump_xhat));
-        hipLaunchKernelGGL(k_combine<R0>, dim3(cap * cfg.n_templates), dim3(1024), 0, stream, cfg,
-                           reinterpret_cast<const cpx*>(twn), reinterpret_cast<const cpx*>(dsub),
-                           partial_x2, work_list + base, work_count, base, corr_stats,
-                           reinterpret_cast<cpx*>(dump_corr), dump_template);
-    }
+    // ONE slot chunk [base, base + cap): dsub / partial_x2 hold one chunk (see long_chunk_blocks);
+    // the caller loops over the chunks and follows each with launch_combine_long
+    hipLaunchKernelGGL(fn, dim3(std::min(grid, cap * R0)), dim3(NT), LDS_BYTES, stream, samples, cfg,
+                       reinterpret_cast<const cpx*>(tables), reinterpret_cast<const cpx*>(twn),
+                       reinterpret_cast<const f4*>(tspec), shifts, work_list + base, work_count, base,
+                       cap, reinterpret_cast<f4*>(dsub), partial_x2,
+                       reinterpret_cast<f4*>(xhat_scratch), reinterpret_cast<cpx*>(dump_xhat));
+    return hipGetLastError();
+}
+
+template <int R0>
+hipError_t combine_r0(const DevCfg& cfg, const float2* twn, const int* work_list,
+                      const int* work_count, const float2* dsub, const float* partial_x2,
+                      CorrStats* corr_stats, float2* dump_corr, int dump_template, int base, int cap,
+                      hipStream_t stream) {
+    hipLaunchKernelGGL(k_combine<R0>, dim3(cap * cfg.n_templates), dim3(1024), 0, stream, cfg,
+                       reinterpret_cast<const cpx*>(twn), reinterpret_cast<const cpx*>(dsub),
+                       partial_x2, work_list + base, work_count, base, corr_stats,
+                       reinterpret_cast<cpx*>(dump_corr), dump_template);
     return hipGetLastError();
 }
 
@@ -775,16 +780,26 @@ hipError_t launch_correlate_long(int fmt, const void* samples, int n_blocks, con
                                  const float2* tables, const float2* twn, const float4* tspec,
                                  const ShiftParams* shifts, const int* work_list,
                                  const int* work_count, float2* dsub, float* partial_x2,
-                                 float4* xhat_scratch, CorrStats* corr_stats, float2* dump_xhat,
-                                 float2* dump_corr, int dump_template, int grid, int chunk,
+                                 float4* xhat_scratch, float2* dump_xhat, int grid, int base, int cap,
                                  hipStream_t stream) {
     return cfg.block_len == 2 * M
                ? correlate_r0<2>(fmt, samples, n_blocks, cfg, tables, twn, tspec, shifts, work_list,
-                                 work_count, dsub, partial_x2, xhat_scratch, corr_stats, dump_xhat,
-                                 dump_corr, dump_template, grid, chunk, stream)
+                                 work_count, dsub, partial_x2, xhat_scratch, dump_xhat, grid, base, cap,
+                                 stream)
                : correlate_r0<4>(fmt, samples, n_blocks, cfg, tables, twn, tspec, shifts, work_list,
-                                 work_count, dsub, partial_x2, xhat_scratch, corr_stats, dump_xhat,
-                                 dump_corr, dump_template, grid, chunk, stream);
+                                 work_count, dsub, partial_x2, xhat_scratch, dump_xhat, grid, base, cap,
+                                 stream);
+}
+
+hipError_t launch_combine_long(const DevCfg& cfg, const float2* twn, const int* work_list,
+                               const int* work_count, const float2* dsub, const float* partial_x2,
+                               CorrStats* corr_stats, float2* dump_corr, int dump_template, int base,
+                               int cap, hipStream_t stream) {
+    return cfg.block_len == 2 * M
+               ? combine_r0<2>(cfg, twn, work_list, work_count, dsub, partial_x2, corr_stats, dump_corr,
+                               dump_template, base, cap, stream)
+               : combine_r0<4>(cfg, twn, work_list, work_count, dsub, partial_x2, corr_stats, dump_corr,
+                               dump_template, base, cap, stream);
 }
 
 // blocks per correlate-stage chunk: the d_k0 exchange (8 * block_len * T bytes per block) of one

@@ -191,28 +191,27 @@ class Detector(object):
         return detected, result, shifted_fft, corr
 
     # -------------------------------------------------------------- iterator
-    def _refill(self):
+    def _next_records(self):
+        """Pull one batch from the block source and run it: -> (stamps, idxs, recs) or None
+        when the source is exhausted."""
         if self._card is not None:
             batch = self._card.next_batch(self.batch_size)
             if batch is None:
                 self._exhausted = True
-                return
+                return None
             stamps, idxs, text, offs = batch
-            recs = self._engine.detect_card(text, offs, idxs)[:, 0]
-            self._emit(stamps, idxs, recs)
-            return
+            return stamps, idxs, self._engine.detect_card(text, offs, idxs)[:, 0]
         if self._raw is not None:
             batch = self._raw.next_batch(self.batch_size)
             if batch is None:
                 self._exhausted = True
-                return
+                return None
             kind, stamps, idxs, data = batch
             if kind == "u8":
                 recs = self._engine.detect_stream(data, int(idxs[0]))[:, 0]
             else:   # lead-in blocks that still contain the all-zero initial history
                 recs = self._engine.detect(data, idxs)[:, 0]
-            self._emit(stamps, idxs, recs)
-            return
+            return stamps, idxs, recs
         items = []
         while len(items) < self.batch_size and not self._exhausted:
             t0 = time.perf_counter()
@@ -224,20 +223,57 @@ class Detector(object):
             # from batching: process what has arrived instead of waiting for a full batch
             if time.perf_counter() - t0 > _SLOW_SOURCE_S:
                 break
+        if not items:
+            return None
         if self.yield_data:
-            self._ready.extend(self.detect(*it) for it in items)
-        elif items:
-            arr = self._stack([it[2] for it in items])
-            idx = np.array([int(it[1]) for it in items], dtype=np.int64)
-            recs = self._engine.detect(arr, idx)[:, 0]
-            self._ready.extend(self._results([it[0] for it in items], idx, recs))
+            return items
+        arr = self._stack([it[2] for it in items])
+        idx = np.array([int(it[1]) for it in items], dtype=np.int64)
+        return [it[0] for it in items], idx, self._engine.detect(arr, idx)[:, 0]
 
-    def _emit(self, stamps, idxs, recs):
+    def _refill(self):
+        got = self._next_records()
+        if got is None:
+            return
+        if self.yield_data:
+            self._ready.extend(self.detect(*it) for it in got)
+            return
+        stamps, idxs, recs = got
         if self.only_detections:
             keep = np.flatnonzero(recs["flags"] & (_native.FLAG_CORR | _native.FLAG_INDEX_ERROR))
             if len(keep) != len(recs):
                 stamps, idxs, recs = [stamps[i] for i in keep], idxs[keep], recs[keep]
         self._ready.extend(self._results(stamps, idxs, recs))
+
+    def iter_detected_records(self):
+        """Batches of (timestamps float64[k], records[k]) of the DETECTED blocks only, in input
+        order -- the engine's records as they are, no per-block Python objects.  A block on
+        which the reference raises IndexError (carrier_sync.py:187) ends the iteration with
+        that error after the detections before it have been yielded."""
+        if self.blocks is None:
+            raise TypeError("Detector was constructed without a block source")
+        if self.yield_data:
+            raise TypeError("record iteration is not available with yield_data")
+        while not self._exhausted:
+            got = self._next_records()
+            if got is None:
+                continue
+            stamps, idxs, recs = got
+            bad = np.flatnonzero(recs["flags"] & _native.FLAG_INDEX_ERROR)
+            stop = int(bad[0]) if len(bad) else len(recs)
+            keep = np.flatnonzero(recs["flags"][:stop] & _native.FLAG_CORR)
+            if len(keep):
+                yield np.asarray(stamps, dtype=np.float64)[keep], recs[keep]
+            if len(bad):
+                self._exhausted = True
+                self._result(stamps[stop], int(idxs[stop]), recs[stop])   # raises
+
+    def iter_toad_lines(self):
+        """Batches of `.toad` lines (lists of str) for the detected blocks, formatted a column
+        at a time (toads_data.toad_lines) -- what `detector_cli --quiet -o` writes."""
+        for stamps, recs in self.iter_detected_records():
+            yield toads_data.toad_lines(recs, stamps, self.new_len, rxid=self.rxid,
+                                        carrier_offset_type=self._offset_type)
 
     def next(self):
         """Result for the next block of the `blocks` iterator."""
@@ -349,10 +385,41 @@ class SummaryLineFormatter(object):
         return text
 
 
+def _strip_output_args(argv):
+    """argv without -o/--output/-a/--append (ranks other than 0 must not open -- and with -o
+    truncate -- the output file that rank 0 writes)."""
+    out, skip = [], False
+    for a in argv:
+        if skip:
+            skip = False
+            continue
+        if a in ("-o", "--output", "-a", "--append"):
+            skip = True
+            continue
+        if a.startswith(("--output=", "--append=")) or (a[:2] in ("-o", "-a") and len(a) > 2 and a[1] != "-"):
+            continue
+        out.append(a)
+    return out
+
+
 def detector_cli(detector_class, parser=None, extra_args=None, argv=None):
     """`thrifty detect` front end (reference detect.py:161-223): same arguments and
     settings keys; `detector_class(settings, blocks, rxid=..., **kwargs)` must iterate
-    to `(detected, result)` pairs."""
+    to `(detected, result)` pairs.
+
+    Addition: `--gpus N` shards a regular input file over N GPUs of this node by contiguous
+    block ranges, one process per GPU (re-launched under `torch.distributed.run`); the ranks'
+    detection records are gathered to rank 0 over RCCL and written as ONE `.toad` in input
+    order.  The per-block summary lines are a console aid of the
+    single-process loop and are not printed in that mode."""
+    from thrifty_amd import parallel
+    argv = list(sys.argv[1:] if argv is None else argv)
+    rank, world, local = parallel.torchrun_env()
+    gpus = parallel.peek_gpus(argv)
+    if gpus > 1 and world is None:
+        sys.exit(parallel.relaunch_under_torchrun(gpus, argv))
+    if world is not None and rank != 0:
+        argv = _strip_output_args(argv)
     if parser is None:
         parser = argparse.ArgumentParser(description=__doc__,
                                          formatter_class=argparse.RawDescriptionHelpFormatter)
@@ -361,6 +428,8 @@ def detector_cli(detector_class, parser=None, extra_args=None, argv=None):
     parser.add_argument("--raw", dest="raw", action="store_true", help="input data is raw binary data")
     parser.add_argument("--quiet", dest="quiet", action="store_true",
                         help="do not write anything to standard output")
+    parser.add_argument("--gpus", dest="gpus", type=int, default=1,
+                        help="shard a regular input file over this many GPUs of the node")
     group = parser.add_mutually_exclusive_group()
     group.add_argument("-o", "--output", dest="output", type=argparse.FileType("w"),
                        help="Output file (.toad) ('-' for stdout)")
@@ -387,9 +456,23 @@ def detector_cli(detector_class, parser=None, extra_args=None, argv=None):
                                 carrier_len=len(template), carrier_thresh=config.carrier_threshold,
                                 carrier_window=window, template=template,
                                 corr_thresh=config.corr_threshold)
+    if world is not None:
+        # one rank of a sharded run (also world == 1 under torchrun: same code path, same collectives)
+        if args.gpus != world:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+        blocks.shard(rank, world)
+        detections = detector_class(settings, blocks, rxid=config.rxid, device_id=local, **kwargs)
+        parallel.run_sharded(detections, rank, world, local, output_file)
+        return
     detections = detector_class(settings, blocks, rxid=config.rxid, **kwargs)
     if args.quiet and hasattr(detections, "only_detections"):
         detections.only_detections = True   # nothing is printed for the other blocks anyway
+    if args.quiet and output_file is not None and hasattr(detections, "iter_toad_lines"):
+        # nothing per block is needed: format the detections a column at a time
+        for lines in detections.iter_toad_lines():
+            output_file.write("\n".join(lines) + "\n")
+        output_file.flush()
+        return
     summary = SummaryLineFormatter(config.sample_rate, config.block_size, add_dt=True)
     for detected, result in detections:
         if detected and output_file is not None:

@@ -10,6 +10,13 @@ large batch, never per launch.
 """
 from __future__ import annotations
 
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
 RECORD_BYTES = 64
 
 
@@ -46,3 +53,99 @@ def gather_records(local, world, rank, device=None, group=None, force=False):
         return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
     dist.gather(padded, None, dst=0, group=group)
     return padded[:0]
+
+
+# ---------------------------------------------------------------------------------------------
+# `thrifty detect --gpus N`: one process per GPU, each over its contiguous range of the input
+# ---------------------------------------------------------------------------------------------
+def torchrun_env():
+    """(rank, world, local_rank) when started by torch.distributed.run, else (0, None, 0)."""
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ:
+        return (int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]),
+                int(os.environ.get("LOCAL_RANK", os.environ["RANK"])))
+    return 0, None, 0
+
+
+def peek_gpus(argv):
+    """Value of --gpus in argv (1 if absent) without parsing anything else."""
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if a.startswith("--gpus="):
+            return int(a.split("=", 1)[1])
+    return 1
+
+
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def relaunch_under_torchrun(gpus, argv):
+    """Start `gpus` ranks of the CLI that is running now (same module, same arguments) on this
+    node; returns the launcher's exit status."""
+    import __main__
+    spec = getattr(__main__, "__spec__", None)
+    target = ["-m", spec.name] if spec is not None and spec.name else [os.path.abspath(sys.argv[0])]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + target + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def run_sharded(detections, rank, world, local, output_file, backend="nccl"):
+    """Body of one rank of `thrifty detect --gpus N`: run this rank's block range, gather the
+    detected records to rank 0 (RCCL), write one .toad there in input order.
+
+    `detections` is a Detector over a reader already restricted with `.shard(rank, world)`.
+    Each record's timestamp travels in its `reserved` field.  If the reference would have
+    raised IndexError on some block (carrier_sync.py:187), rank 0 writes the detections before
+    that block and every rank raises, like the single-process loop."""
+    import torch
+    import torch.distributed as dist
+    from thrifty_amd import _native, toads_data
+
+    if backend == "nccl":       # RCCL; "gloo" (CPU tensors) is for the tests of this function
+        dev = torch.device("cuda", local)
+        torch.cuda.set_device(dev)
+        if not dist.is_initialized():
+            dist.init_process_group("nccl", device_id=dev)
+    else:
+        dev = torch.device("cpu")
+        if not dist.is_initialized():
+            dist.init_process_group(backend)
+    chunks, error = [], None
+    try:
+        for stamps, recs in detections.iter_detected_records():
+            recs = recs.copy()
+            recs["reserved"] = np.ascontiguousarray(stamps, dtype=np.float64).view(np.uint64)
+            chunks.append(recs)
+    except IndexError as exc:
+        error = exc
+    mine = (np.concatenate(chunks) if chunks else np.zeros(0, dtype=_native.RECORD_DTYPE))
+    failed = torch.tensor([1 if error is not None else 0], dtype=torch.int64, device=dev)
+    flags = [torch.zeros_like(failed) for _ in range(world)]
+    dist.all_gather(flags, failed)
+    flags = [int(f.item()) for f in flags]
+    first_bad = flags.index(1) if 1 in flags else world
+    if rank > first_bad:
+        mine = mine[:0]                 # the single-process loop never got this far
+    local_t = torch.from_numpy(mine.view(np.uint8).reshape(-1, RECORD_BYTES).copy()).to(dev)
+    gathered = gather_records(local_t, world, rank, dev, force=True)
+    if rank == 0 and output_file is not None:
+        recs = gathered.cpu().numpy().reshape(-1).view(_native.RECORD_DTYPE)
+        stamps = recs["reserved"].view(np.float64)
+        step = 1 << 16
+        for s in range(0, len(recs), step):
+            lines = toads_data.toad_lines(recs[s:s + step], stamps[s:s + step], detections.new_len,
+                                          rxid=detections.rxid,
+                                          carrier_offset_type=getattr(detections, "_offset_type", float))
+            output_file.write("\n".join(lines) + "\n")
+        output_file.flush()
+    dist.barrier()
+    dist.destroy_process_group()
+    if first_bad < world:
+        raise error if error is not None else IndexError(
+            "rank %d hit a block on which the reference raises IndexError" % first_bad)

@@ -57,6 +57,42 @@ class DetectionResult(object):
             self.block, self.soa, self.carrier_info, self.corr_info)
 
 
+def toad_lines(recs, timestamps, new_len, rxid=None, txid=None, carrier_offset_type=float):
+    """`DetectionResult.serialize()` for a whole batch of engine records at once.
+
+    recs: structured records (thr_record layout) of DETECTED blocks; timestamps: one float each.
+    Whole columns are converted together -- `repr` over `.tolist()` for the float fields (the
+    carrier energy / noise are np.float32 in the reference, and `'{}'.format(np.float32)` prints
+    the value widened to a double, so they too are the repr of the widened value), `%.6f` /
+    `%.8f` for timestamp / soa -- and joined, with no per-record result objects.  Text is identical to building each `DetectionResult` and
+    serialising it (tests/test_host_logic.py)."""
+    n = len(recs)
+    if n == 0:
+        return []
+    block = recs["block_idx"].astype(np.int64)
+    sample = recs["corr_sample"].astype(np.int64)
+    off = recs["corr_offset"].astype(np.float64)
+    # soa = new_len * block_idx + sample + offset: exact integer part, then one float64 add
+    soa = (np.int64(new_len) * block + sample).astype(np.float64) + off
+    cols = [
+        ["%.6f" % v for v in np.asarray(timestamps, dtype=np.float64).tolist()],
+        list(map(str, block.tolist())),
+        ["%.8f" % v for v in soa.tolist()],
+        list(map(str, sample.tolist())),
+        list(map(repr, off.tolist())),
+        list(map(repr, recs["corr_energy"].astype(np.float64).tolist())),
+        list(map(repr, recs["corr_noise"].astype(np.float64).tolist())),
+        list(map(str, recs["carrier_bin"].tolist())),
+        # (PreshiftDetector: np.float32 in the reference -- rounded to it, printed widened)
+        list(map(repr, recs["carrier_offset"].astype(carrier_offset_type).astype(np.float64).tolist())),
+        list(map(repr, recs["carrier_energy"].astype(np.float64).tolist())),
+        list(map(repr, recs["carrier_noise"].astype(np.float64).tolist())),
+    ]
+    ids = [str(v) for v in (rxid, txid) if v is not None]
+    head = " ".join(ids) + " " if ids else ""
+    return [head + " ".join(row) for row in zip(*cols)]
+
+
 def _read(stream, with_rxid, with_txid):
     own = isinstance(stream, str)
     if own:
