@@ -192,11 +192,16 @@ def physical_cores():
     return max(1, len(cores)), "%d logical CPUs available, %d distinct SMT sibling sets" % (len(avail), len(cores))
 
 
-def cpu_all_cores(n, h, blocks_u8, template, procs, single_rate, seconds=6.0):
+def cpu_all_cores(n, h, blocks_u8, template, procs, single_rate, seconds=4.0):
     """Oracle throughput with `procs` spawned workers (one per physical core), each over its own
-    slab of the blocks, sized from the single-core rate so the leg takes ~`seconds`."""
+    slab of the blocks, sized from the single-core rate so the leg takes `seconds` if the cores
+    scaled perfectly (they do not: all-core clocks and memory bandwidth; expect ~2x that)."""
     import multiprocessing as mp
-    per_proc = int(max(4, min(len(blocks_u8), single_rate * seconds * 0.8)))
+    # one compute thread per worker: the children read these when THEY import NumPy / SciPy
+    # (set inside the worker it would be too late -- the BLAS thread pools start at import)
+    for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ[var] = "1"
+    per_proc = int(max(4, min(len(blocks_u8), single_rate * seconds)))
     jobs = [(n, h, blocks_u8[(i * per_proc) % max(1, len(blocks_u8) - per_proc + 1):][:per_proc], template)
             for i in range(procs)]
     ctx = mp.get_context("spawn")

@@ -45,8 +45,10 @@ def run_oracle(blocks, n, h, tpl, cthr, cwin, xthr, procs=None, chunk=64):
     return rows
 
 
-def compare(rec, rows, blocks, flag_carrier=1, flag_corr=2, flag_index_error=4):
-    """-> (mismatch counts, worst deviations, [indices of carrier-bin ties])."""
+def compare(rec, rows, blocks, flag_carrier=1, flag_corr=2, flag_index_error=4, only=None):
+    """-> (mismatch counts, worst deviations, [indices of carrier-bin ties]).  Exact fields (bin,
+    sample, verdicts) are counted over every block; the worst deviations only over the blocks
+    where `only` (bool array) is set, when given."""
     from oracle import thrifty_np as onp
     mism = dict(bin=0, carrier=0, sample=0, det=0, index_error=0)
     worst = dict(energy=0.0, offset=0.0, car_off=0.0, car_energy=0.0, noise=0.0)
@@ -68,11 +70,13 @@ def compare(rec, rows, blocks, flag_carrier=1, flag_corr=2, flag_index_error=4):
             mism["bin"] += 1
             continue
         mism["carrier"] += bool(r["flags"] & flag_carrier) != cdet
-        worst["car_energy"] = max(worst["car_energy"], abs(r["carrier_energy"] - cen) / abs(cen))
         if not cdet or bool(r["flags"] & flag_carrier) != cdet:
             continue
         mism["sample"] += r["corr_sample"] != samp
         mism["det"] += bool(r["flags"] & flag_corr) != det
+        if only is not None and not only[i]:
+            continue
+        worst["car_energy"] = max(worst["car_energy"], abs(r["carrier_energy"] - cen) / abs(cen))
         worst["car_off"] = max(worst["car_off"], abs(r["carrier_offset"] - coff))
         if r["corr_sample"] == samp:
             worst["energy"] = max(worst["energy"], abs(r["corr_energy"] - en) / abs(en))

