@@ -179,8 +179,18 @@ def _oracle_worker(job):
     return len(blocks), time.perf_counter() - t0
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max), or None if unlimited."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        return None
+
+
 def physical_cores():
-    """(worker count, how it was derived): one per physical core of the CPUs this process may use."""
+    """(worker count, how it was derived): one per physical core of the CPUs this process may use,
+    capped by the container's CPU quota (more workers than quota only time-slice)."""
     avail = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
     cores = set()
     for c in avail:
@@ -189,7 +199,11 @@ def physical_cores():
                 cores.add(f.read().strip())
         except OSError:
             cores.add(str(c))
-    return max(1, len(cores)), "%d logical CPUs available, %d distinct SMT sibling sets" % (len(avail), len(cores))
+    n, how = max(1, len(cores)), "%d logical CPUs available, %d distinct SMT sibling sets" % (len(avail), len(cores))
+    q = cpu_quota()
+    if q is not None and q < n:
+        n, how = max(1, int(q)), how + "; cgroup cpu.max allows %.1f CPUs -> %d workers" % (q, max(1, int(q)))
+    return n, how
 
 
 def cpu_all_cores(n, h, blocks_u8, template, procs, single_rate, seconds=4.0):

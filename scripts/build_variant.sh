@@ -1,0 +1,10 @@
+#!/bin/bash
+# dev: build the library with extra compile flags into ab/<name>.so (for scripts/ab.sh), then
+# restore the default build.   scripts/build_variant.sh nobar -DTHR_DEV_NOBAR
+set -e
+cd "$(dirname "$0")/.."
+NAME=$1; shift
+mkdir -p ab
+THR_EXTRA_CFLAGS="$*" python -m thrifty_amd.build --force > /dev/null
+cp thrifty_amd/libthriftyhip.so ab/$NAME.so
+echo "ab/$NAME.so  [$*]"

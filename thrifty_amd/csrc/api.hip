@@ -103,7 +103,6 @@ struct thr_handle {
     int long_chunk = 0;      // long path: work-list slots per correlate-stage chunk (sizes d_dsub)
     float* d_win_pow = nullptr;     // long: [long_batch][win_w] |X|^2 of the window bins (+-3)
     float* d_partial = nullptr;     // long: [long_batch][R0][2] partial sums of FFT#1
-    float* d_partial_x2 = nullptr;  // long: [long_batch][R0] partial sum |X^|^2
     float2* d_dsub = nullptr;       // long: [long_batch][T][R0][16384] sub-transform outputs
     int gen_batch = 0;       // generic path: blocks per internal sub-batch
     float2* d_gen_scratch = nullptr;  // generic path: 3 * gen_batch * N complex
@@ -344,7 +343,7 @@ int run_batch_fast(thr_handle* h, const void* d_samples, int format,
     {
         ProfScope p(h, 1);
         HIP_TRY(thr::launch_fit(n_blocks, h->dev, h->d_stats, d_block_idx, h->d_shifts,
-                                h->d_work_list, h->d_work_count, d_out, h->stream));
+                                h->d_work_list, h->d_work_count, d_out, h->d_corr_stats, h->stream));
     }
     {
         ProfScope p(h, 2);
@@ -406,7 +405,8 @@ int run_batch_generic(thr_handle* h, const void* d_samples, int format,
         {
             ProfScope p(h, 1);
             HIP_TRY(thr::launch_fit(nb, h->dev, h->d_stats, d_block_idx ? d_block_idx + off : nullptr,
-                                    h->d_shifts, h->d_work_list, h->d_work_count, out, h->stream));
+                                    h->d_shifts, h->d_work_list, h->d_work_count, out, nullptr,
+                                    h->stream));
         }
         float2 *xh = nullptr, *cc = nullptr;
         {
@@ -454,7 +454,8 @@ int run_batch_long(thr_handle* h, const void* d_samples, int format,
         {
             ProfScope p(h, 1);
             HIP_TRY(thr::launch_fit(nb, h->dev, h->d_stats, d_block_idx ? d_block_idx + off : nullptr,
-                                    h->d_shifts, h->d_work_list, h->d_work_count, out, h->stream));
+                                    h->d_shifts, h->d_work_list, h->d_work_count, out,
+                                    h->d_corr_stats, h->stream));   // (sub-batch-local indices)
         }
         // correlate stage in chunks of work-list slots: one chunk's d_k0 exchange stays in the
         // Infinity Cache between the sub-transform kernel and the combination
@@ -464,13 +465,13 @@ int run_batch_long(thr_handle* h, const void* d_samples, int format,
                 ProfScope p(h, 2);
                 HIP_TRY(thr::launch_correlate_long(
                     format, in, nb, h->dev, h->d_tables, h->d_twn, h->d_tspec, h->d_shifts,
-                    h->d_work_list, h->d_work_count, h->d_dsub, h->d_partial_x2, h->d_xhat_scratch,
+                    h->d_work_list, h->d_work_count, h->d_dsub, h->d_xhat_scratch,
                     dump_xhat ? dump_xhat + size_t(off) * n : nullptr, std::min(nb * r0, h->n_cu), base,
                     cap, h->stream));
             }
             ProfScope p(h, 4);
             HIP_TRY(thr::launch_combine_long(h->dev, h->d_twn, h->d_work_list, h->d_work_count,
-                                             h->d_dsub, h->d_partial_x2, h->d_corr_stats,
+                                             h->d_dsub, h->d_corr_stats,
                                              dump_corr ? dump_corr + size_t(off) * n : nullptr,
                                              dump_template, base, cap, h->stream));
         }
@@ -650,7 +651,6 @@ static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out
             h->long_chunk = std::min(h->long_batch, thr::long_chunk_blocks(n, s->n_templates));
             if (getenv("THR_LONG_CHUNK")) h->long_chunk = std::max(1, std::min(h->long_batch, atoi(getenv("THR_LONG_CHUNK"))));
             const size_t lc = size_t(h->long_chunk);
-            CREATE_TRY(hipMalloc(&h->d_partial_x2, lc * r0 * sizeof(float)));
             CREATE_TRY(hipMalloc(&h->d_dsub, lc * s->n_templates * size_t(n) * sizeof(float2)));
             CREATE_TRY(hipMalloc(&h->d_xhat_scratch, size_t(h->n_cu) * 16384 * sizeof(float2)));
         }
@@ -693,7 +693,7 @@ void thr_destroy(thr_handle* h) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
     }
-    void* bufs[] = {h->d_tables, h->d_twn, h->d_tspec, h->d_stats, h->d_shifts, h->d_corr_stats, h->d_text, h->d_payload_off, h->d_bad, h->d_gen_scratch, h->d_tspec_nat, h->d_bank, h->d_gtw, h->d_win_pow, h->d_partial, h->d_partial_x2, h->d_dsub, h->d_work_list,
+    void* bufs[] = {h->d_tables, h->d_twn, h->d_tspec, h->d_stats, h->d_shifts, h->d_corr_stats, h->d_text, h->d_payload_off, h->d_bad, h->d_gen_scratch, h->d_tspec_nat, h->d_bank, h->d_gtw, h->d_win_pow, h->d_partial, h->d_dsub, h->d_work_list,
                     h->d_work_count, h->d_xhat_scratch, h->d_ncompact, h->d_compact_tiles, h->d_in, h->d_idx, h->d_rec};
     for (void* b : bufs)
         if (b) (void)hipFree(b);

@@ -71,6 +71,18 @@ __global__ __launch_bounds__(NT) void k_correlate(
     const size_t blk_bytes = cfg.blk_stride;  // dense: N * sample size; raw streams: 2 (N - H)
     const int n_work = *work_count;
     int parity = 0;
+#ifdef THR_DEV_NOBAR
+    // dev: with the loop barriers gone, offset the waves once so that they stay out of phase:
+    // THR_STAGGER = 10 + k: wave w starts w * k * 512 cycles late; 20 + k: waves 4-7 start
+    // k * 512 cycles late (the partner of each SIMD's older wave)
+    {
+        const int w = threadIdx.x >> 6;
+        int n = 0;
+        if (cfg.stagger >= 20) n = w >= 4 ? cfg.stagger - 20 : 0;
+        else if (cfg.stagger >= 10) n = w * (cfg.stagger - 10);
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
 
     RawSamples<FMT> cur;
     cpx p[2] = {cpx{0.f, 0.f}, cpx{0.f, 0.f}};
@@ -126,7 +138,7 @@ __global__ __launch_bounds__(NT) void k_correlate(
         if (more && early_half) shift_phasor(shifts + b_next, twn, t, p);
         THR_STAMP(3);
         if (dyn && t == 0) *sc_dyn = wi_dyn;
-        __syncthreads();
+        THR_LOOP_BARRIER();
         // (sc_dyn is rewritten only after two more barriers: every thread has read it by then)
         const int wi_nxt2 = dyn ? *sc_dyn : wi_nxt + int(gridDim.x);
         if (dyn && wi_nxt2 < n_work) b_next2 = work_list[wi_nxt2];
@@ -162,10 +174,9 @@ __global__ __launch_bounds__(NT) void k_correlate(
 #endif
 
         const int kbase = (t >> 5) + 16 * (t & 31);
-        float e2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < R3; ++i) e2 += cnorm(xh[i]);
-        asm volatile("" : "+v"(e2));  // pin here: else LLVM sinks the sum (and 64 live VGPRs) to its use
+        // (sum |X^|^2, which the correlation noise estimate needs (soa_estimator.py:108-120), is
+        // N sum |x|^2 whatever the shift -- the phasor has unit modulus -- and the carrier stage
+        // has that sum already: k_fit hands it to k_finish, nothing is summed here)
         if constexpr (DUMP) {
             if (dump_xhat != nullptr) {
                 cpx* out = dump_xhat + size_t(b) * N;
@@ -193,15 +204,22 @@ __global__ __launch_bounds__(NT) void k_correlate(
         }
 
         const int n_tpl = MULTI ? cfg.n_templates : 1;
+        // template spectrum of this thread's 32 bins (16 x float4, L2-resident).  With several
+        // templates the NEXT template's slice is requested before pass C of the current one, so
+        // that its L2 latency hides under pass C, the statistics and the reduction.
+        f4 tq[R3 / 2];
+        {
+            const f4* ts = tspec + opaque_tid();
+            static_for<R3 / 2>([&](auto J) { tq[decltype(J)::value] = ts[decltype(J)::value * NT]; });
+        }
         for (int tpl = 0; tpl < n_tpl; ++tpl) {
             // ---- X * conj(T)/N in digit-reversed register order
             const int t = opaque_tid();  // re-derive per template: keeps LICM off the loop body
             if constexpr (PARK) park = xhat_scratch + size_t(blockIdx.x) * (N / 2) + t;
-            const f4* ts = tspec + size_t(tpl) * (N / 2) + t;
             cpx z[R3];
             static_for<R3 / 2>([&](auto J) {
                 constexpr int j = decltype(J)::value;
-                const f4 q = ts[j * NT];
+                const f4 q = tq[j];
                 cpx x0, x1;
                 if constexpr (PARK) {
                     const f4 xx = park[j * NT];  // own writes: program order suffices
@@ -222,9 +240,15 @@ __global__ __launch_bounds__(NT) void k_correlate(
             THR_ABLATE_AT(14, { __syncthreads(); continue; });
             inv_passB(lds, gtw);
             THR_STAMP(8);
-            __syncthreads();
+            THR_LOOP_BARRIER();
             THR_STAMP(9);
             THR_ABLATE_AT(15, continue);
+            if constexpr (MULTI) {
+                if (tpl + 1 < n_tpl) {
+                    const f4* ts = tspec + size_t(tpl + 1) * (N / 2) + opaque_tid();
+                    static_for<R3 / 2>([&](auto J) { tq[decltype(J)::value] = ts[decltype(J)::value * NT]; });
+                }
+            }
             cpx c0[R1], c1[R1];
             inv_passC(lds, c0, c1);
             THR_STAMP(10);
@@ -242,7 +266,7 @@ __global__ __launch_bounds__(NT) void k_correlate(
             // ---- |corr|^2, windowed first-max, optional std sums
             // per-thread first-max in float (lags visited in increasing n, strict '>'), one
             // 64-bit key per thread only for the cross-lane reduction
-            float sums[3] = {tpl == 0 ? e2 : 0.f, 0.f, 0.f};
+            float sums[2] = {0.f, 0.f};     // sum |corr|, sum |corr|^2 over [0, corr_len): WANT_STD only
             float pw0[R1], pw1[R1];
             float bestp = -1.0f;
             int bestn = 0;
@@ -260,8 +284,8 @@ __global__ __launch_bounds__(NT) void k_correlate(
                     bestn = take ? n : bestn;
                     if constexpr (WANT_STD) {
                         if (n < cfg.corr_len) {
-                            sums[2] += pw;
-                            sums[1] += __builtin_amdgcn_sqrtf(pw);
+                            sums[1] += pw;
+                            sums[0] += __builtin_amdgcn_sqrtf(pw);
                         }
                     }
                 }
@@ -270,11 +294,12 @@ __global__ __launch_bounds__(NT) void k_correlate(
                 bestp < 0.f ? 0ull
                             : ((unsigned long long)__float_as_uint(bestp) << 32) |
                                   (0xFFFFFFFFu - unsigned(bestn));
-            constexpr int NS = WANT_STD ? 3 : 1;
-            double tot[3] = {0, 0, 0};
+            double tot[2] = {0, 0};
             THR_STAMP(11);
-            block_reduce<NS, NT / 64>(reinterpret_cast<float(&)[NS]>(sums),
-                             reinterpret_cast<double(&)[NS]>(tot), best, sc_red, parity);
+            if constexpr (WANT_STD)
+                block_reduce<2, NT / 64>(sums, tot, best, sc_red, parity);
+            else
+                block_reduce_max<NT / 64>(best, sc_red, parity);
             THR_STAMP(12);
             parity ^= 1;
             const int pk = int(0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu));
@@ -287,12 +312,22 @@ __global__ __launch_bounds__(NT) void k_correlate(
                 const int delta = pk - 1 - (2 * t + e);        // want n1*1024 == delta + d
                 const unsigned d = unsigned(-delta) & 1023u;    // d in [0,1024)
                 const int n1s = (delta + int(d)) >> 10;
-                float val = 0.f;
-                static_for<R1>([&](auto K) {
-                    constexpr int n1 = decltype(K)::value;
-                    val = (n1s == n1) ? (e ? pw1[n1] : pw0[n1]) : val;
-                });
-                if (d < 3u && n1s >= 0 && n1s < R1) cs->m2[d] = val;
+                // at most three threads of the workgroup are owners: with one template the 16-way
+                // select runs under a branch that seven of the eight waves skip (-2 % kernel time);
+                // inside the template loop the same branch costs +7 % (measured), so there the
+                // select stays branch-free
+#ifndef THR_NB_BRANCH
+#define THR_NB_BRANCH (!MULTI)
+#endif
+                const bool owner = d < 3u && n1s >= 0 && n1s < R1;
+                if (!THR_NB_BRANCH || owner) {
+                    float val = 0.f;
+                    static_for<R1>([&](auto K) {
+                        constexpr int n1 = decltype(K)::value;
+                        val = (n1s == n1) ? (e ? pw1[n1] : pw0[n1]) : val;
+                    });
+                    if (owner) cs->m2[d] = val;
+                }
             }
             if constexpr (DUMP) {
                 if (dump_corr != nullptr && tpl == dump_template) {
@@ -308,9 +343,8 @@ __global__ __launch_bounds__(NT) void k_correlate(
             if (t == 0) {
                 cs->pm2 = __uint_as_float(unsigned(best >> 32));
                 cs->pk = pk;
-                if (tpl == 0) cs->sum_x2 = (float)tot[0];  // sum |X^|^2, shared by all templates
-                cs->sum_mag = WANT_STD ? (float)tot[1] : 0.f;
-                cs->sum_mag2 = WANT_STD ? (float)tot[2] : 0.f;
+                cs->sum_mag = WANT_STD ? (float)tot[0] : 0.f;
+                cs->sum_mag2 = WANT_STD ? (float)tot[1] : 0.f;
             }
             THR_STAMP(13);
         }

@@ -259,7 +259,8 @@ __global__ __launch_bounds__(64) void k_fit(int n_blocks, DevCfg cfg,
                                             ShiftParams* __restrict__ shifts,
                                             int* __restrict__ work_list,
                                             int* __restrict__ work_count,
-                                            thr_record* __restrict__ records) {
+                                            thr_record* __restrict__ records,
+                                            CorrStats* __restrict__ corr_stats) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = gid & 7;
     int b = gid >> 3;
@@ -352,6 +353,10 @@ __global__ __launch_bounds__(64) void k_fit(int n_blocks, DevCfg cfg,
             if (push) work_list[base + __popcll(m & ((1ull << lane) - 1ull))] = b;
         }
     }
+    // sum |X^|^2 of the frequency-shifted spectrum == sum |X|^2 (unit-modulus phasor, Parseval):
+    // the LDS-resident correlate kernels take it from here instead of summing it again
+    if (valid && j == 0 && corr_stats != nullptr)
+        corr_stats[size_t(b) * cfg.n_templates].sum_x2 = sum_mag2;
     if (valid && j < cfg.n_templates) {
         thr_record r;
         r.block_idx = block_idx ? block_idx[b] : (long long)b;
@@ -601,9 +606,10 @@ hipError_t launch_carrier_16k(int fmt, const void* samples, int n_blocks, const 
 
 hipError_t launch_fit(int n_blocks, const DevCfg& cfg, const CarStats* stats,
                       const long long* block_idx, ShiftParams* shifts, int* work_list,
-                      int* work_count, thr_record* records, hipStream_t stream) {
+                      int* work_count, thr_record* records, CorrStats* corr_stats,
+                      hipStream_t stream) {
     hipLaunchKernelGGL(k_fit, dim3((n_blocks * 8 + 63) / 64), dim3(64), 0, stream, n_blocks, cfg,
-                       stats, block_idx, shifts, work_list, work_count, records);
+                       stats, block_idx, shifts, work_list, work_count, records, corr_stats);
     return hipGetLastError();
 }
 

@@ -91,7 +91,8 @@ hipError_t launch_carrier_16k(int fmt, const void* samples, int n_blocks, const 
                               float2* dump_fft, int grid, hipStream_t stream);
 hipError_t launch_fit(int n_blocks, const DevCfg& cfg, const CarStats* stats,
                       const long long* block_idx, ShiftParams* shifts, int* work_list,
-                      int* work_count, thr_record* records, hipStream_t stream);
+                      int* work_count, thr_record* records, CorrStats* corr_stats_x2,
+                      hipStream_t stream);   // corr_stats_x2: where to park sum |X|^2 (or null)
 hipError_t launch_correlate_16k(int fmt, const void* samples, const DevCfg& cfg,
                                 const float2* tables, const float2* twn, const float4* tspec,
                                 const ShiftParams* shifts, const int* work_list,
@@ -116,13 +117,12 @@ hipError_t launch_carrier_long(int fmt, const void* samples, int n_blocks, const
 hipError_t launch_correlate_long(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,
                                  const float2* tables, const float2* twn, const float4* tspec,
                                  const ShiftParams* shifts, const int* work_list,
-                                 const int* work_count, float2* dsub, float* partial_x2,
-                                 float4* xhat_scratch, float2* dump_xhat, int grid, int base, int cap,
-                                 hipStream_t stream);
+                                 const int* work_count, float2* dsub, float4* xhat_scratch,
+                                 float2* dump_xhat, int grid, int base, int cap, hipStream_t stream);
 hipError_t launch_combine_long(const DevCfg& cfg, const float2* twn, const int* work_list,
-                               const int* work_count, const float2* dsub, const float* partial_x2,
-                               CorrStats* corr_stats, float2* dump_corr, int dump_template, int base,
-                               int cap, hipStream_t stream);
+                               const int* work_count, const float2* dsub, CorrStats* corr_stats,
+                               float2* dump_corr, int dump_template, int base, int cap,
+                               hipStream_t stream);
 int long_chunk_blocks(int block_len, int n_templates);
 
 // card_ingest.hip (.card base64 payloads -> u8 IQ on the device)

@@ -465,7 +465,6 @@ __global__ __launch_bounds__(NT) void k_correlate_sub(
     const ShiftParams* __restrict__ shifts, const int* __restrict__ work_list,
     const int* __restrict__ work_count, int slot_base, int slot_cap,
     f4* __restrict__ dsub,           // [slot - slot_base][tpl][k0][M/2] float4
-    float* __restrict__ partial_x2,  // [slot - slot_base][R0]
     f4* __restrict__ xhat_scratch, cpx* __restrict__ dump_xhat) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cpx* lds = reinterpret_cast<cpx*>(smem_raw);
@@ -483,7 +482,6 @@ __global__ __launch_bounds__(NT) void k_correlate_sub(
     // (`work_list` already points at slot_base)
     const int n_work = max(0, min(*work_count - slot_base, slot_cap));
     const int T = cfg.n_templates;
-    int parity = 0;
 
     const bool per_block = n_work >= int(gridDim.x);
     const int n_iter = per_block ? ((n_work - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x)) * R0
@@ -527,9 +525,6 @@ __global__ __launch_bounds__(NT) void k_correlate_sub(
         fwd_pass3(lds, xh);
 
         const int kbase = (t >> 5) + 16 * (t & 31);
-        float sums[1] = {0.f};
-#pragma unroll
-        for (int i = 0; i < R3; ++i) sums[0] += cnorm(xh[i]);
         if constexpr (DUMP) {
             if (dump_xhat != nullptr)
                 static_for<R3>([&](auto K) {
@@ -537,11 +532,7 @@ __global__ __launch_bounds__(NT) void k_correlate_sub(
                     dump_xhat[size_t(b) * NL + k0 + R0 * (kbase + 512 * k3)] = xh[brev(k3, R3)];
                 });
         }
-        double tot[1];
-        unsigned long long dummy = 0;
-        block_reduce<1, NT / 64>(sums, tot, dummy, sc_red, parity);
-        parity ^= 1;
-        if (t == 0) partial_x2[size_t(slot) * R0 + k0] = (float)tot[0];
+        // (sum |X^|^2 for the noise estimate == sum |X|^2 of the carrier stage: k_fit parks it)
         // the spectrum stays in registers across templates (64 VGPRs; parking it in an L2
         // scratch row between templates measured slower, as in k_correlate)
         for (int tpl = 0; tpl < T; ++tpl) {
@@ -587,7 +578,6 @@ __device__ __forceinline__ void combine_at(const cpx* __restrict__ d, const cpx*
 template <int R0>
 __global__ __launch_bounds__(1024) void k_combine(DevCfg cfg, const cpx* __restrict__ twn,
                                                   const cpx* __restrict__ dsub,
-                                                  const float* __restrict__ partial_x2,
                                                   const int* __restrict__ work_list,
                                                   const int* __restrict__ work_count,
                                                   int slot_base, CorrStats* __restrict__ corr_stats,
@@ -645,11 +635,6 @@ __global__ __launch_bounds__(1024) void k_combine(DevCfg cfg, const cpx* __restr
                 v = cnorm(sel);
             }
             cs->m2[dd] = v;
-        }
-        if (tpl == 0) {
-            float s = 0.f;
-            for (int k0 = 0; k0 < R0; ++k0) s += partial_x2[size_t(slot) * R0 + k0];
-            cs->sum_x2 = s;
         }
         cs->sum_mag = (float)tot[0];
         cs->sum_mag2 = (float)tot[1];
@@ -727,10 +712,10 @@ template <int R0>
 hipError_t correlate_r0(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,
                         const float2* tables, const float2* twn, const float4* tspec,
                         const ShiftParams* shifts, const int* work_list, const int* work_count,
-                        float2* dsub, float* partial_x2, float4* xhat_scratch, float2* dump_xhat,
-                        int grid, int base, int cap, hipStream_t stream) {
+                        float2* dsub, float4* xhat_scratch, float2* dump_xhat, int grid, int base,
+                        int cap, hipStream_t stream) {
     typedef void (*fn_t)(const void*, DevCfg, const cpx*, const cpx*, const f4*, const ShiftParams*,
-                         const int*, const int*, int, int, f4*, float*, f4*, cpx*);
+                         const int*, const int*, int, int, f4*, f4*, cpx*);
     const bool dump = dump_xhat != nullptr;
     fn_t fn = fmt == THR_IN_U8
                   ? (dump ? &k_correlate_sub<THR_IN_U8, R0, true> : &k_correlate_sub<THR_IN_U8, R0, false>)
@@ -740,19 +725,18 @@ hipError_t correlate_r0(int fmt, const void* samples, int n_blocks, const DevCfg
     hipLaunchKernelGGL(fn, dim3(std::min(grid, cap * R0)), dim3(NT), LDS_BYTES, stream, samples, cfg,
                        reinterpret_cast<const cpx*>(tables), reinterpret_cast<const cpx*>(twn),
                        reinterpret_cast<const f4*>(tspec), shifts, work_list + base, work_count, base,
-                       cap, reinterpret_cast<f4*>(dsub), partial_x2,
-                       reinterpret_cast<f4*>(xhat_scratch), reinterpret_cast<cpx*>(dump_xhat));
+                       cap, reinterpret_cast<f4*>(dsub), reinterpret_cast<f4*>(xhat_scratch),
+                       reinterpret_cast<cpx*>(dump_xhat));
     return hipGetLastError();
 }
 
 template <int R0>
 hipError_t combine_r0(const DevCfg& cfg, const float2* twn, const int* work_list,
-                      const int* work_count, const float2* dsub, const float* partial_x2,
-                      CorrStats* corr_stats, float2* dump_corr, int dump_template, int base, int cap,
+                      const int* work_count, const float2* dsub, CorrStats* corr_stats, float2* dump_corr, int dump_template, int base, int cap,
                       hipStream_t stream) {
     hipLaunchKernelGGL(k_combine<R0>, dim3(cap * cfg.n_templates), dim3(1024), 0, stream, cfg,
                        reinterpret_cast<const cpx*>(twn), reinterpret_cast<const cpx*>(dsub),
-                       partial_x2, work_list + base, work_count, base, corr_stats,
+                       work_list + base, work_count, base, corr_stats,
                        reinterpret_cast<cpx*>(dump_corr), dump_template);
     return hipGetLastError();
 }
@@ -779,26 +763,23 @@ hipError_t launch_carrier_long(int fmt, const void* samples, int n_blocks, const
 hipError_t launch_correlate_long(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,
                                  const float2* tables, const float2* twn, const float4* tspec,
                                  const ShiftParams* shifts, const int* work_list,
-                                 const int* work_count, float2* dsub, float* partial_x2,
-                                 float4* xhat_scratch, float2* dump_xhat, int grid, int base, int cap,
-                                 hipStream_t stream) {
+                                 const int* work_count, float2* dsub, float4* xhat_scratch,
+                                 float2* dump_xhat, int grid, int base, int cap, hipStream_t stream) {
     return cfg.block_len == 2 * M
                ? correlate_r0<2>(fmt, samples, n_blocks, cfg, tables, twn, tspec, shifts, work_list,
-                                 work_count, dsub, partial_x2, xhat_scratch, dump_xhat, grid, base, cap,
-                                 stream)
+                                 work_count, dsub, xhat_scratch, dump_xhat, grid, base, cap, stream)
                : correlate_r0<4>(fmt, samples, n_blocks, cfg, tables, twn, tspec, shifts, work_list,
-                                 work_count, dsub, partial_x2, xhat_scratch, dump_xhat, grid, base, cap,
-                                 stream);
+                                 work_count, dsub, xhat_scratch, dump_xhat, grid, base, cap, stream);
 }
 
 hipError_t launch_combine_long(const DevCfg& cfg, const float2* twn, const int* work_list,
-                               const int* work_count, const float2* dsub, const float* partial_x2,
-                               CorrStats* corr_stats, float2* dump_corr, int dump_template, int base,
-                               int cap, hipStream_t stream) {
+                               const int* work_count, const float2* dsub, CorrStats* corr_stats,
+                               float2* dump_corr, int dump_template, int base, int cap,
+                               hipStream_t stream) {
     return cfg.block_len == 2 * M
-               ? combine_r0<2>(cfg, twn, work_list, work_count, dsub, partial_x2, corr_stats, dump_corr,
+               ? combine_r0<2>(cfg, twn, work_list, work_count, dsub, corr_stats, dump_corr,
                                dump_template, base, cap, stream)
-               : combine_r0<4>(cfg, twn, work_list, work_count, dsub, partial_x2, corr_stats, dump_corr,
+               : combine_r0<4>(cfg, twn, work_list, work_count, dsub, corr_stats, dump_corr,
                                dump_template, base, cap, stream);
 }
 

@@ -28,6 +28,15 @@ __device__ __forceinline__ int opaque_tid() {
 #define THR_ABLATE_AT(code, stmt) do { } while (0)
 #endif
 
+// Dev-only (-DTHR_DEV_NOBAR): the workgroup barriers inside the per-block loops vanish, so the
+// waves free-run and drift apart (results are garbage) -- the kernel time then shows what the
+// barrier lockstep of the LDS and VALU bursts costs.
+#ifdef THR_DEV_NOBAR
+#define THR_LOOP_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#else
+#define THR_LOOP_BARRIER() __syncthreads()
+#endif
+
 // Dev-only cycle timeline (-DTHR_TIMELINE): workgroup 0 records s_memtime at phase
 // boundaries of its 4th block, one row of 16 stamps per wave, into cfg.timeline.
 #ifdef THR_TIMELINE
@@ -108,7 +117,7 @@ __device__ __forceinline__ void block_reduce(float (&s)[NS], double (&out)[NS],
         for (int i = 0; i < NS; ++i) sd[wv * 3 + i] = (double)s[i];
         su[wv] = m;
     }
-    __syncthreads();
+    THR_LOOP_BARRIER();
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         double t = 0;
@@ -122,5 +131,20 @@ __device__ __forceinline__ void block_reduce(float (&s)[NS], double (&out)[NS],
     m = t;
 }
 
+// The same with no sums: one u64 max, ONE barrier (same scratch layout and parity rule).
+template <int NW>
+__device__ __forceinline__ void block_reduce_max(unsigned long long& m, unsigned char* scratch,
+                                                 int parity) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long* su =
+        reinterpret_cast<unsigned long long*>(scratch + parity * red_slot_bytes<NW>()) + 3 * NW;
+    m = wave_max(m);
+    if (lane == 0) su[wv] = m;
+    THR_LOOP_BARRIER();
+    unsigned long long t = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t = su[w] > t ? su[w] : t;
+    m = t;
+}
 
 }  // namespace thr
