@@ -575,14 +575,20 @@ __device__ __forceinline__ void combine_at(const cpx* __restrict__ d, const cpx*
     for (int n0 = 0; n0 < R0; ++n0) out[n0] = u[brev(n0, R0)];
 }
 
+// HBM / Infinity-Cache-bound byte work (8 R0 M bytes read per (slot, template), ~30 flop per
+// 32 bytes).  512 threads and <= 80 VGPRs so that a workgroup fits on a CU NEXT TO a resident
+// k_correlate_sub workgroup (2 x 168 + 2 x 80 <= 512 registers per lane, 1 KiB of LDS): the
+// host runs the combination of chunk i on a second stream under the sub-transforms of chunk
+// i + 1.  Each thread takes two adjacent lags per step (one 16-byte load per sub-transform).
+constexpr int CMB_T = 512;
 template <int R0>
-__global__ __launch_bounds__(1024) void k_combine(DevCfg cfg, const cpx* __restrict__ twn,
-                                                  const cpx* __restrict__ dsub,
-                                                  const int* __restrict__ work_list,
-                                                  const int* __restrict__ work_count,
-                                                  int slot_base, CorrStats* __restrict__ corr_stats,
-                                                  cpx* __restrict__ dump_corr, int dump_template) {
-    __shared__ __attribute__((aligned(16))) unsigned char scratch[2 * 16 * 32];
+__global__ __launch_bounds__(CMB_T) void k_combine(DevCfg cfg, const cpx* __restrict__ twn,
+                                                   const cpx* __restrict__ dsub,
+                                                   const int* __restrict__ work_list,
+                                                   const int* __restrict__ work_count,
+                                                   int slot_base, CorrStats* __restrict__ corr_stats,
+                                                   cpx* __restrict__ dump_corr, int dump_template) {
+    __shared__ __attribute__((aligned(16))) unsigned char scratch[2 * (CMB_T / 64) * 32];
     const int T = cfg.n_templates;
     const int slot = blockIdx.x / T, tpl = blockIdx.x % T;   // chunk-local; work_list points at slot_base
     if (slot_base + slot >= *work_count) return;
@@ -590,34 +596,46 @@ __global__ __launch_bounds__(1024) void k_combine(DevCfg cfg, const cpx* __restr
     const int NL = R0 * M, nl_mask = NL - 1;
     const cpx* d = dsub + (size_t(slot) * T + tpl) * NL;
     float sums[2] = {0.f, 0.f};
-    float bestp = -1.f;
-    int bestn = 0;
     const unsigned win_w = unsigned(cfg.corr_hi - cfg.corr_lo);
     // n0-major order would visit lags out of order; ties are resolved through the key instead
     unsigned long long best = 0;
-    for (int m = threadIdx.x; m < M; m += blockDim.x) {
-        cpx c[R0];
-        combine_at<R0>(d, twn, m, nl_mask, c);
+    for (int m = 2 * threadIdx.x; m < M; m += 2 * CMB_T) {
+        cpx u0[R0], u1[R0];
+        {
+            const f4 q = *reinterpret_cast<const f4*>(d + m);
+            u0[0] = cpx{q.x, q.y};
+            u1[0] = cpx{q.z, q.w};
+        }
+#pragma unroll
+        for (int k0 = 1; k0 < R0; ++k0) {
+            const f4 q = *reinterpret_cast<const f4*>(d + size_t(k0) * M + m);
+            u0[k0] = cmulc(cpx{q.x, q.y}, twn[(m * k0) & nl_mask]);
+            u1[k0] = cmulc(cpx{q.z, q.w}, twn[((m + 1) * k0) & nl_mask]);
+        }
+        dft_dif<R0, +1>(u0);
+        dft_dif<R0, +1>(u1);
 #pragma unroll
         for (int n0 = 0; n0 < R0; ++n0) {
-            const int n = n0 * M + m;
-            const float pw = cnorm(c[n0]);
-            if (unsigned(n - cfg.corr_lo) < win_w) {
-                const unsigned long long key =
-                    ((unsigned long long)__float_as_uint(pw) << 32) | (0xFFFFFFFFu - unsigned(n));
-                best = key > best ? key : best;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const cpx c = e ? u1[brev(n0, R0)] : u0[brev(n0, R0)];
+                const int n = n0 * M + m + e;
+                const float pw = cnorm(c);
+                if (unsigned(n - cfg.corr_lo) < win_w) {
+                    const unsigned long long key =
+                        ((unsigned long long)__float_as_uint(pw) << 32) | (0xFFFFFFFFu - unsigned(n));
+                    best = key > best ? key : best;
+                }
+                if (cfg.cor_want_std && n < cfg.corr_len) {
+                    sums[1] += pw;
+                    sums[0] += __builtin_amdgcn_sqrtf(pw);
+                }
+                if (dump_corr != nullptr && tpl == dump_template) dump_corr[size_t(b) * NL + n] = c;
             }
-            if (cfg.cor_want_std && n < cfg.corr_len) {
-                sums[1] += pw;
-                sums[0] += __builtin_amdgcn_sqrtf(pw);
-            }
-            if (dump_corr != nullptr && tpl == dump_template) dump_corr[size_t(b) * NL + n] = c[n0];
         }
     }
-    (void)bestp;
-    (void)bestn;
     double tot[2];
-    block_reduce<2, 16>(sums, tot, best, scratch, 0);
+    block_reduce<2, CMB_T / 64>(sums, tot, best, scratch, 0);
     if (threadIdx.x == 0) {
         CorrStats* cs = corr_stats + size_t(b) * T + tpl;
         const int pk = int(0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu));
@@ -734,7 +752,7 @@ template <int R0>
 hipError_t combine_r0(const DevCfg& cfg, const float2* twn, const int* work_list,
                       const int* work_count, const float2* dsub, CorrStats* corr_stats, float2* dump_corr, int dump_template, int base, int cap,
                       hipStream_t stream) {
-    hipLaunchKernelGGL(k_combine<R0>, dim3(cap * cfg.n_templates), dim3(1024), 0, stream, cfg,
+    hipLaunchKernelGGL(k_combine<R0>, dim3(cap * cfg.n_templates), dim3(CMB_T), 0, stream, cfg,
                        reinterpret_cast<const cpx*>(twn), reinterpret_cast<const cpx*>(dsub),
                        work_list + base, work_count, base, corr_stats,
                        reinterpret_cast<cpx*>(dump_corr), dump_template);
