@@ -5,14 +5,18 @@
 set -u
 TAG=${1:-r01}; shift || true
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/prof_$TAG
-mkdir -p $O
+# raw rocprofv3 output (tens of MB per pass) stays on the box; only the summaries, the kernel
+# stats CSV and the bench logs go to gpurun_out/ (which is merged back, 64 MiB limit)
+O=/tmp/prof_$TAG
+K=$R/gpurun_out/prof_$TAG
+rm -rf $O; mkdir -p $O $K
 export TMPDIR=/tmp
 cd $R
 # kernel-trace pass: bench.py's own defaults (32 steps x 32768 blocks), so that clocks settle and the per-kernel averages
 # are the ones bench.py's HIP events see; PMC passes: 8 steps (counter collection serialises
 # every dispatch, data generation included -- a full-length run takes tens of minutes)
 BENCH_STATS="python bench.py --streams 1 --cpu-seconds 0 --profile-kernels 0 $*"
+# (long blocks, --config c3: THR_LONG_OVERLAP=0 in the environment keeps the two kernels of the correlate stage from overlapping in the trace)
 BENCH="python bench.py --streams 1 --steps 8 --warmup 1 --cpu-seconds 0 --profile-kernels 0 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o stats -- $BENCH_STATS > $O/bench_stats.log 2>&1
 pass() {  # name counters...
@@ -24,6 +28,7 @@ pass pmc_sq2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_LDS_BANK_
 pass pmc_grbm GRBM_GUI_ACTIVE GRBM_COUNT
 pass pmc_fetch FETCH_SIZE
 pass pmc_write WRITE_SIZE
-find $O -name "*.csv" | head -40
 python scripts/summarize_profile.py $O > $O/summary.md 2>&1
+cp $O/summary.md $O/hbm_traffic.json $O/bench_*.log $K/ 2>/dev/null
+cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $K/kernel_stats.csv 2>/dev/null
 cat $O/summary.md

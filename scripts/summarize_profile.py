@@ -10,8 +10,10 @@ root = sys.argv[1]
 
 
 def short(name):
-    for k in ("k_carrier_pruned", "k_carrier", "k_fit_preshift", "k_fit", "k_finish", "k_correlate", "k_preshift",
-              "k_compact"):
+    for k in ("k_carrier_pruned", "k_carrier_dit", "k_carrier_sub_pruned", "k_carrier_sub", "k_carrier_small",
+              "k_carrier", "k_select_dit", "k_select", "k_fit_preshift", "k_fit", "k_finish",
+              "k_correlate_sub", "k_correlate_small", "k_correlate", "k_combine", "k_preshift",
+              "k_compact_count", "k_compact_scan", "k_compact_scatter", "k_b64_decode"):
         if k in name:
             return k
     return name[:60]
@@ -58,6 +60,5 @@ if acc:
         if k.startswith("k_") and "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
             f = sum(acc[k]["FETCH_SIZE"]) / len(acc[k]["FETCH_SIZE"])
             w = sum(acc[k]["WRITE_SIZE"]) / len(acc[k]["WRITE_SIZE"])
-            traffic[k] = {"fetch_kib_raw": f, "write_kib": w,
-                          "bytes_per_launch_at_batch": {os.environ.get("THR_PROFILE_BATCH", "32768"): int((2 * f + w) * 1024)}}
+            traffic[k] = {"fetch_kib_raw": f, "write_kib": w, "bytes_per_launch": int((2 * f + w) * 1024)}
     json.dump(traffic, open(os.path.join(root, "hbm_traffic.json"), "w"), indent=1)

@@ -99,6 +99,8 @@ struct thr_handle {
     int n_cu = 0;
     bool fast = false;       // LDS-resident 16384 kernels; else the generic multi-pass path
     bool lng = false;        // block_len = 2 or 4 x 16384: R0 LDS sub-transforms per block
+    bool small = false;      // block_len = 1024 ... 8192: 16 / R1 blocks per workgroup in LDS (no
+                             // stddev threshold terms; dumps take the generic path)
     int long_batch = 0;      // long path: blocks per internal sub-batch
     int long_chunk = 0;      // long path: work-list slots per correlate-stage chunk (sizes d_dsub)
     float* d_win_pow = nullptr;     // long: [long_batch][win_w] |X|^2 of the window bins (+-3)
@@ -215,7 +217,7 @@ int build_constants(thr_handle* h) {
     // --- pass-1 / pass-B twiddles W_16384^(k1 q) of k_correlate as one L2-resident table in
     //     global memory (THR_GTW=0: the factored LDS tables A[k1][n2] * Bt[k1][m'] instead)
     h->dev.gtw = nullptr;
-    if (h->fast && !(getenv("THR_GTW") && atoi(getenv("THR_GTW")) == 0)) {
+    if (h->small || (h->fast && !(getenv("THR_GTW") && atoi(getenv("THR_GTW")) == 0))) {
         std::vector<float2> g(16 * 1024);
         for (int k1 = 0; k1 < 16; ++k1)
             for (int q = 0; q < 1024; ++q) g[k1 * 1024 + q] = unit_root((long long)k1 * q, 16384);
@@ -232,6 +234,7 @@ int build_constants(thr_handle* h) {
     //     digit-reversed, lane-coalesced order k_correlate consumes
     const int w = h->cfg.template_len, nt = h->cfg.n_templates;
     std::vector<float2> spec(size_t(nt) * n);
+    std::vector<float2> spec_nat(h->small ? size_t(nt) * n : 0);   // small: natural order too (dump path)
     for (int t = 0; t < nt; ++t) {
         std::vector<std::complex<double>> buf(n, 0.0);
         double energy = 0;
@@ -254,6 +257,21 @@ int build_constants(thr_handle* h) {
                         out[size_t(k0) * 16384 + ((k3 >> 1) * 512 + tid) * 2 + (k3 & 1)] =
                             float2{float(c.real()), float(c.imag())};
                     }
+        } else if (h->small) {
+            // thread column c = k1 * 32 + k2 (k1 < R1) holds bins k1 + R1 k2 + 32 R1 k3;
+            // float4 j of the column = k3 in {2j, 2j + 1}, stored [j][c] for coalescing
+            const int r1 = n / 1024, tb = 32 * r1;
+            for (int c = 0; c < tb; ++c)
+                for (int k3 = 0; k3 < 32; ++k3) {
+                    const int k = (c >> 5) + r1 * (c & 31) + tb * k3;
+                    const std::complex<double> cc = std::conj(buf[k]) / double(n);
+                    out[((k3 >> 1) * tb + c) * 2 + (k3 & 1)] = float2{float(cc.real()), float(cc.imag())};
+                }
+            float2* nat = spec_nat.data() + size_t(t) * n;
+            for (int k = 0; k < n; ++k) {
+                const std::complex<double> cc = std::conj(buf[k]) / double(n);
+                nat[k] = float2{float(cc.real()), float(cc.imag())};
+            }
         } else if (h->fast) {
             for (int tid = 0; tid < 512; ++tid)
                 for (int k3 = 0; k3 < 32; ++k3) {
@@ -272,10 +290,15 @@ int build_constants(thr_handle* h) {
     float2* d_spec = nullptr;
     HIP_TRY(hipMalloc(&d_spec, spec.size() * sizeof(float2)));
     HIP_TRY(hipMemcpy(d_spec, spec.data(), spec.size() * sizeof(float2), hipMemcpyHostToDevice));
-    if (h->fast || h->lng)
+    if (h->fast || h->lng || h->small)
         h->d_tspec = reinterpret_cast<float4*>(d_spec);
     else
         h->d_tspec_nat = d_spec;
+    if (h->small) {
+        HIP_TRY(hipMalloc(&h->d_tspec_nat, spec_nat.size() * sizeof(float2)));
+        HIP_TRY(hipMemcpy(h->d_tspec_nat, spec_nat.data(), spec_nat.size() * sizeof(float2),
+                          hipMemcpyHostToDevice));
+    }
     return THR_OK;
 }
 
@@ -519,11 +542,46 @@ int run_batch_long(thr_handle* h, const void* d_samples, int format,
     return THR_OK;
 }
 
+// Short blocks (1024 ... 8192): 16 / R1 blocks per workgroup, LDS-resident (detect_small.hip).
+int run_batch_small(thr_handle* h, const void* d_samples, int format,
+                    const long long* d_block_idx, int n_blocks, thr_record* d_out) {
+    h->prof = h->prof_every > 0 && (h->batch_no++ % h->prof_every) == 0;
+    {
+        ProfScope p(h, 0);
+        HIP_TRY(thr::launch_carrier_small(format, d_samples, n_blocks, h->dev, h->d_tables, h->d_gtw,
+                                          h->d_stats, h->n_cu, h->stream));
+    }
+    {
+        ProfScope p(h, 1);
+        HIP_TRY(thr::launch_fit(n_blocks, h->dev, h->d_stats, d_block_idx, h->d_shifts,
+                                h->d_work_list, h->d_work_count, d_out, h->d_corr_stats, h->stream));
+    }
+    {
+        ProfScope p(h, 2);
+        HIP_TRY(thr::launch_correlate_small(format, d_samples, n_blocks, h->dev, h->d_tables, h->d_gtw,
+                                            h->d_twn, h->d_tspec, h->d_shifts, h->d_work_list,
+                                            h->d_work_count, h->d_corr_stats, h->n_cu, h->stream));
+    }
+    {
+        ProfScope p(h, 3);
+        HIP_TRY(thr::launch_finish(n_blocks * h->cfg.n_templates, h->dev, h->d_corr_stats, d_out,
+                                   h->d_work_count, h->stream));
+    }
+    return THR_OK;
+}
+
 int run_batch(thr_handle* h, const void* d_samples, int format, const long long* d_block_idx,
               int n_blocks, thr_record* d_out, float2* dump_fft, float2* dump_xhat,
               float2* dump_corr, int dump_template, bool carrier_only, size_t stride = 0) {
     // stride 0: blocks packed back to back; otherwise raw-stream framing (overlapping blocks)
     h->dev.blk_stride = stride ? stride : size_t(h->cfg.block_len) * (format == THR_IN_U8 ? 2 : 8);
+    if (h->small) {
+        if (!dump_fft && !dump_xhat && !dump_corr && !carrier_only)
+            return run_batch_small(h, d_samples, format, d_block_idx, n_blocks, d_out);
+        if (!h->d_gen_scratch)   // stage dumps (test hooks, yield_data): the multi-pass pipeline, on demand
+            HIP_TRY(hipMalloc(&h->d_gen_scratch,
+                              thr::generic_scratch_bytes(h->cfg.block_len, h->gen_batch)));
+    }
     return (h->fast ? run_batch_fast : h->lng ? run_batch_long : run_batch_generic)(
         h, d_samples, format, d_block_idx, n_blocks, d_out, dump_fft, dump_xhat, dump_corr,
         dump_template, carrier_only);
@@ -608,7 +666,7 @@ static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out
             break;
         }
         h->n_cu = prop.multiProcessorCount;
-        if ((h->fast || h->lng) && size_t(prop.maxSharedMemoryPerMultiProcessor) <
+        if ((h->fast || h->lng || thr::small_supported(n)) && size_t(prop.maxSharedMemoryPerMultiProcessor) <
                            thr::lds_bytes_16k()) {
             rc = fail(THR_ERR_DEVICE, "device has %zu B LDS per CU, need %zu",
                       size_t(prop.maxSharedMemoryPerMultiProcessor), thr::lds_bytes_16k());
@@ -657,6 +715,8 @@ static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out
                 d.car_prune = 2;  // any narrow window: pre-shift by win_lo - 3
         }
         d.cor_want_std = s->corr_thresh[2] != 0.0;
+        h->small = thr::small_supported(n) && getenv("THR_FORCE_GENERIC") == nullptr && !preshift_num &&
+                   !d.car_want_std && !d.cor_want_std;
 
         h->cfg.templates = s->templates;
         rc = build_constants(h);
@@ -671,6 +731,7 @@ static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out
     }
         if (h->fast) CREATE_TRY(thr::prepare_16k());
         if (h->fast && preshift_num) CREATE_TRY(thr::prepare_preshift_16k());
+        if (h->small) CREATE_TRY(thr::prepare_small(n));
         if (h->lng) {
             CREATE_TRY(thr::prepare_long(n));
             const int r0 = n / 16384;
@@ -706,7 +767,8 @@ static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out
             const size_t per_block = size_t(3) * n * sizeof(float2);
             h->gen_batch = int(std::max<size_t>(1, std::min<size_t>(size_t(s->max_batch),
                                                                     (size_t(256) << 20) / per_block)));
-            CREATE_TRY(hipMalloc(&h->d_gen_scratch, thr::generic_scratch_bytes(n, h->gen_batch)));
+            if (!h->small)   // (short blocks run LDS-resident; their dump path allocates this on demand)
+                CREATE_TRY(hipMalloc(&h->d_gen_scratch, thr::generic_scratch_bytes(n, h->gen_batch)));
         }
         CREATE_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
         h->stream = h->own_stream;

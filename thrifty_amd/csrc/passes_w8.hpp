@@ -203,7 +203,11 @@ __device__ __forceinline__ void inv_passA(cpx* lds, cpx* z) {
 
 // Pass B (radix 32 over k2, in place) -- thread (k1 = t>>5, n3 = t&31);
 // twiddle conj(W_N^(k1*(32*n2 + n3))) = conj(A[k1][n2] * Bt[k1][n3]).
-__device__ __forceinline__ void inv_passB(cpx* lds, const cpx* __restrict__ gtw = nullptr) {
+// tw_row >= 0: row of the gtw table to use instead of k1 (block_len R1 * 1024 < 16384: LDS row
+// r holds sub-sequence k1 = r mod R1 of one of the 16 / R1 blocks, whose twiddle
+// W_N^(k1 q) = W_16384^(k1 (16 / R1) q) is table row k1 * 16 / R1 -- detect_small.hip)
+__device__ __forceinline__ void inv_passB(cpx* lds, const cpx* __restrict__ gtw = nullptr,
+                                          int tw_row = -1) {
     const int t = opaque_tid();
     const int k1 = t >> 5, n3 = t & 31;
     cpx* base = lds + k1 * ROW + n3;
@@ -213,7 +217,7 @@ __device__ __forceinline__ void inv_passB(cpx* lds, const cpx* __restrict__ gtw 
     if (gtw != nullptr) {
         // twiddles W_N^(k1 (32 n2 + n3)) straight from the L2-resident table: issued before the
         // butterfly, consumed after it
-        const cpx* tw = gtw + k1 * 1024 + n3;
+        const cpx* tw = gtw + (tw_row >= 0 ? tw_row : k1) * 1024 + n3;
         cpx w[R2];
 #pragma unroll
         for (int n2 = 0; n2 < R2; ++n2) w[n2] = tw[n2 * 32];
