@@ -16,7 +16,6 @@ cd $R
 # are the ones bench.py's HIP events see; PMC passes: 8 steps (counter collection serialises
 # every dispatch, data generation included -- a full-length run takes tens of minutes)
 BENCH_STATS="python bench.py --streams 1 --cpu-seconds 0 --profile-kernels 0 $*"
-# (long blocks, --config c3: THR_LONG_OVERLAP=0 in the environment keeps the two kernels of the correlate stage from overlapping in the trace)
 BENCH="python bench.py --streams 1 --steps 8 --warmup 1 --cpu-seconds 0 --profile-kernels 0 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o stats -- $BENCH_STATS > $O/bench_stats.log 2>&1
 pass() {  # name counters...

@@ -136,8 +136,13 @@ def _read_arrived(stream, view, grace=0.002):
     `readinto` on a BufferedReader (sys.stdin.buffer) blocks until the whole view is full, so
     `fastcard ... | thrifty detect -` would emit nothing until 64 MiB had accumulated; the
     reference's readers return per line / per block.  A fast producer (`cat rx.card |`) keeps the
-    descriptor readable, so its batches still fill up."""
+    descriptor readable, so its batches still fill up.  In-memory streams (no descriptor) have
+    nothing to wait for: one plain `readinto`."""
     one = getattr(stream, "readinto1", None)
+    try:
+        stream.fileno()
+    except (AttributeError, OSError, ValueError):
+        one = None
     if one is None:
         if hasattr(stream, "readinto"):
             return stream.readinto(view) or 0
@@ -152,6 +157,18 @@ def _read_arrived(stream, view, grace=0.002):
         got = one(view[total:]) or 0
         total += got
     return total
+
+
+def _widen_pipe(stream, size=1 << 20):
+    """A FIFO's kernel buffer is 64 KiB by default -- one .card line is 43 KiB: ask for 1 MiB so
+    that a fast producer is drained in few system calls (Linux F_SETPIPE_SZ; best effort)."""
+    try:
+        fd = stream.fileno()
+        if stat.S_ISFIFO(os.fstat(fd).st_mode):
+            import fcntl
+            fcntl.fcntl(fd, getattr(fcntl, "F_SETPIPE_SZ", 1031), size)
+    except (AttributeError, OSError, ValueError, ImportError):
+        pass
 
 
 class CardStream(object):
@@ -176,6 +193,7 @@ class CardStream(object):
         if mapped is not None:       # regular file: the whole text is "already read"
             self._buf, self._pos, self._end, self._eof = mapped, at, len(mapped), True
             return
+        _widen_pipe(stream)
         self._buf = bytearray(self.chunk_bytes)
         self._pos = 0   # first unconsumed byte
         self._end = 0   # one past the last valid byte
@@ -315,6 +333,8 @@ class RawStream(object):
         self._arrivals = []     # (valid bytes after the read, time.time()) of this batch's reads
         # regular file: overlapping blocks are plain slices of the mapping (no carry, no copy)
         self._map, self._off = _map_regular_file(stream)
+        if self._map is None:
+            _widen_pipe(stream)
         self._origin = self._off    # stream byte 0 (the caller may have consumed a header)
         self._stop_idx = None       # sharded mapped file: one past this rank's last block
 

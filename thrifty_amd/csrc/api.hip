@@ -106,13 +106,6 @@ struct thr_handle {
     float* d_win_pow = nullptr;     // long: [long_batch][win_w] |X|^2 of the window bins (+-3)
     float* d_partial = nullptr;     // long: [long_batch][R0][2] partial sums of FFT#1
     float2* d_dsub = nullptr;       // long: [long_chunk][T][R0][16384] sub-transform outputs
-    float2* d_dsub2 = nullptr;      // long: second buffer -- the combination of chunk i runs on
-                                    // aux_stream under the sub-transforms of chunk i + 1
-    hipStream_t aux_stream = nullptr;
-    hipEvent_t ev_sub[2] = {nullptr, nullptr};   // sub-transforms of the chunk in buffer b are done
-    hipEvent_t ev_cmb[2] = {nullptr, nullptr};   // the combination has finished reading buffer b
-    bool cmb_pending[2] = {false, false};
-    bool long_overlap = false;
     int gen_batch = 0;       // generic path: blocks per internal sub-batch
     float2* d_gen_scratch = nullptr;  // generic path: 3 * gen_batch * N complex
     float2* d_tspec_nat = nullptr;    // generic path: conj(FFT(template))/N, natural order
@@ -136,12 +129,31 @@ struct thr_handle {
     int preshift_num = 0;       // 0 = default detector
     float2* d_gtw = nullptr;    // optional combined twiddle table (THR_GTW)
     float2* d_bank = nullptr;   // [num][N]; 16384: [k3][k1][k2] gather layout, else natural order
-    // .card ingest staging (lazy)
-    unsigned char* d_text = nullptr;
-    size_t d_text_bytes = 0;
-    long long* d_payload_off = nullptr;
-    int* d_bad = nullptr;
-    // host-path staging (lazy)
+    // host-buffer entry points (thr_detect / _stream / _card): two sets of staging buffers so
+    // that the H2D copy of chunk i + 1 (copy stream) runs under the kernels of chunk i (lazy)
+    struct HostPipe {
+        bool ready = false;
+        hipStream_t copy = nullptr;
+        hipEvent_t ev_h2d[2] = {nullptr, nullptr};    // chunk's inputs have landed (copy stream)
+        hipEvent_t ev_done[2] = {nullptr, nullptr};   // chunk's records are in h_rec (main stream)
+        void* d_in[2] = {nullptr, nullptr};
+        size_t in_bytes[2] = {0, 0};
+        long long* d_idx[2] = {nullptr, nullptr};
+        thr_record* d_rec[2] = {nullptr, nullptr};
+        thr_record* h_rec[2] = {nullptr, nullptr};    // pinned: D2H never blocks the host
+        unsigned char* d_text[2] = {nullptr, nullptr};
+        size_t text_bytes[2] = {0, 0};
+        long long* d_off[2] = {nullptr, nullptr};
+        int* d_bad[2] = {nullptr, nullptr};
+        int* h_bad = nullptr;                         // pinned int[2]
+        std::vector<long long> idx_host[2], off_host[2];
+        // records of the chunk in buffer b still to be handed to the caller
+        thr_record* pend_dst[2] = {nullptr, nullptr};
+        size_t pend_n[2] = {0, 0};
+        size_t pend_first[2] = {0, 0};                // (first block of the chunk: error messages)
+        bool pend_card[2] = {false, false};
+    } hp;
+    // single-chunk staging of the test hooks (lazy)
     void* d_in = nullptr;
     size_t d_in_bytes = 0;
     long long* d_idx = nullptr;
@@ -330,6 +342,84 @@ int build_preshift_bank(thr_handle* h) {
     return THR_OK;
 }
 
+int ensure_pipe(thr_handle* h) {
+    auto& p = h->hp;
+    if (p.ready) return THR_OK;
+    const size_t mb = size_t(h->cfg.max_batch), nt = size_t(h->cfg.n_templates);
+    HIP_TRY(hipStreamCreateWithFlags(&p.copy, hipStreamNonBlocking));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p.h_bad), 2 * sizeof(int), hipHostMallocDefault));
+    for (int b = 0; b < 2; ++b) {
+        HIP_TRY(hipEventCreateWithFlags(&p.ev_h2d[b], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&p.ev_done[b], hipEventDisableTiming));
+        HIP_TRY(hipMalloc(&p.d_idx[b], mb * sizeof(long long)));
+        HIP_TRY(hipMalloc(&p.d_rec[b], mb * nt * sizeof(thr_record)));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p.h_rec[b]), mb * nt * sizeof(thr_record),
+                              hipHostMallocDefault));
+    }
+    p.ready = true;
+    return THR_OK;
+}
+
+int pipe_grow(void** buf, size_t* have, size_t need) {
+    if (*have >= need) return THR_OK;
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr;
+    *have = 0;
+    HIP_TRY(hipMalloc(buf, need + (need >> 3)));
+    *have = need + (need >> 3);
+    return THR_OK;
+}
+
+// hand the finished chunk of buffer b to the caller (waits for it); THR_OK if nothing is pending
+int pipe_drain(thr_handle* h, int b) {
+    auto& p = h->hp;
+    if (p.pend_n[b] == 0) return THR_OK;
+    HIP_TRY(hipEventSynchronize(p.ev_done[b]));
+    std::memcpy(p.pend_dst[b], p.h_rec[b], p.pend_n[b] * sizeof(thr_record));
+    const size_t n = p.pend_n[b], first = p.pend_first[b];
+    p.pend_n[b] = 0;
+    if (p.pend_card[b] && p.h_bad[b] != 0)
+        return fail(THR_ERR_ARG, "%d .card payload(s) in blocks [%zu, %zu) are not valid base64",
+                    p.h_bad[b], first, first + n / size_t(h->cfg.n_templates));
+    return THR_OK;
+}
+
+// after the chunk's H2D copies were enqueued on the copy stream: make the main stream wait for them
+int pipe_inputs_enqueued(thr_handle* h, int b) {
+    auto& p = h->hp;
+    HIP_TRY(hipEventRecord(p.ev_h2d[b], p.copy));
+    HIP_TRY(hipStreamWaitEvent(h->stream, p.ev_h2d[b], 0));
+    return THR_OK;
+}
+
+// after the chunk's kernels were enqueued on the main stream: records -> pinned staging, async
+int pipe_records_enqueued(thr_handle* h, int b, thr_record* dst, size_t n_rec, size_t first, bool card) {
+    auto& p = h->hp;
+    HIP_TRY(hipMemcpyAsync(p.h_rec[b], p.d_rec[b], n_rec * sizeof(thr_record), hipMemcpyDeviceToHost,
+                           h->stream));
+    if (card)
+        HIP_TRY(hipMemcpyAsync(p.h_bad + b, p.d_bad[b], sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipEventRecord(p.ev_done[b], h->stream));
+    p.pend_dst[b] = dst;
+    p.pend_n[b] = n_rec;
+    p.pend_first[b] = first;
+    p.pend_card[b] = card;
+    return THR_OK;
+}
+
+int pipe_finish(thr_handle* h, int rc) {   // drain both buffers; keeps the first error
+    for (int b = 0; b < 2; ++b) {
+        const int r = pipe_drain(h, b);
+        if (rc == THR_OK) rc = r;
+    }
+    if (rc != THR_OK) {
+        (void)hipStreamSynchronize(h->hp.copy);
+        (void)hipStreamSynchronize(h->stream);
+        h->hp.pend_n[0] = h->hp.pend_n[1] = 0;
+    }
+    return rc;
+}
+
 int ensure_staging(thr_handle* h, int format) {
     const size_t need = size_t(h->cfg.max_batch) * h->cfg.block_len * (format == THR_IN_U8 ? 2 : 8);
     if (h->d_in_bytes < need) {
@@ -491,48 +581,23 @@ int run_batch_long(thr_handle* h, const void* d_samples, int format,
         }
         // correlate stage in chunks of work-list slots: one chunk's d_k0 exchange stays in the
         // Infinity Cache between the sub-transform kernel (VALU/LDS-bound) and the combination
-        // (bandwidth-bound), and the combination of chunk i runs on a second stream under the
-        // sub-transforms of chunk i + 1 (two exchange buffers; its workgroups fit beside a
-        // resident k_correlate_sub workgroup, see detect_long.hip)
-        int c = 0;
-        for (int base = 0; base < nb; base += h->long_chunk, ++c) {
+        // (bandwidth-bound)
+        for (int base = 0; base < nb; base += h->long_chunk) {
             const int cap = std::min(h->long_chunk, nb - base);
-            const int buf = h->long_overlap ? (c & 1) : 0;
-            float2* dsub = buf ? h->d_dsub2 : h->d_dsub;
-            hipStream_t cs = h->long_overlap ? h->aux_stream : h->stream;
-            if (h->cmb_pending[buf]) {   // the combination of chunk c - 2 still reads this buffer
-                HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_cmb[buf], 0));
-                h->cmb_pending[buf] = false;
-            }
             {
                 ProfScope p(h, 2);
                 HIP_TRY(thr::launch_correlate_long(
                     format, in, nb, h->dev, h->d_tables, h->d_twn, h->d_tspec, h->d_shifts,
-                    h->d_work_list, h->d_work_count, dsub, h->d_xhat_scratch,
+                    h->d_work_list, h->d_work_count, h->d_dsub, h->d_xhat_scratch,
                     dump_xhat ? dump_xhat + size_t(off) * n : nullptr, std::min(nb * r0, h->n_cu), base,
                     cap, h->stream));
             }
-            if (h->long_overlap) {
-                HIP_TRY(hipEventRecord(h->ev_sub[buf], h->stream));
-                HIP_TRY(hipStreamWaitEvent(cs, h->ev_sub[buf], 0));
-            }
-            {
-                ProfScope p(h, 4, cs);
-                HIP_TRY(thr::launch_combine_long(h->dev, h->d_twn, h->d_work_list, h->d_work_count,
-                                                 dsub, h->d_corr_stats,
-                                                 dump_corr ? dump_corr + size_t(off) * n : nullptr,
-                                                 dump_template, base, cap, cs));
-            }
-            if (h->long_overlap) {
-                HIP_TRY(hipEventRecord(h->ev_cmb[buf], cs));
-                h->cmb_pending[buf] = true;
-            }
+            ProfScope p(h, 4);
+            HIP_TRY(thr::launch_combine_long(h->dev, h->d_twn, h->d_work_list, h->d_work_count,
+                                             h->d_dsub, h->d_corr_stats,
+                                             dump_corr ? dump_corr + size_t(off) * n : nullptr,
+                                             dump_template, base, cap, h->stream));
         }
-        for (int buf = 0; buf < 2; ++buf)   // join: k_finish (and the next sub-batch) follow the combinations
-            if (h->cmb_pending[buf]) {
-                HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_cmb[buf], 0));
-                h->cmb_pending[buf] = false;
-            }
         {
             ProfScope p(h, 3);
             HIP_TRY(thr::launch_finish(nb * int(T), h->dev, h->d_corr_stats, out, h->d_work_count,
@@ -744,22 +809,10 @@ static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out
             // (the decimation-in-time carrier stage parks R0 complex values per window bin here)
             CREATE_TRY(hipMalloc(&h->d_win_pow, lb * win_w * sizeof(float) * 2 * r0));
             CREATE_TRY(hipMalloc(&h->d_partial, lb * r0 * 2 * sizeof(float)));
-            // (measured at N = 65536, 4096-block batches: no overlap 1.71 M blocks/s; overlap with
-            // chunks of 64 / 128 / 256 / 512 slots 1.14 / 1.55 / 1.74 / 1.62 M -- the chunk size is
-            // NOT halved although two exchange buffers are then in flight)
-            h->long_overlap = !(getenv("THR_LONG_OVERLAP") && atoi(getenv("THR_LONG_OVERLAP")) == 0);
             h->long_chunk = std::min(h->long_batch, thr::long_chunk_blocks(n, s->n_templates));
             if (getenv("THR_LONG_CHUNK")) h->long_chunk = std::max(1, std::min(h->long_batch, atoi(getenv("THR_LONG_CHUNK"))));
             const size_t lc = size_t(h->long_chunk);
             CREATE_TRY(hipMalloc(&h->d_dsub, lc * s->n_templates * size_t(n) * sizeof(float2)));
-            if (h->long_overlap) {
-                CREATE_TRY(hipMalloc(&h->d_dsub2, lc * s->n_templates * size_t(n) * sizeof(float2)));
-                CREATE_TRY(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
-                for (int i = 0; i < 2; ++i) {
-                    CREATE_TRY(hipEventCreateWithFlags(&h->ev_sub[i], hipEventDisableTiming));
-                    CREATE_TRY(hipEventCreateWithFlags(&h->ev_cmb[i], hipEventDisableTiming));
-                }
-            }
             CREATE_TRY(hipMalloc(&h->d_xhat_scratch, size_t(h->n_cu) * 16384 * sizeof(float2)));
         }
         if (!h->fast && !h->lng) {
@@ -796,13 +849,22 @@ void thr_destroy(thr_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
-    if (h->aux_stream) {
-        (void)hipStreamSynchronize(h->aux_stream);
-        (void)hipStreamDestroy(h->aux_stream);
-    }
-    for (int i = 0; i < 2; ++i) {
-        if (h->ev_sub[i]) (void)hipEventDestroy(h->ev_sub[i]);
-        if (h->ev_cmb[i]) (void)hipEventDestroy(h->ev_cmb[i]);
+    if (h->hp.ready || h->hp.copy) {
+        auto& p = h->hp;
+        if (p.copy) {
+            (void)hipStreamSynchronize(p.copy);
+            (void)hipStreamDestroy(p.copy);
+        }
+        if (p.h_bad) (void)hipHostFree(p.h_bad);
+        for (int b = 0; b < 2; ++b) {
+            if (p.ev_h2d[b]) (void)hipEventDestroy(p.ev_h2d[b]);
+            if (p.ev_done[b]) (void)hipEventDestroy(p.ev_done[b]);
+            if (p.h_rec[b]) (void)hipHostFree(p.h_rec[b]);
+            for (void* q : {p.d_in[b], static_cast<void*>(p.d_idx[b]), static_cast<void*>(p.d_rec[b]),
+                            static_cast<void*>(p.d_text[b]), static_cast<void*>(p.d_off[b]),
+                            static_cast<void*>(p.d_bad[b])})
+                if (q) (void)hipFree(q);
+        }
     }
     for (auto& v : h->pending)
         for (auto& e : v) h->free_events.push_back(e);
@@ -810,7 +872,7 @@ void thr_destroy(thr_handle* h) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
     }
-    void* bufs[] = {h->d_tables, h->d_twn, h->d_tspec, h->d_stats, h->d_shifts, h->d_corr_stats, h->d_text, h->d_payload_off, h->d_bad, h->d_gen_scratch, h->d_tspec_nat, h->d_bank, h->d_gtw, h->d_win_pow, h->d_partial, h->d_dsub, h->d_dsub2, h->d_work_list,
+    void* bufs[] = {h->d_tables, h->d_twn, h->d_tspec, h->d_stats, h->d_shifts, h->d_corr_stats, h->d_gen_scratch, h->d_tspec_nat, h->d_bank, h->d_gtw, h->d_win_pow, h->d_partial, h->d_dsub, h->d_work_list,
                     h->d_work_count, h->d_xhat_scratch, h->d_ncompact, h->d_compact_tiles, h->d_in, h->d_idx, h->d_rec};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -886,26 +948,31 @@ int thr_detect_stream(thr_handle* h, const uint8_t* stream, size_t n_bytes, int6
         return fail(THR_ERR_ARG, "stream holds %zu blocks, records array only %zu", n_blocks,
                     out_capacity);
     HIP_TRY(hipSetDevice(h->device));
-    rc = ensure_staging(h, THR_IN_U8);
+    rc = ensure_pipe(h);
     if (rc != THR_OK) return rc;
+    auto& p = h->hp;
     const size_t nt = size_t(h->cfg.n_templates);
-    std::vector<long long> idx;
-    for (size_t done = 0; done < n_blocks;) {
+    int chunk = 0;
+    for (size_t done = 0; done < n_blocks && rc == THR_OK; ++chunk) {
+        const int b = chunk & 1;
         const size_t nb = std::min(n_blocks - done, size_t(h->cfg.max_batch));
-        HIP_TRY(hipMemcpyAsync(h->d_in, stream + done * stride, (nb - 1) * stride + blk,
-                               hipMemcpyHostToDevice, h->stream));
-        idx.resize(nb);
-        for (size_t i = 0; i < nb; ++i) idx[i] = (long long)(first_block_idx + int64_t(done + i));
-        HIP_TRY(hipMemcpyAsync(h->d_idx, idx.data(), nb * sizeof(long long), hipMemcpyHostToDevice,
-                               h->stream));
-        rc = run_batch(h, h->d_in, THR_IN_U8, h->d_idx, int(nb), h->d_rec, nullptr, nullptr, nullptr, 0,
-                       false, stride);
-        if (rc != THR_OK) return rc;
-        HIP_TRY(hipMemcpyAsync(out + done * nt, h->d_rec, nb * nt * sizeof(thr_record),
-                               hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));  // also keeps idx alive long enough
+        const size_t bytes = (nb - 1) * stride + blk;
+        if ((rc = pipe_drain(h, b)) != THR_OK) break;        // buffer b's previous chunk is handed out
+        if ((rc = pipe_grow(&p.d_in[b], &p.in_bytes[b], bytes)) != THR_OK) break;
+        HIP_TRY(hipMemcpyAsync(p.d_in[b], stream + done * stride, bytes, hipMemcpyHostToDevice, p.copy));
+        p.idx_host[b].resize(nb);
+        for (size_t i = 0; i < nb; ++i) p.idx_host[b][i] = (long long)(first_block_idx + int64_t(done + i));
+        HIP_TRY(hipMemcpyAsync(p.d_idx[b], p.idx_host[b].data(), nb * sizeof(long long),
+                               hipMemcpyHostToDevice, p.copy));
+        if ((rc = pipe_inputs_enqueued(h, b)) != THR_OK) break;
+        rc = run_batch(h, p.d_in[b], THR_IN_U8, p.d_idx[b], int(nb), p.d_rec[b], nullptr, nullptr,
+                       nullptr, 0, false, stride);
+        if (rc != THR_OK) break;
+        rc = pipe_records_enqueued(h, b, out + done * nt, nb * nt, done, false);
         done += nb;
     }
+    rc = pipe_finish(h, rc);
+    if (rc != THR_OK) return rc;
     *n_blocks_out = n_blocks;
     return THR_OK;
 }
@@ -915,94 +982,91 @@ int thr_detect(thr_handle* h, const void* samples, int format, const int64_t* bl
     if (!h || !samples || !out) return fail(THR_ERR_ARG, "thr_detect: null argument");
     if (format != THR_IN_U8 && format != THR_IN_C64) return fail(THR_ERR_ARG, "bad format %d", format);
     HIP_TRY(hipSetDevice(h->device));
-    int rc = ensure_staging(h, format);
+    int rc = ensure_pipe(h);
     if (rc != THR_OK) return rc;
+    auto& p = h->hp;
     const size_t blk_bytes = size_t(h->cfg.block_len) * (format == THR_IN_U8 ? 2 : 8);
     const size_t nt = size_t(h->cfg.n_templates);
-    for (size_t done = 0; done < n_blocks;) {
+    // chunk i + 1 is copied (copy stream; the call blocks while the pageable source is staged)
+    // while the kernels of chunk i run; records return through pinned staging
+    int chunk = 0;
+    for (size_t done = 0; done < n_blocks && rc == THR_OK; ++chunk) {
+        const int b = chunk & 1;
         const size_t nb = std::min(n_blocks - done, size_t(h->cfg.max_batch));
-        HIP_TRY(hipMemcpyAsync(h->d_in, static_cast<const unsigned char*>(samples) + done * blk_bytes,
-                               nb * blk_bytes, hipMemcpyHostToDevice, h->stream));
-        if (block_idx) {
-            HIP_TRY(hipMemcpyAsync(h->d_idx, block_idx + done, nb * sizeof(long long),
-                                   hipMemcpyHostToDevice, h->stream));
-        } else {
-            std::vector<long long> idx(nb);
-            for (size_t i = 0; i < nb; ++i) idx[i] = (long long)(done + i);
-            HIP_TRY(hipMemcpyAsync(h->d_idx, idx.data(), nb * sizeof(long long), hipMemcpyHostToDevice,
-                                   h->stream));
-            HIP_TRY(hipStreamSynchronize(h->stream));  // idx goes out of scope
-        }
-        rc = run_batch(h, h->d_in, format, h->d_idx, int(nb), h->d_rec, nullptr, nullptr, nullptr, 0,
-                       false);
-        if (rc != THR_OK) return rc;
-        HIP_TRY(hipMemcpyAsync(out + done * nt, h->d_rec, nb * nt * sizeof(thr_record),
-                               hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        if ((rc = pipe_drain(h, b)) != THR_OK) break;
+        if ((rc = pipe_grow(&p.d_in[b], &p.in_bytes[b], nb * blk_bytes)) != THR_OK) break;
+        HIP_TRY(hipMemcpyAsync(p.d_in[b], static_cast<const unsigned char*>(samples) + done * blk_bytes,
+                               nb * blk_bytes, hipMemcpyHostToDevice, p.copy));
+        p.idx_host[b].resize(nb);
+        for (size_t i = 0; i < nb; ++i)
+            p.idx_host[b][i] = block_idx ? (long long)block_idx[done + i] : (long long)(done + i);
+        HIP_TRY(hipMemcpyAsync(p.d_idx[b], p.idx_host[b].data(), nb * sizeof(long long),
+                               hipMemcpyHostToDevice, p.copy));
+        if ((rc = pipe_inputs_enqueued(h, b)) != THR_OK) break;
+        rc = run_batch(h, p.d_in[b], format, p.d_idx[b], int(nb), p.d_rec[b], nullptr, nullptr, nullptr,
+                       0, false);
+        if (rc != THR_OK) break;
+        rc = pipe_records_enqueued(h, b, out + done * nt, nb * nt, done, false);
         done += nb;
     }
-    return THR_OK;
+    return pipe_finish(h, rc);
 }
 
 int thr_detect_card(thr_handle* h, const char* text, size_t text_len, const int64_t* payload_off,
                     const int64_t* block_idx, size_t n_blocks, thr_record* out) {
     if (!h || !text || !payload_off || !out) return fail(THR_ERR_ARG, "thr_detect_card: null argument");
     HIP_TRY(hipSetDevice(h->device));
-    int rc = ensure_staging(h, THR_IN_U8);
+    int rc = ensure_pipe(h);
     if (rc != THR_OK) return rc;
+    auto& p = h->hp;
     const size_t out_bytes = size_t(h->cfg.block_len) * 2;
     const size_t chars = ((out_bytes + 2) / 3) * 4;  // base64 payload length of one block
     const size_t nt = size_t(h->cfg.n_templates);
-    if (!h->d_payload_off)
-        HIP_TRY(hipMalloc(&h->d_payload_off, size_t(h->cfg.max_batch) * sizeof(long long)));
-    if (!h->d_bad) HIP_TRY(hipMalloc(&h->d_bad, sizeof(int)));
-    std::vector<long long> rel;
-    for (size_t done = 0; done < n_blocks;) {
+    int chunk = 0;
+    for (size_t done = 0; done < n_blocks && rc == THR_OK; ++chunk) {
+        const int b = chunk & 1;
         const size_t nb = std::min(n_blocks - done, size_t(h->cfg.max_batch));
         // contiguous span of text covering this chunk's payloads
         long long lo = payload_off[done], hi = payload_off[done];
         for (size_t i = 0; i < nb; ++i) {
             const long long o = payload_off[done + i];
-            if (o < 0 || size_t(o) + chars > text_len)
-                return fail(THR_ERR_ARG, "payload %zu (offset %lld, %zu chars) lies outside the text",
-                            done + i, o, chars);
+            if (o < 0 || size_t(o) + chars > text_len) {
+                rc = fail(THR_ERR_ARG, "payload %zu (offset %lld, %zu chars) lies outside the text",
+                          done + i, o, chars);
+                break;
+            }
             lo = std::min(lo, o);
             hi = std::max(hi, o);
         }
+        if (rc != THR_OK) break;
         const size_t span = size_t(hi - lo) + chars;
-        if (h->d_text_bytes < span) {
-            if (h->d_text) (void)hipFree(h->d_text);
-            h->d_text = nullptr;
-            h->d_text_bytes = 0;
-            HIP_TRY(hipMalloc(&h->d_text, span + (span >> 2)));
-            h->d_text_bytes = span + (span >> 2);
+        if ((rc = pipe_drain(h, b)) != THR_OK) break;
+        if ((rc = pipe_grow(reinterpret_cast<void**>(&p.d_text[b]), &p.text_bytes[b], span)) != THR_OK) break;
+        if ((rc = pipe_grow(&p.d_in[b], &p.in_bytes[b], nb * out_bytes)) != THR_OK) break;
+        if (!p.d_off[b]) HIP_TRY(hipMalloc(&p.d_off[b], size_t(h->cfg.max_batch) * sizeof(long long)));
+        if (!p.d_bad[b]) HIP_TRY(hipMalloc(&p.d_bad[b], sizeof(int)));
+        p.off_host[b].resize(nb);
+        p.idx_host[b].resize(nb);
+        for (size_t i = 0; i < nb; ++i) {
+            p.off_host[b][i] = payload_off[done + i] - lo;
+            p.idx_host[b][i] = block_idx ? (long long)block_idx[done + i] : (long long)(done + i);
         }
-        rel.resize(nb);
-        for (size_t i = 0; i < nb; ++i) rel[i] = payload_off[done + i] - lo;
-        HIP_TRY(hipMemcpyAsync(h->d_text, text + lo, span, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipMemcpyAsync(h->d_payload_off, rel.data(), nb * sizeof(long long),
-                               hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipMemsetAsync(h->d_bad, 0, sizeof(int), h->stream));
-        std::vector<long long> idx(nb);
-        for (size_t i = 0; i < nb; ++i) idx[i] = block_idx ? block_idx[done + i] : (long long)(done + i);
-        HIP_TRY(hipMemcpyAsync(h->d_idx, idx.data(), nb * sizeof(long long), hipMemcpyHostToDevice,
-                               h->stream));
-        HIP_TRY(thr::launch_b64_decode(h->d_text, h->d_payload_off, int(nb), int(out_bytes),
-                                       static_cast<unsigned char*>(h->d_in), h->d_bad, h->stream));
-        rc = run_batch(h, h->d_in, THR_IN_U8, h->d_idx, int(nb), h->d_rec, nullptr, nullptr, nullptr, 0,
-                       false);
-        if (rc != THR_OK) return rc;
-        int bad = 0;
-        HIP_TRY(hipMemcpyAsync(&bad, h->d_bad, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipMemcpyAsync(out + done * nt, h->d_rec, nb * nt * sizeof(thr_record),
-                               hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));  // also keeps rel/idx alive until copied
-        if (bad != 0)
-            return fail(THR_ERR_ARG, "%d .card payload(s) in blocks [%zu, %zu) are not valid base64",
-                        bad, done, done + nb);
+        HIP_TRY(hipMemcpyAsync(p.d_text[b], text + lo, span, hipMemcpyHostToDevice, p.copy));
+        HIP_TRY(hipMemcpyAsync(p.d_off[b], p.off_host[b].data(), nb * sizeof(long long),
+                               hipMemcpyHostToDevice, p.copy));
+        HIP_TRY(hipMemcpyAsync(p.d_idx[b], p.idx_host[b].data(), nb * sizeof(long long),
+                               hipMemcpyHostToDevice, p.copy));
+        HIP_TRY(hipMemsetAsync(p.d_bad[b], 0, sizeof(int), p.copy));
+        if ((rc = pipe_inputs_enqueued(h, b)) != THR_OK) break;
+        HIP_TRY(thr::launch_b64_decode(p.d_text[b], p.d_off[b], int(nb), int(out_bytes),
+                                       static_cast<unsigned char*>(p.d_in[b]), p.d_bad[b], h->stream));
+        rc = run_batch(h, p.d_in[b], THR_IN_U8, p.d_idx[b], int(nb), p.d_rec[b], nullptr, nullptr,
+                       nullptr, 0, false);
+        if (rc != THR_OK) break;
+        rc = pipe_records_enqueued(h, b, out + done * nt, nb * nt, done, true);
         done += nb;
     }
-    return THR_OK;
+    return pipe_finish(h, rc);
 }
 
 int thr_compact_device(thr_handle* h, const thr_record* d_in, size_t n_records, thr_record* d_out,

@@ -53,6 +53,21 @@ struct RawLong {
     // (it is linear): y = sum g[n0] (sc u + of (1+i)) = sc * sum g[n0] u + of (1+i) sum g[n0]
     // -- one packed fma per output instead of one fma per byte.
     cpx kadd = cpx{0.f, 0.f};
+    // u8, HELD: the block's R0 x 16 raw words stay in registers across the R0 sub-transforms
+    // of the block (fetch() once per block, 16 R0 VGPRs) instead of being re-read from L2 / the
+    // Infinity Cache for each of them.
+    static constexpr bool HELD = FMT == THR_IN_U8 && GEN;
+    unsigned w[HELD ? R0 : 1][HELD ? R1 : 1];
+    __device__ __forceinline__ void fetch() {
+        if constexpr (HELD) {
+#pragma unroll
+            for (int n0 = 0; n0 < R0; ++n0)
+#pragma unroll
+                for (int n1 = 0; n1 < R1; ++n1)
+                    w[n0][n1] = reinterpret_cast<const unsigned*>(blk)[size_t(n0) * (M / 2) +
+                                                                       size_t(n1) * (S1 / 2) + t];
+        }
+    }
     __device__ __forceinline__ void prepare() {
         if constexpr (FMT == THR_IN_U8) {
             constexpr float of = -127.4f / 128.0f;
@@ -68,13 +83,15 @@ struct RawLong {
     __device__ __forceinline__ void pair(int n0, int n1, cpx& a, cpx& b) const {
         const size_t idx = size_t(n0) * (M / 2) + size_t(n1) * (S1 / 2) + t;
         if constexpr (FMT == THR_IN_U8) {
-            const unsigned w = reinterpret_cast<const unsigned*>(blk)[idx];
-            a = cpx{float(w & 0xffu), float((w >> 8) & 0xffu)};      // raw bytes: see prepare()
-            b = cpx{float((w >> 16) & 0xffu), float(w >> 24)};
+            unsigned v;
+            if constexpr (HELD) v = w[n0][n1];
+            else v = reinterpret_cast<const unsigned*>(blk)[idx];
+            a = cpx{float(v & 0xffu), float((v >> 8) & 0xffu)};      // raw bytes: see prepare()
+            b = cpx{float((v >> 16) & 0xffu), float(v >> 24)};
         } else {
-            const f4 w = reinterpret_cast<const f4*>(blk)[idx];
-            a = cpx{w.x, w.y};
-            b = cpx{w.z, w.w};
+            const f4 v = reinterpret_cast<const f4*>(blk)[idx];
+            a = cpx{v.x, v.y};
+            b = cpx{v.z, v.w};
         }
     }
     __device__ __forceinline__ void get(int n1, cpx& a, cpx& b) const {
@@ -84,9 +101,9 @@ struct RawLong {
             cpx x, y;
             pair(n0, n1, x, y);
             if constexpr (GEN) {
-                const cpx w = cpx{g[n0].x, g[n0].y};
-                a += cmul(x, w);
-                b += cmul(y, w);
+                const cpx wg = cpx{g[n0].x, g[n0].y};
+                a += cmul(x, wg);
+                b += cmul(y, wg);
             } else {
                 const int q = (n0 * k0 * (4 / R0)) & 3;  // W_R0^(n0 k0) as quarter turns
                 a += rot_quarter_neg(x, q);
@@ -477,6 +494,8 @@ __global__ __launch_bounds__(NT) void k_correlate_sub(
     const size_t blk_bytes = cfg.blk_stride;
     cpx ph[2] = {cpx{1.f, 0.f}, cpx{1.f, 0.f}};
     int ph_block = -1;
+    RawLong<FMT, R0, true> raw{};
+    int raw_block = -1;
     // this launch owns work-list slots [slot_base, slot_base + slot_cap): the correlate stage
     // runs in chunks small enough for the d_k0 exchange to stay in the Infinity Cache
     // (`work_list` already points at slot_base)
@@ -514,8 +533,14 @@ __global__ __launch_bounds__(NT) void k_correlate_sub(
 #pragma unroll
         for (int e = 0; e < 2; ++e) p[e] = cmul(ph[e], twn[((2 * t + e) * k0) & nl_mask]);
         __syncthreads();
-        RawLong<FMT, R0, true> raw{static_cast<const unsigned char*>(samples) + size_t(b) * blk_bytes,
-                                   sc_g, t, k0};
+        raw.blk = static_cast<const unsigned char*>(samples) + size_t(b) * blk_bytes;
+        raw.g = sc_g;
+        raw.t = t;
+        raw.k0 = k0;
+        if (b != raw_block) {   // block-major work order: once per R0 sub-transforms
+            raw.fetch();
+            raw_block = b;
+        }
         raw.prepare();
         fwd_pass1<true>(lds, raw, sc_rp, p[0], p[1]);
         __syncthreads();
@@ -576,10 +601,11 @@ __device__ __forceinline__ void combine_at(const cpx* __restrict__ d, const cpx*
 }
 
 // HBM / Infinity-Cache-bound byte work (8 R0 M bytes read per (slot, template), ~30 flop per
-// 32 bytes).  512 threads and <= 80 VGPRs so that a workgroup fits on a CU NEXT TO a resident
-// k_correlate_sub workgroup (2 x 168 + 2 x 80 <= 512 registers per lane, 1 KiB of LDS): the
-// host runs the combination of chunk i on a second stream under the sub-transforms of chunk
-// i + 1.  Each thread takes two adjacent lags per step (one 16-byte load per sub-transform).
+// 32 bytes): 512 threads, two adjacent lags per thread and step (one 16-byte load per
+// sub-transform).  (Measured and dropped: running it on a second stream under the
+// sub-transforms of the next chunk -- 1.74 M blocks/s at N = 65536 against 1.71 M serial; with
+// the raw block held in registers by k_correlate_sub, 230 VGPRs, the two kernels no longer fit
+// on a CU together and serial order wins: 1.78 M against 1.18 M.)
 constexpr int CMB_T = 512;
 template <int R0>
 __global__ __launch_bounds__(CMB_T) void k_combine(DevCfg cfg, const cpx* __restrict__ twn,
