@@ -18,7 +18,7 @@ tmp.write(text); tmp.close()
 for name, mk in (("host decode (card_reader)", lambda: block_data.card_reader(io.StringIO(text.decode()))),
                  ("device decode (CardStream, pipe)", lambda: block_data.CardStream(io.BytesIO(text), n)),
                  ("device decode (CardStream, file)", lambda: block_data.CardStream(open(tmp.name, "rb"), n))):
-    det = Detector(st, mk(), batch_size=1024)
+    det = Detector(st, mk())
     t0 = time.perf_counter()
     cnt = sum(1 for d, r in det if d)
     dt = time.perf_counter() - t0

@@ -25,7 +25,7 @@ tmp.write(raw); tmp.close()
 for name, mk in (("host framing (block_reader)", lambda: block_data.block_reader(io.BytesIO(raw), n, h)),
                  ("device framing (RawStream, pipe)", lambda: block_data.RawStream(io.BytesIO(raw), n, h)),
                  ("device framing (RawStream, file)", lambda: block_data.RawStream(open(tmp.name, "rb"), n, h))):
-    det = Detector(st, mk(), batch_size=1024)
+    det = Detector(st, mk())
     t0 = time.perf_counter()
     cnt = sum(1 for d, r in det if d)
     dt = time.perf_counter() - t0

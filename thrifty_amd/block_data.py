@@ -199,6 +199,11 @@ class CardStream(object):
         self._end = 0   # one past the last valid byte
         self._eof = False
 
+    @property
+    def mapped(self):
+        """True if the input is a regular file read through mmap (no read buffer of our own)."""
+        return isinstance(self._buf, mmap.mmap)
+
     def shard(self, rank, world):
         """Restrict a mapped .card file to the rank-th of `world` contiguous byte ranges, cut at
         line starts (a line belongs to the range its first byte lies in).  Lines have one length,
@@ -337,6 +342,11 @@ class RawStream(object):
             _widen_pipe(stream)
         self._origin = self._off    # stream byte 0 (the caller may have consumed a header)
         self._stop_idx = None       # sharded mapped file: one past this rank's last block
+
+    @property
+    def mapped(self):
+        """True if the input is a regular file read through mmap."""
+        return self._map is not None
 
     def shard(self, rank, world):
         """Restrict a mapped raw file to this rank's contiguous block range.  The lead-in blocks

@@ -360,6 +360,22 @@ int ensure_pipe(thr_handle* h) {
     return THR_OK;
 }
 
+// chunk input: caller memory -> device on the copy stream.  The source is pageable, so the call
+// returns once the HIP runtime has staged it (~44 GB/s, whatever the chunk size); the DMA and the
+// kernels of the previous chunk run meanwhile.  (Measured and not adopted: our own pinned
+// staging filled by 3-6 host threads with one chunk of look-ahead -- 54 GB/s in some runs,
+// 29-33 GB/s in others on the same box, and never ahead below 48 MiB per chunk.)
+int pipe_h2d(thr_handle* h, void* d_dst, const void* src, size_t bytes) {
+    HIP_TRY(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, h->hp.copy));
+    return THR_OK;
+}
+
+// blocks per chunk of the host entry points: the staging buffers stay near 64 MiB each
+size_t pipe_chunk_blocks(const thr_handle* h, size_t bytes_per_block) {
+    const size_t cap = std::max<size_t>(1, (size_t(64) << 20) / std::max<size_t>(1, bytes_per_block));
+    return std::min(size_t(h->cfg.max_batch), cap);
+}
+
 int pipe_grow(void** buf, size_t* have, size_t need) {
     if (*have >= need) return THR_OK;
     if (*buf) (void)hipFree(*buf);
@@ -436,48 +452,63 @@ int ensure_staging(thr_handle* h, int format) {
     return THR_OK;
 }
 
-int run_batch_fast(thr_handle* h, const void* d_samples, int format,
-                   const long long* d_block_idx, int n_blocks, thr_record* d_out, float2* dump_fft,
-                   float2* dump_xhat, float2* dump_corr, int dump_template, bool carrier_only) {
-    const int grid = std::min(n_blocks, h->n_cu);
+int run_batch_fast(thr_handle* h, const void* d_samples_all, int format,
+                   const long long* d_block_idx_all, int n_blocks_all, thr_record* d_out_all,
+                   float2* dump_fft, float2* dump_xhat, float2* dump_corr, int dump_template,
+                   bool carrier_only) {
     h->prof = h->prof_every > 0 && (h->batch_no++ % h->prof_every) == 0;
     if (h->preshift_num) {
+        const int grid = std::min(n_blocks_all, h->n_cu);
         if (dump_fft || dump_xhat || dump_corr || carrier_only)
             return fail(THR_ERR_ARG, "stage dumps are not available in the preshift variant");
         {
             ProfScope p(h, 2);   // the fused kernel is accounted in k_correlate's slot
-            HIP_TRY(thr::launch_preshift_16k(format, d_samples, n_blocks, h->dev, h->d_tables,
-                                             h->d_bank, h->preshift_num, d_block_idx,
-                                             h->d_corr_stats, d_out, grid, h->stream));
+            HIP_TRY(thr::launch_preshift_16k(format, d_samples_all, n_blocks_all, h->dev, h->d_tables,
+                                             h->d_bank, h->preshift_num, d_block_idx_all,
+                                             h->d_corr_stats, d_out_all, grid, h->stream));
         }
         ProfScope p(h, 3);
-        HIP_TRY(thr::launch_finish(n_blocks, h->dev, h->d_corr_stats, d_out, h->d_work_count,
+        HIP_TRY(thr::launch_finish(n_blocks_all, h->dev, h->d_corr_stats, d_out_all, h->d_work_count,
                                    h->stream));
         return THR_OK;
     }
-    {
-        ProfScope p(h, 0);
-        HIP_TRY(thr::launch_carrier_16k(
-            format, d_samples, n_blocks, h->dev, h->d_tables, h->d_twn, h->d_stats, dump_fft, grid,
-            h->stream));
-    }
-    if (carrier_only) return THR_OK;
-    {
-        ProfScope p(h, 1);
-        HIP_TRY(thr::launch_fit(n_blocks, h->dev, h->d_stats, d_block_idx, h->d_shifts,
-                                h->d_work_list, h->d_work_count, d_out, h->d_corr_stats, h->stream));
-    }
-    {
-        ProfScope p(h, 2);
-        HIP_TRY(thr::launch_correlate_16k(
-            format, d_samples, h->dev, h->d_tables, h->d_twn, h->d_tspec, h->d_shifts, h->d_work_list,
-            h->d_work_count, h->d_corr_stats, d_out, h->d_xhat_scratch, dump_xhat, dump_corr,
-            dump_template, grid, h->stream));
-    }
-    {
-        ProfScope p(h, 3);
-        HIP_TRY(thr::launch_finish(n_blocks * h->cfg.n_templates, h->dev, h->d_corr_stats, d_out,
-                                   h->d_work_count, h->stream));
+    // (Measured and not adopted: internal chunks of 4096 / 8192 blocks, so that k_correlate's read
+    // of the samples finds them in the 256 MiB Infinity Cache after the carrier kernel -- 11.5 /
+    // 12.1 M blocks/s against 12.4 M for the whole batch (one grid ramp per extra launch), and
+    // FETCH_SIZE does not move: it counts L2-to-fabric requests, Infinity-Cache hits included.
+    // profiles/README.md.)
+    const int chunk = n_blocks_all;
+    const size_t T = size_t(h->cfg.n_templates);
+    for (int off = 0; off < n_blocks_all; off += chunk) {
+        const int n_blocks = std::min(chunk, n_blocks_all - off);
+        const void* d_samples =
+            static_cast<const unsigned char*>(d_samples_all) + size_t(off) * size_t(h->dev.blk_stride);
+        const long long* d_block_idx = d_block_idx_all ? d_block_idx_all + off : nullptr;
+        thr_record* d_out = d_out_all + size_t(off) * T;
+        const int grid = std::min(n_blocks, h->n_cu);
+        {
+            ProfScope p(h, 0);
+            HIP_TRY(thr::launch_carrier_16k(format, d_samples, n_blocks, h->dev, h->d_tables, h->d_twn,
+                                            h->d_stats, dump_fft, grid, h->stream));
+        }
+        if (carrier_only) continue;
+        {
+            ProfScope p(h, 1);
+            HIP_TRY(thr::launch_fit(n_blocks, h->dev, h->d_stats, d_block_idx, h->d_shifts,
+                                    h->d_work_list, h->d_work_count, d_out, h->d_corr_stats, h->stream));
+        }
+        {
+            ProfScope p(h, 2);
+            HIP_TRY(thr::launch_correlate_16k(
+                format, d_samples, h->dev, h->d_tables, h->d_twn, h->d_tspec, h->d_shifts, h->d_work_list,
+                h->d_work_count, h->d_corr_stats, d_out, h->d_xhat_scratch, dump_xhat, dump_corr,
+                dump_template, grid, h->stream));
+        }
+        {
+            ProfScope p(h, 3);
+            HIP_TRY(thr::launch_finish(n_blocks * h->cfg.n_templates, h->dev, h->d_corr_stats, d_out,
+                                       h->d_work_count, h->stream));
+        }
     }
     return THR_OK;
 }
@@ -955,11 +986,11 @@ int thr_detect_stream(thr_handle* h, const uint8_t* stream, size_t n_bytes, int6
     int chunk = 0;
     for (size_t done = 0; done < n_blocks && rc == THR_OK; ++chunk) {
         const int b = chunk & 1;
-        const size_t nb = std::min(n_blocks - done, size_t(h->cfg.max_batch));
+        const size_t nb = std::min(n_blocks - done, pipe_chunk_blocks(h, stride));
         const size_t bytes = (nb - 1) * stride + blk;
         if ((rc = pipe_drain(h, b)) != THR_OK) break;        // buffer b's previous chunk is handed out
         if ((rc = pipe_grow(&p.d_in[b], &p.in_bytes[b], bytes)) != THR_OK) break;
-        HIP_TRY(hipMemcpyAsync(p.d_in[b], stream + done * stride, bytes, hipMemcpyHostToDevice, p.copy));
+        if ((rc = pipe_h2d(h, p.d_in[b], stream + done * stride, bytes)) != THR_OK) break;
         p.idx_host[b].resize(nb);
         for (size_t i = 0; i < nb; ++i) p.idx_host[b][i] = (long long)(first_block_idx + int64_t(done + i));
         HIP_TRY(hipMemcpyAsync(p.d_idx[b], p.idx_host[b].data(), nb * sizeof(long long),
@@ -992,11 +1023,12 @@ int thr_detect(thr_handle* h, const void* samples, int format, const int64_t* bl
     int chunk = 0;
     for (size_t done = 0; done < n_blocks && rc == THR_OK; ++chunk) {
         const int b = chunk & 1;
-        const size_t nb = std::min(n_blocks - done, size_t(h->cfg.max_batch));
+        const size_t nb = std::min(n_blocks - done, pipe_chunk_blocks(h, blk_bytes));
         if ((rc = pipe_drain(h, b)) != THR_OK) break;
         if ((rc = pipe_grow(&p.d_in[b], &p.in_bytes[b], nb * blk_bytes)) != THR_OK) break;
-        HIP_TRY(hipMemcpyAsync(p.d_in[b], static_cast<const unsigned char*>(samples) + done * blk_bytes,
-                               nb * blk_bytes, hipMemcpyHostToDevice, p.copy));
+        if ((rc = pipe_h2d(h, p.d_in[b], static_cast<const unsigned char*>(samples) + done * blk_bytes,
+                           nb * blk_bytes)) != THR_OK)
+            break;
         p.idx_host[b].resize(nb);
         for (size_t i = 0; i < nb; ++i)
             p.idx_host[b][i] = block_idx ? (long long)block_idx[done + i] : (long long)(done + i);
@@ -1025,20 +1057,24 @@ int thr_detect_card(thr_handle* h, const char* text, size_t text_len, const int6
     int chunk = 0;
     for (size_t done = 0; done < n_blocks && rc == THR_OK; ++chunk) {
         const int b = chunk & 1;
-        const size_t nb = std::min(n_blocks - done, size_t(h->cfg.max_batch));
-        // contiguous span of text covering this chunk's payloads
-        long long lo = payload_off[done], hi = payload_off[done];
-        for (size_t i = 0; i < nb; ++i) {
-            const long long o = payload_off[done + i];
-            if (o < 0 || size_t(o) + chars > text_len) {
-                rc = fail(THR_ERR_ARG, "payload %zu (offset %lld, %zu chars) lies outside the text",
-                          done + i, o, chars);
-                break;
+        const size_t nb = std::min(n_blocks - done, pipe_chunk_blocks(h, chars + 32));
+        // contiguous span of text covering a chunk's payloads: [lo, hi + chars)
+        auto span_of = [&](size_t first, size_t count, long long* plo, long long* phi) {
+            long long lo_ = payload_off[first], hi_ = payload_off[first];
+            for (size_t i = 0; i < count; ++i) {
+                const long long o = payload_off[first + i];
+                if (o < 0 || size_t(o) + chars > text_len)
+                    return fail(THR_ERR_ARG, "payload %zu (offset %lld, %zu chars) lies outside the text",
+                                first + i, o, chars);
+                lo_ = std::min(lo_, o);
+                hi_ = std::max(hi_, o);
             }
-            lo = std::min(lo, o);
-            hi = std::max(hi, o);
-        }
-        if (rc != THR_OK) break;
+            *plo = lo_;
+            *phi = hi_;
+            return THR_OK;
+        };
+        long long lo = 0, hi = 0;
+        if ((rc = span_of(done, nb, &lo, &hi)) != THR_OK) break;
         const size_t span = size_t(hi - lo) + chars;
         if ((rc = pipe_drain(h, b)) != THR_OK) break;
         if ((rc = pipe_grow(reinterpret_cast<void**>(&p.d_text[b]), &p.text_bytes[b], span)) != THR_OK) break;
@@ -1051,7 +1087,7 @@ int thr_detect_card(thr_handle* h, const char* text, size_t text_len, const int6
             p.off_host[b][i] = payload_off[done + i] - lo;
             p.idx_host[b][i] = block_idx ? (long long)block_idx[done + i] : (long long)(done + i);
         }
-        HIP_TRY(hipMemcpyAsync(p.d_text[b], text + lo, span, hipMemcpyHostToDevice, p.copy));
+        if ((rc = pipe_h2d(h, p.d_text[b], text + lo, span)) != THR_OK) break;
         HIP_TRY(hipMemcpyAsync(p.d_off[b], p.off_host[b].data(), nb * sizeof(long long),
                                hipMemcpyHostToDevice, p.copy));
         HIP_TRY(hipMemcpyAsync(p.d_idx[b], p.idx_host[b].data(), nb * sizeof(long long),

@@ -29,6 +29,7 @@ DetectorSettings = namedtuple("DetectorSettings", [
 
 
 _SLOW_SOURCE_S = 0.002   # inter-arrival time above which Detector stops filling a batch
+_CHUNKS_PER_CALL = 8      # engine batches a batch reader hands to one thr_detect_card / _stream call
 
 
 def unique_window(block_len, history_len, template_len):
@@ -59,8 +60,10 @@ class Detector(object):
     _fit_reach = 3            # the carrier interpolator reads fft_mag[peak + 3] (carrier_sync.py:187)
     _offset_type = float      # CarrierSyncInfo.offset as the reference types it
 
-    def __init__(self, settings, blocks=None, rxid=-1, yield_data=False, batch_size=1024,
+    def __init__(self, settings, blocks=None, rxid=-1, yield_data=False, batch_size=None,
                  device_id=0, _preshift_num=0, _fastdet=False):
+        if batch_size is None:      # ~64 MiB of u8 samples per engine batch (the staging chunk size)
+            batch_size = max(64, min(65536, (64 << 20) // (2 * int(settings.block_len))))
         self.settings = settings
         # a CardStream is consumed in whole batches with the base64 payloads decoded on the GPU
         self._card = blocks if isinstance(blocks, CardStream) and not yield_data else None
@@ -194,15 +197,18 @@ class Detector(object):
     def _next_records(self):
         """Pull one batch from the block source and run it: -> (stamps, idxs, recs) or None
         when the source is exhausted."""
+        # a batch reader over a regular (mmap-ed) file hands over up to 8 engine batches per call:
+        # the C entry points then stage, copy and process them as a pipeline (chunk i + 1 is
+        # copied while chunk i is detected); pipes are read one engine batch at a time
         if self._card is not None:
-            batch = self._card.next_batch(self.batch_size)
+            batch = self._card.next_batch(self.batch_size * (_CHUNKS_PER_CALL if self._card.mapped else 1))
             if batch is None:
                 self._exhausted = True
                 return None
             stamps, idxs, text, offs = batch
             return stamps, idxs, self._engine.detect_card(text, offs, idxs)[:, 0]
         if self._raw is not None:
-            batch = self._raw.next_batch(self.batch_size)
+            batch = self._raw.next_batch(self.batch_size * (_CHUNKS_PER_CALL if self._raw.mapped else 1))
             if batch is None:
                 self._exhausted = True
                 return None

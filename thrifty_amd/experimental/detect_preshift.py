@@ -33,7 +33,7 @@ class PreshiftDetector(Detector):
     _offset_type = np.float32      # float32 magnitudes in -> float32 offset out, as in the reference
 
     def __init__(self, settings, blocks=None, rxid=-1, yield_data=False, num=NUM_TEMPLATES,
-                 interpolator=parabolic, corr_shift=False, batch_size=1024, device_id=0):
+                 interpolator=parabolic, corr_shift=False, batch_size=None, device_id=0):
         if interpolator is not parabolic and interpolator != "parabolic":
             raise NotImplementedError("only the parabolic carrier interpolator runs on the device")
         if yield_data:

@@ -60,7 +60,7 @@ class FastDetector(Detector):
     """Same constructor and iteration protocol as `Detector`; `settings.carrier_thresh` and
     `settings.corr_thresh` are (const, snr, 0) in the power domain."""
 
-    def __init__(self, settings, blocks=None, rxid=-1, yield_data=False, batch_size=1024,
+    def __init__(self, settings, blocks=None, rxid=-1, yield_data=False, batch_size=None,
                  device_id=0):
         if yield_data:
             raise NotImplementedError("yield_data is not available in the fastdet variant")
