@@ -266,7 +266,7 @@ def card_to_toad_leg(n_card):
     with tempfile.NamedTemporaryFile(suffix=".card") as tmp:     # a regular file, as `thrifty detect rx.card`
         tmp.write(text)
         tmp.flush()
-        warm = Detector(st, block_data.CardStream(io.BytesIO(text[:len(text) // n_card * 8]), n), rxid=0)
+        warm = Detector(st, block_data.CardStream(io.BytesIO(b"\n".join(text.split(b"\n", 8)[:8]) + b"\n"), n), rxid=0)
         list(warm.iter_toad_lines())                             # library / device warm-up, not timed
         with open(tmp.name, "rb") as f:
             det = Detector(st, block_data.CardStream(f, n), rxid=0)
