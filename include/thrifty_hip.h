@@ -25,9 +25,10 @@ extern "C" {
 
 /* 2: + thr_create_preshift / thr_create_fastdet, thr_detect_stream[_device], thr_detect_card,
  *    thr_identify (additions only: every version-1 entry point is unchanged) */
-/* 3: THR_N_KERNEL_SLOTS 4 -> 5 (the arrays of thr_profile_read grow; slot 4 = the long-block
- *    combination kernel); everything else unchanged */
-#define THR_ABI_VERSION 3
+/* (3: THR_N_KERNEL_SLOTS 4 -> 5 (the arrays of thr_profile_read grow; slot 4 = the long-block
+ *    combination kernel); everything else unchanged) */
+/* 4: + thr_frame_card (addition only) */
+#define THR_ABI_VERSION 4
 
 /* status codes */
 #define THR_OK 0
@@ -158,6 +159,20 @@ int thr_detect(thr_handle* h, const void* samples, int format, const int64_t* bl
  * fastcard/lib/base64.c), then processed exactly like thr_detect().  Host pointers,
  * synchronous.  Invalid base64 -> THR_ERR_ARG.
  */
+/*
+ * Host-side framing for thr_detect_card(): find the records of a .card text.  Skips what the
+ * reference's card_reader skips (block_data.py:101-131: '#' comments, blank lines, fastcard's
+ * banner lines "Using Volk machine:" / "linux;"); every other line must be
+ * "<timestamp> <block_idx> <payload>" with a payload of exactly 4*ceil(2*block_len/3)
+ * characters.  Frames at most `max_records` whole lines starting at `text`; a last line without
+ * a newline counts only if `at_eof`.  Outputs per record: timestamp (correctly rounded, like
+ * Python's float()), block index, payload offset relative to `text`; `*consumed` = bytes
+ * framed (the next call starts there).  No device involved.  Malformed line -> THR_ERR_ARG.
+ */
+int thr_frame_card(const char* text, size_t text_len, int block_len, int at_eof, size_t max_records,
+                   double* timestamps, int64_t* block_idx, int64_t* payload_off, size_t* n_records,
+                   size_t* consumed);
+
 int thr_detect_card(thr_handle* h, const char* text, size_t text_len, const int64_t* payload_off,
                     const int64_t* block_idx, size_t n_blocks, thr_record* out);
 

@@ -408,3 +408,48 @@ def test_toad_lines_equal_per_record_serialize():
             got = toads_data.toad_lines(recs, stamps, new_len, rxid=rxid, carrier_offset_type=otype)
             assert got == want
     assert toads_data.toad_lines(recs[:0], stamps[:0], new_len) == []
+
+
+def test_native_card_framing_equals_python_framing():
+    """thr_frame_card (C, host-only) and CardStream._next_batch_py frame the same records: comments,
+    banners, blank lines, CRLF, a last line without newline, refills in the middle of a line."""
+    import io
+    _lib_or_skip()
+    rng = np.random.default_rng(3)
+    n = 64
+    lines = []
+    for i in range(57):
+        raw = rng.integers(0, 256, 2 * n, dtype=np.uint8)
+        ln = block_data.card_line(1.5e9 + 0.001 * i + rng.random() * 1e-3, 1000 + 7 * i, raw)
+        if i % 9 == 4:
+            ln = ln[:-1] + "\r\n"
+        lines.append(ln)
+        if i % 11 == 2:
+            lines.append("# comment %d\n" % i)
+        if i % 13 == 5:
+            lines.append("\n")
+        if i == 0:
+            lines.append("Using Volk machine: avx2_64_mmx\n")
+            lines.append("linux; GNU C++ version 4.9\n")
+    for tail in ("\n", ""):
+        text = ("".join(lines)[:-1] + tail).encode()
+        for chunk in (1, 700, 1 << 20):
+            for batch in (1, 5, 1000):
+                def run(py):
+                    cs = block_data.CardStream(io.BytesIO(text), n, chunk_bytes=chunk)
+                    out = []
+                    while True:
+                        b = cs._next_batch_py(batch) if py else cs.next_batch(batch)
+                        if b is None:
+                            return out
+                        stamps, idxs, buf, offs = b
+                        for ts, ix, off in zip(stamps, idxs.tolist(), offs.tolist()):
+                            out.append((ts, ix, bytes(buf[off:off + cs.payload_chars])))
+                a, b = run(False), run(True)
+                assert len(a) == 57 and a == b, (tail, chunk, batch)
+    cs = block_data.CardStream(io.BytesIO(b"12.5 3 QUJD\n"), n)
+    with pytest.raises(ValueError):
+        cs.next_batch(4)
+    cs = block_data.CardStream(io.BytesIO(b"hello\n"), n)
+    with pytest.raises(ValueError):
+        cs.next_batch(4)

@@ -20,13 +20,13 @@ FLAG_CORR = 2
 FLAG_INDEX_ERROR = 4
 N_KERNEL_SLOTS = 5
 
-ABI_VERSION = 3     # THR_ABI_VERSION of include/thrifty_hip.h
+ABI_VERSION = 4     # THR_ABI_VERSION of include/thrifty_hip.h
 
 EXPORTS = [
     "thr_abi_version", "thr_last_error", "thr_create", "thr_destroy", "thr_detect",
     "thr_create_preshift", "thr_create_fastdet", "thr_detect_card", "thr_detect_stream", "thr_detect_stream_device", "thr_detect_device", "thr_sync", "thr_set_stream", "thr_compact_device",
     "thr_profile_enable", "thr_profile_read", "thr_kernel_name", "thr_debug_fft",
-    "thr_debug_stage", "thr_identify",
+    "thr_debug_stage", "thr_identify", "thr_frame_card",
 ]
 
 
@@ -112,6 +112,8 @@ def load_library():
     lib.thr_destroy.restype = None
     lib.thr_detect.argtypes = [vp, vp, C.c_int, vp, C.c_size_t, vp]
     lib.thr_detect_card.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_size_t, vp]
+    lib.thr_frame_card.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_size_t, vp, vp, vp,
+                                   C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     lib.thr_detect_device.argtypes = [vp, vp, C.c_int, vp, C.c_size_t, vp]
     lib.thr_detect_stream.argtypes = [vp, vp, C.c_size_t, C.c_int64, vp, C.c_size_t,
                                       C.POINTER(C.c_size_t)]
@@ -132,6 +134,24 @@ def load_library():
 def _check(lib, rc):
     if rc != 0:
         raise NativeError("libthriftyhip: %s (code %d)" % (lib.thr_last_error().decode(), rc))
+
+
+def frame_card(buf, start, stop, block_len, at_eof, max_records):
+    """thr_frame_card over buf[start:stop] (bytes-like: bytearray, mmap, ...) ->
+    (timestamps float64[n], block_idx int64[n], payload_off int64[n] relative to buf, next start)."""
+    lib = load_library()
+    arr = np.frombuffer(buf, dtype=np.uint8)
+    cap = int(min(max_records, (stop - start) // 16 + 1))
+    ts = np.empty(cap, dtype=np.float64)
+    idx = np.empty(cap, dtype=np.int64)
+    off = np.empty(cap, dtype=np.int64)
+    n, used = C.c_size_t(0), C.c_size_t(0)
+    _check(lib, lib.thr_frame_card(arr.ctypes.data + start, stop - start, int(block_len), int(bool(at_eof)),
+                                   cap, ts.ctypes.data, idx.ctypes.data, off.ctypes.data,
+                                   C.byref(n), C.byref(used)))
+    del arr
+    k = n.value
+    return ts[:k], idx[:k], off[:k] + start, start + used.value
 
 
 FREQ_RANGE_DTYPE = np.dtype([("rxid", "<i4"), ("txid", "<i4"), ("lo", "<f8"), ("hi", "<f8")])

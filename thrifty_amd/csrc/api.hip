@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <charconv>
 #include <string>
 #include <utility>
 #include <vector>
@@ -1042,6 +1043,78 @@ int thr_detect(thr_handle* h, const void* samples, int format, const int64_t* bl
         done += nb;
     }
     return pipe_finish(h, rc);
+}
+
+int thr_frame_card(const char* text, size_t text_len, int block_len, int at_eof, size_t max_records,
+                   double* timestamps, int64_t* block_idx, int64_t* payload_off, size_t* n_records,
+                   size_t* consumed) {
+    if (!text || !timestamps || !block_idx || !payload_off || !n_records || !consumed)
+        return fail(THR_ERR_ARG, "thr_frame_card: null argument");
+    if (block_len <= 0) return fail(THR_ERR_ARG, "thr_frame_card: bad block_len %d", block_len);
+    const size_t chars = ((size_t(block_len) * 2 + 2) / 3) * 4;
+    size_t pos = 0, n = 0;
+    *n_records = 0;
+    *consumed = 0;
+    while (n < max_records && pos < text_len) {
+        // a data line is `<ts> <idx> ` + exactly `chars` characters: its end follows from the two
+        // spaces of the short header -- no 43 KB newline scan
+        const char* line = text + pos;
+        const size_t left = text_len - pos;
+        size_t end;  // index of the line terminator (or text_len)
+        const char* sp1 = nullptr;
+        const char* sp2 = nullptr;
+        if (line[0] >= '0' && line[0] <= '9') {
+            sp1 = static_cast<const char*>(memchr(line, ' ', std::min<size_t>(left, 40)));
+            if (sp1) sp2 = static_cast<const char*>(memchr(sp1 + 1, ' ', std::min<size_t>(size_t(line + left - sp1 - 1), 32)));
+        }
+        if (sp2 && size_t(sp2 + 1 - line) + chars <= left) {
+            end = size_t(sp2 + 1 - line) + chars;
+            if (!(end == left || line[end] == '\n' || (line[end] == '\r' && end + 1 < left && line[end + 1] == '\n')))
+                sp2 = nullptr;   // not the fixed layout: take the general path
+        } else {
+            sp2 = nullptr;
+        }
+        if (!sp2) {
+            const char* nl = static_cast<const char*>(memchr(line, '\n', left));
+            if (!nl && !at_eof) break;                    // incomplete last line: wait for more text
+            end = nl ? size_t(nl - line) : left;
+            if (end > 0 && line[end - 1] == '\r') --end;
+            const size_t next = nl ? size_t(nl - line) + 1 : left;
+            if (end == 0 || line[0] == '#' || (end >= 19 && memcmp(line, "Using Volk machine:", 19) == 0) ||
+                (end >= 6 && memcmp(line, "linux;", 6) == 0)) {
+                pos += next;
+                continue;
+            }
+            sp1 = static_cast<const char*>(memchr(line, ' ', end));
+            sp2 = sp1 ? static_cast<const char*>(memchr(sp1 + 1, ' ', size_t(line + end - sp1 - 1))) : nullptr;
+            if (!sp1 || !sp2)
+                return fail(THR_ERR_ARG, "malformed .card line at byte %zu: %.60s", pos, std::string(line, std::min<size_t>(end, 60)).c_str());
+            if (size_t(line + end - (sp2 + 1)) != chars)
+                return fail(THR_ERR_ARG, "block %.*s: payload of %zu base64 characters, expected %zu (block_len %d)",
+                            int(sp2 - sp1 - 1), sp1 + 1, size_t(line + end - (sp2 + 1)), chars, block_len);
+        } else if (end == left && !at_eof) {
+            break;   // the payload is complete but its newline has not arrived: wait (the next read brings it)
+        }
+        double ts = 0;
+        long long idx = 0;
+        const auto r1 = std::from_chars(line, sp1, ts);
+        const auto r2 = std::from_chars(sp1 + 1, sp2, idx);
+        if (r1.ec != std::errc() || r1.ptr != sp1 || r2.ec != std::errc() || r2.ptr != sp2)
+            return fail(THR_ERR_ARG, "malformed .card header at byte %zu: %.40s", pos,
+                        std::string(line, size_t(sp2 - line)).c_str());
+        timestamps[n] = ts;
+        block_idx[n] = idx;
+        payload_off[n] = (long long)(pos + size_t(sp2 + 1 - line));
+        ++n;
+        // step over the terminator
+        size_t adv = size_t(sp2 + 1 - line) + chars;
+        if (adv < left && line[adv] == '\r') ++adv;
+        if (adv < left && line[adv] == '\n') ++adv;
+        pos += adv;
+    }
+    *n_records = n;
+    *consumed = pos;
+    return THR_OK;
 }
 
 int thr_detect_card(thr_handle* h, const char* text, size_t text_len, const int64_t* payload_off,
