@@ -94,3 +94,38 @@ def test_thrifty_detect_gpus_cli_writes_the_single_process_toad(golden, tmp_path
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert (tmp_path / "many.toad").read_text() == (tmp_path / "one.toad").read_text()
     assert_toad_close((tmp_path / "one.toad").read_text().strip().split("\n"), g["toad"])
+
+
+def test_thrifty_detect_raw_gpus_cli_equals_single_process(tmp_path):
+    """`--raw --gpus 1` under torchrun (block-range sharding of a raw u8 stream, lead-in blocks on
+    rank 0) writes the same .toad as the single-process CLI, and detects the planted bursts."""
+    from thrifty_amd import synth
+    from thrifty_amd.detect import Detector, detector_cli
+    n, h = 16384, 4096
+    new = n - h
+    tpl = synth.gold_template(10, 2).astype(np.float64)
+    np.save(tmp_path / "template.npy", tpl)
+    (tmp_path / "detector.cfg").write_text(
+        "rxid: 2\nsample_rate: 2.4M\nblock_size: 16384\nblock_history: 4096\n"
+        "carrier_window: 7 - 110\ncarrier_threshold: 15 * snr\ncorr_threshold: 15*snr\n"
+        "template: %s\n" % (tmp_path / "template.npy"))
+    rng = np.random.default_rng(12)
+    nblk = 40
+    x = (rng.normal(0, 0.02, nblk * new) + 1j * rng.normal(0, 0.02, nblk * new)).astype(np.complex64)
+    ook = 0.3 * (tpl + 1) / 2
+    planted = 0
+    for b in range(1, nblk - 1, 2):                    # one burst well inside every other block
+        pos = b * new + int(rng.integers(2000, new - 2000))
+        f = rng.uniform(20, 90)
+        ar = np.arange(len(tpl))
+        x[pos:pos + len(tpl)] += (ook * np.exp(2j * np.pi * f * (ar + pos) / n)).astype(np.complex64)
+        planted += 1
+    synth.quantise_iq(x).tofile(tmp_path / "rx.bin")
+    common = [str(tmp_path / "rx.bin"), "--raw", "--quiet", "-c", str(tmp_path / "detector.cfg")]
+    detector_cli(Detector, argv=common + ["-o", str(tmp_path / "one.toad")])
+    _torchrun(1, ["-m", "thrifty_amd.detect"], ["--gpus", "1"] + common + ["-o", str(tmp_path / "rank.toad")])
+    def fields(path):       # (a raw stream is stamped with wall-clock time: drop that column)
+        return [ln.split()[:1] + ln.split()[2:] for ln in path.read_text().strip().split("\n") if ln]
+    one = fields(tmp_path / "one.toad")
+    assert fields(tmp_path / "rank.toad") == one
+    assert len(one) >= planted - 2 and all(f[0] == "2" for f in one)
