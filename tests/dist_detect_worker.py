@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--blocks", type=int, default=203)
     ap.add_argument("--seed", type=int, default=77)
     ap.add_argument("--out", required=True)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: every rank uses GPU 0 and the records travel as CPU tensors -- the "
+                         "sharding / ordering logic of world sizes a 1-GPU box cannot give to RCCL")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -37,10 +40,15 @@ def main():
 
     rank, world, local = parallel.torchrun_env()
     assert world is not None, "start me with torch.distributed.run"
+    if args.backend == "gloo":
+        local = 0
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    dist.init_process_group("nccl", device_id=dev)
-    assert dist.get_backend() == "nccl" and dist.get_world_size() == world
+    if args.backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group("gloo")
+    assert dist.get_backend() == args.backend and dist.get_world_size() == world
     tpl, blocks = make_blocks(args.blocks, args.seed)
     lo, hi = parallel.shard_range(args.blocks, rank, world)
     n = hi - lo
@@ -53,7 +61,10 @@ def main():
     if n:
         eng.detect_device(data.data_ptr(), F.THR_IN_U8, n, rec.data_ptr(), idx.data_ptr())
     n_kept = eng.compact_device(rec.data_ptr(), n, kept.data_ptr())
-    gathered = parallel.gather_records(kept[:n_kept], world, rank, dev, force=True)
+    if args.backend == "nccl":
+        gathered = parallel.gather_records(kept[:n_kept], world, rank, dev, force=True)
+    else:
+        gathered = parallel.gather_records(kept[:n_kept].cpu(), world, rank, torch.device("cpu"), force=True)
     torch.cuda.synchronize()
     if rank == 0:
         np.save(args.out, gathered.cpu().numpy())

@@ -58,6 +58,25 @@ def test_shard_detect_compact_gather_equals_single_process(tmp_path, k):
     assert np.all(np.diff(got["block_idx"]) > 0)
 
 
+@pytest.mark.parametrize("k", [2, 5, 8])
+def test_world_sizes_beyond_the_box_share_gpu0_over_gloo(tmp_path, k):
+    """K ranks that all run their shard on GPU 0 and exchange the records over gloo: everything
+    of the K-way path except the RCCL transport (uneven shards, empty-ish shards, rank order)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dist_detect_worker as w
+    from thrifty_amd import _native as F
+    n_blocks, seed = 37, 78
+    out = str(tmp_path / "gathered.npy")
+    _torchrun(k, [os.path.join(ROOT, "tests", "dist_detect_worker.py")],
+              ["--blocks", str(n_blocks), "--seed", str(seed), "--out", out, "--backend", "gloo"])
+    got = np.load(out).reshape(-1).view(F.RECORD_DTYPE)
+    tpl, blocks = w.make_blocks(n_blocks, seed)
+    rec = F.Engine(16384, 4096, tpl, (0, 15, 0), (7, 110), (0, 15, 0), max_batch=n_blocks).detect(
+        blocks, np.arange(n_blocks))[:, 0]
+    want = rec[(rec["flags"] & F.FLAG_CORR) != 0]
+    assert len(want) > 10 and got.tobytes() == want.tobytes()
+
+
 def _write_case(tmp_path, g, raw=False):
     from thrifty_amd import block_data
     np.save(tmp_path / "template.npy", g["template"])
