@@ -366,6 +366,7 @@ def main():
     idx = torch.arange(first, first + total, dtype=torch.int64, device=dev)
     rec = torch.zeros((total * T, 64), dtype=torch.uint8, device=dev)
     kept = torch.zeros_like(rec)
+    torch.cuda.synchronize()     # fills done before the engines' own streams write records
 
     def step(i):
         s = (i % resident_steps) * B

@@ -212,7 +212,10 @@ int thr_detect_stream_device(thr_handle* h, const uint8_t* d_stream, const int64
 int thr_detect_device(thr_handle* h, const void* d_samples, int format,
                       const int64_t* d_block_idx, size_t n_blocks, thr_record* d_out);
 int thr_sync(thr_handle* h);
-/* Use an externally owned hipStream_t (e.g. torch's current stream); NULL restores the handle's own. */
+/* Use an externally owned hipStream_t (e.g. a torch side stream); NULL restores the handle's own
+ * (non-blocking) stream -- NOTE that torch's DEFAULT stream has the handle value 0, i.e. NULL:
+ * passing it selects the engine's own stream, which does not synchronise with the legacy
+ * default stream, so work queued there (fills, copies) must be complete before thr_detect_device. */
 int thr_set_stream(thr_handle* h, void* hip_stream);
 
 /*

@@ -16,6 +16,7 @@ def run(n, nblk, reps=8):
     dev = torch.device("cuda:0")
     data = torch.from_numpy(np.tile(seed, (nblk // 64, 1))).to(dev)
     out = torch.zeros(nblk * 64, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
     eng = F.Engine(n, h, tpl, (0, 15, 0), cwin, (0, 15, 0), max_batch=nblk)
     eng.detect_device(data.data_ptr(), F.THR_IN_U8, nblk, out.data_ptr()); eng.sync()
     eng.profile_enable(1); eng.profile_read()

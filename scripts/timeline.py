@@ -16,6 +16,7 @@ eng = F.Engine(n, h, tpl, (0, 15, 0), (7, 110), (0, 15, 0), max_batch=B)
 dev = torch.device("cuda:0")
 data = torch.from_numpy(np.tile(blocks, (B // 256, 1))).to(dev)
 out = torch.zeros(B * 64, dtype=torch.uint8, device=dev)
+torch.cuda.synchronize()
 for _ in range(3):
     eng.detect_device(data.data_ptr(), F.THR_IN_U8, B, out.data_ptr())
 eng.sync()

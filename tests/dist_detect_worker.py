@@ -58,6 +58,9 @@ def main():
     idx = torch.arange(lo, hi, dtype=torch.int64, device=dev)
     rec = torch.zeros((max(n, 1), 64), dtype=torch.uint8, device=dev)
     kept = torch.zeros_like(rec)
+    # (the engine runs on its own non-blocking stream: torch's fills on the null stream must have
+    # landed before it writes records into these buffers)
+    torch.cuda.synchronize()
     if n:
         eng.detect_device(data.data_ptr(), F.THR_IN_U8, n, rec.data_ptr(), idx.data_ptr())
     n_kept = eng.compact_device(rec.data_ptr(), n, kept.data_ptr())

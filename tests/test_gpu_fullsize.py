@@ -35,6 +35,7 @@ def workload():
 def run_all(torch, dev, eng, data, batch, idx, order=None):
     total = data.shape[0]
     rec = torch.zeros((total, 64), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()     # (zero fill on torch's stream before the engine's own stream writes)
     starts = list(range(0, total, batch))
     for s in (starts if order is None else [starts[i] for i in order]):
         nb = min(batch, total - s)
@@ -80,6 +81,7 @@ def test_full_size_properties(workload):
 
     # --- compaction bookkeeping (K7): count, order, checksum of the kept block indices
     kept = torch.zeros_like(rec_d)
+    torch.cuda.synchronize()
     n_kept = eng.compact_device(rec_d.data_ptr(), TOTAL, kept.data_ptr())
     assert n_kept == int(cor_flag.sum())
     kept = kept[:n_kept].cpu().numpy().view(F.RECORD_DTYPE).reshape(-1)

@@ -131,6 +131,7 @@ def test_device_resident_path_and_compaction(golden):
     idx = torch.from_numpy(g["block_idx"]).to(dev)
     out = torch.zeros(len(g["blocks"]) * 64, dtype=torch.uint8, device=dev)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()     # (torch's default stream handle is 0 == "the engine's own stream")
     eng.profile_enable(True)
     eng.detect_device(blocks.data_ptr(), F.THR_IN_U8, len(g["blocks"]), out.data_ptr(), idx.data_ptr())
     torch.cuda.synchronize()
@@ -139,6 +140,7 @@ def test_device_resident_path_and_compaction(golden):
     prof = eng.profile_read()
     assert all(cnt == 1 and ms > 0 for k, (ms, cnt) in prof.items() if k != "k_combine"), prof
     kept = torch.zeros_like(out)
+    torch.cuda.synchronize()
     n_kept = eng.compact_device(out.data_ptr(), len(g["blocks"]), kept.data_ptr())
     krec = kept.cpu().numpy().view(F.RECORD_DTYPE)[:n_kept]
     want = rec[(rec["flags"] & F.FLAG_CORR) != 0]

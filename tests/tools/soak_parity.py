@@ -45,6 +45,7 @@ def main():
     eng = F.Engine(N, H, tpl, (0, 15, 0), (7, 110), (0, 15, 0), max_batch=8192,
                    preshift_num=21 if variant == "preshift" else 0)
     rec = torch.zeros((total, 64), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
     for s in range(0, total, 8192):
         nb = min(8192, total - s)
         eng.detect_device(data[s:s + nb].data_ptr(), F.THR_IN_U8, nb, rec[s:].data_ptr())

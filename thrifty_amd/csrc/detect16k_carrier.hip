@@ -41,6 +41,8 @@ __global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples
     if (cfg.prio_mode == 2 && threadIdx.x < NT / 2) __builtin_amdgcn_s_setprio(1);
     const size_t blk_bytes = cfg.blk_stride;  // dense: N * sample size; raw streams: 2 (N - H)
     int parity = 0;
+    cpx tw0[R1], tw1[R1];   // block-invariant pass-1 twiddles of this thread's two columns
+    pass1_twiddles(lds, tw0, tw1);
 
     RawSamples<FMT> cur;
     if (int(blockIdx.x) < n_blocks)
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples
             nxt.load(static_cast<const unsigned char*>(samples) + size_t(b + gridDim.x) * blk_bytes,
                      opaque_tid());
         // (previous block's pass-3 LDS reads all precede its reduction barrier)
-        fwd_pass1<false>(lds, cur, nullptr, cpx{}, cpx{});
+        fwd_pass1_pre(lds, cur, tw0, tw1);
         cur = nxt;
         __syncthreads();
         THR_ABLATE_AT(1, continue);
@@ -190,6 +192,8 @@ __global__ __launch_bounds__(NT) void k_carrier_pruned(const void* __restrict__ 
     if (cfg.prio_mode == 2 && threadIdx.x < NT / 2) __builtin_amdgcn_s_setprio(1);
     const size_t blk_bytes = cfg.blk_stride;  // dense: N * sample size; raw streams: 2 (N - H)
     int parity = 0;
+    cpx tw0[R1], tw1[R1];   // block-invariant pass-1 twiddles (unshifted variant only)
+    if constexpr (!SHIFTED) pass1_twiddles(lds, tw0, tw1);
 
     RawSamples<FMT> cur;
     if (int(blockIdx.x) < n_blocks)
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(NT) void k_carrier_pruned(const void* __restrict__ 
             asm volatile("" : "+v"(p0), "+v"(p1));  // keep the loop body free of hoisted products
             fwd_pass1<true>(lds, cur, sc_rp, p0, p1, &sums[0]);
         } else {
-            fwd_pass1<false>(lds, cur, nullptr, cpx{}, cpx{}, &sums[0]);
+            fwd_pass1_pre(lds, cur, tw0, tw1, &sums[0]);
         }
         cur = nxt;
         __syncthreads();

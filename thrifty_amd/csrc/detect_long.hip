@@ -355,6 +355,8 @@ __global__ __launch_bounds__(NT) void k_carrier_dit(const void* __restrict__ sam
     const size_t blk_bytes = cfg.blk_stride;
     const int win_w = cfg.win_count + 6, win_base = cfg.win_lo - 3;
     int parity = 0;
+    cpx tw0[R1], tw1[R1];   // block-invariant pass-1 twiddles of this thread's two columns
+    pass1_twiddles(lds, tw0, tw1);
     for (int b = blockIdx.x; b < n_blocks; b += gridDim.x) {
       RawDecim<FMT, R0> raw;
       raw.fetch(static_cast<const unsigned char*>(samples) + size_t(b) * blk_bytes, opaque_tid());
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(NT) void k_carrier_dit(const void* __restrict__ sam
         raw.select(r);
         float sums[1];
         // (the previous item's pass-3 LDS reads precede its reduction barrier)
-        fwd_pass1<false>(lds, raw, nullptr, cpx{}, cpx{}, &sums[0]);
+        fwd_pass1_pre(lds, raw, tw0, tw1, &sums[0]);
         __syncthreads();
         fwd_pass2<8>(lds);
         __builtin_amdgcn_sched_barrier(0);

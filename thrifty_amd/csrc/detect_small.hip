@@ -86,11 +86,24 @@ struct RawSmall<THR_IN_C64, R1> {
 // ---------------------------------------------------------------- first forward pass
 // radix R1 over n1 for the thread's A adjacent columns -> rows g*R1 + k1 of the LDS image.
 // PH: x[n1] is pre-rotated by rpow[n1] and column m by p0 * e[m - m0] (the frequency shift).
+// `pre` (optional, PH == false): the block-invariant twiddles already in registers
+// (small_twiddles), [(k1 - 1) * A / 2 + i] = W_N^(k1 (m0 + 2i)), W_N^(k1 (m0 + 2i + 1)).
+template <int R1>
+__device__ __forceinline__ void small_twiddles(int tb, const cpx* __restrict__ gtw, f4* pre) {
+    constexpr int A = Geo<R1>::A, TROW = Geo<R1>::TROW;
+    const int m0 = tb * A;
+#pragma unroll
+    for (int k1 = 1; k1 < R1; ++k1)
+#pragma unroll
+        for (int i = 0; i < A / 2; ++i)
+            pre[(k1 - 1) * (A / 2) + i] = *reinterpret_cast<const f4*>(gtw + (k1 * TROW) * 1024 + m0 + 2 * i);
+}
+
 template <int R1, bool PH, class RAW>
 __device__ __forceinline__ void small_pass1(cpx* lds, const RAW& raw, int g, int tb,
                                             const float2* __restrict__ rpow, cpx p0,
                                             const cpx* __restrict__ e, const cpx* __restrict__ gtw,
-                                            float* energy) {
+                                            float* energy, const f4* pre = nullptr) {
     constexpr int A = Geo<R1>::A, TROW = Geo<R1>::TROW;
     const int m0 = tb * A;
     cpx* out = lds + (g * R1) * ROW + (m0 >> 5) * CHUNK + (m0 & 31);
@@ -133,7 +146,9 @@ __device__ __forceinline__ void small_pass1(cpx* lds, const RAW& raw, int g, int
                     y1 = cmul(y1, pb);
                 }
             } else {
-                const f4 ww = *reinterpret_cast<const f4*>(gtw + (k1 * TROW) * 1024 + m0 + 2 * i);
+                const f4 ww = pre != nullptr
+                                  ? pre[(k1 - 1) * (A / 2) + i]
+                                  : *reinterpret_cast<const f4*>(gtw + (k1 * TROW) * 1024 + m0 + 2 * i);
                 cpx w0 = cpx{ww.x, ww.y}, w1 = cpx{ww.z, ww.w};
                 if constexpr (PH) {
                     w0 = cmul(w0, pa);
@@ -250,6 +265,9 @@ __global__ __launch_bounds__(NT) void k_carrier_small(const void* __restrict__ s
     const size_t blk_bytes = cfg.blk_stride;
     const int n_groups = (n_blocks + GE::G - 1) / GE::G;
     int parity = 0;
+    // block-invariant pass-1 twiddles of this thread's columns: loaded once per kernel
+    f4 tw[R1 > 1 ? (R1 - 1) * (GE::A / 2) : 1];
+    if constexpr (R1 > 1) small_twiddles<R1>(opaque_tid() % GE::TB, gtw, tw);
     RawSmall<FMT, R1> cur;
     {
         const int t = opaque_tid();
@@ -268,7 +286,7 @@ __global__ __launch_bounds__(NT) void k_carrier_small(const void* __restrict__ s
             nxt.load(static_cast<const unsigned char*>(samples) + size_t(bn) * blk_bytes, tb);
         }
         // (the previous group's pass-3 LDS reads all precede its reduction barrier)
-        small_pass1<R1, false>(lds, cur, g, tb, nullptr, cpx{}, nullptr, gtw, nullptr);
+        small_pass1<R1, false>(lds, cur, g, tb, nullptr, cpx{}, nullptr, gtw, nullptr, R1 > 1 ? tw : nullptr);
         cur = nxt;
         __syncthreads();
         fwd_pass2(lds);

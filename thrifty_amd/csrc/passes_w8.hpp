@@ -143,6 +143,53 @@ __device__ __forceinline__ void fwd_pass1(cpx* lds, const RAW& raw,
     });
 }
 
+// Pass-1 twiddles W_N^(k1 m) of a thread's two columns m = 2t, 2t+1 (k1 = 1..15): they do not
+// depend on the block, so a persistent kernel WITHOUT a frequency shift forms them once (60
+// VGPRs) instead of two LDS reads and a complex product per output and block.
+__device__ __forceinline__ void pass1_twiddles(const cpx* lds, cpx (&w0)[R1], cpx (&w1)[R1]) {
+    const int t = opaque_tid();
+    const int n2 = t >> 4, mp = 2 * (t & 15);
+    const cpx* tA = lds + OFF_A;
+    const cpx* tB = lds + OFF_B;
+    w0[0] = w1[0] = cpx{1.f, 0.f};
+#pragma unroll
+    for (int k1 = 1; k1 < R1; ++k1) {
+        const cpx a = tA[k1 * 32 + n2];
+        const f4 bb = *reinterpret_cast<const f4*>(tB + k1 * 32 + mp);
+        w0[k1] = cmul(a, cpx{bb.x, bb.y});
+        w1[k1] = cmul(a, cpx{bb.z, bb.w});
+    }
+}
+
+// Pass 1 without a frequency shift, twiddles from registers (pass1_twiddles).
+template <class RAW>
+__device__ __forceinline__ void fwd_pass1_pre(cpx* lds, const RAW& raw, const cpx (&w0)[R1],
+                                              const cpx (&w1)[R1], float* energy = nullptr) {
+    const int t = opaque_tid();
+    cpx v0[R1], v1[R1];
+    float e = 0.f;
+#pragma unroll
+    for (int n1 = 0; n1 < R1; ++n1) {
+        raw.get(n1, v0[n1], v1[n1]);
+        if (energy != nullptr) e += cnorm(v0[n1]) + cnorm(v1[n1]);  // time-domain sum |x|^2
+    }
+    if (energy != nullptr) *energy = e;
+    dft_dif<R1, -1>(v0);
+    dft_dif<R1, -1>(v1);
+    const int n2 = t >> 4, mp = 2 * (t & 15);
+    f4* out = reinterpret_cast<f4*>(lds + n2 * CHUNK + mp);
+    static_for<R1>([&](auto K) {
+        constexpr int k1 = decltype(K)::value;
+        constexpr int src = brev(k1, R1);
+        cpx y0 = v0[src], y1 = v1[src];
+        if constexpr (k1 != 0) {
+            y0 = cmul(y0, w0[k1]);
+            y1 = cmul(y1, w1[k1]);
+        }
+        out[k1 * (ROW / 2)] = f4{y0.x, y0.y, y1.x, y1.y};
+    });
+}
+
 // Pass 2 (radix 32 over n2, in place) -- thread (k1 = t>>5, m' = t&31).
 // KEEP < 32: only outputs k2 < KEEP are written back (pruned FFT: bins k2 >= KEEP unused).
 template <int KEEP = R2>
