@@ -29,23 +29,31 @@ using namespace k16;
 // =========================================================================
 // K_B: shift + FFT#2 + matched filter + SoA
 // =========================================================================
-// Per-thread shift phasor for samples m = 2t, 2t+1: c0 * exp(2 pi i s m / N), from the
-// factored ShiftParams (integer part via the exact root table, fractional part via a
-// small-angle sincosf).
-__device__ __forceinline__ void shift_phasor(const ShiftParams* __restrict__ sp,
-                                             const cpx* __restrict__ twn, int t, cpx (&p)[2]) {
-    const int si = sp->si_mod;
-    const float sf = sp->sf_over_n;
-    const cpx c0 = cpx{sp->c0.x, sp->c0.y};
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int m = 2 * t + e;
+// Shift phasor c0 * exp(2 pi i s m / N) of a thread's samples m = 2t, 2t+1, t = 64 w + l:
+//     p(2t) = [c0 exp(2 pi i s 128 w / N)] * [exp(2 pi i s 2 l / N)],   p(2t + 1) = p(2t) * exp(2 pi i s / N)
+// -- 8 wave factors, 64 lane factors and the one-sample step: 73 exactly formed numbers per
+// block (integer part of s through the root table, fractional part through a small-angle
+// sincosf).  73 threads form one each for the NEXT block and park them in LDS; every thread then
+// needs two LDS reads and two complex products instead of two sincosf + gathers of its own.
+constexpr int PH_OFF = 896;   // bytes into the scratch area: [896, 896 + 73 * 8)
+__device__ __forceinline__ void phasor_table(const ShiftParams* __restrict__ sp,
+                                             const cpx* __restrict__ twn, int t, cpx* sc_ph) {
+    if (t < 73) {
+        const int si = sp->si_mod;
+        const float sf = sp->sf_over_n;
+        const int m = t < 64 ? 2 * t : t < 72 ? 128 * (t - 64) : 1;
         const int q = (si * m) & (N - 1);
         const cpx wq = cconj(twn[q]);  // exp(+2 pi i q / N)
         float sn, cs;
         sincosf(6.283185307179586f * (sf * float(m)), &sn, &cs);
-        p[e] = cmul(cmul(wq, cpx{cs, sn}), c0);
+        cpx v = cmul(wq, cpx{cs, sn});
+        if (t >= 64 && t < 72) v = cmul(v, cpx{sp->c0.x, sp->c0.y});
+        sc_ph[t] = v;
     }
+}
+__device__ __forceinline__ void thread_phasor(const cpx* sc_ph, int t, cpx (&p)[2]) {
+    p[0] = cmul(sc_ph[64 + (t >> 6)], sc_ph[t & 63]);
+    p[1] = cmul(p[0], sc_ph[72]);
 }
 
 // MULTI: more than one template -- the shifted spectrum is parked in a
@@ -89,11 +97,13 @@ __global__ __launch_bounds__(NT) void k_correlate(
     int b_next = int(blockIdx.x) < n_work ? work_list[blockIdx.x] : 0;
     // work-list entry two iterations ahead, so the sample prefetch never waits on an index load
     int b_next2 = int(blockIdx.x + gridDim.x) < n_work ? work_list[blockIdx.x + gridDim.x] : 0;
+    cpx* sc_ph = reinterpret_cast<cpx*>(sc_red + PH_OFF);
     if (int(blockIdx.x) < n_work) {
         cur.load(static_cast<const unsigned char*>(samples) + size_t(b_next) * blk_bytes,
                  opaque_tid());
-        shift_phasor(shifts + b_next, twn, opaque_tid(), p);
+        phasor_table(shifts + b_next, twn, opaque_tid(), sc_ph);
     }
+    __syncthreads();
     // Work distribution.  Static: workgroup g takes entries g, g + G, g + 2G, ...  Dynamic
     // (cfg.dyn_sched): the first two entries are static (their prefetches are already in
     // flight), every later one comes from a global counter, fetched by thread 0 two
@@ -127,15 +137,10 @@ __global__ __launch_bounds__(NT) void k_correlate(
         // (the previous block's pass-C LDS reads all precede its reduction barrier)
         // (multi-template: 64 more live VGPRs for the spectrum -- the L2-table path would spill)
         const cpx* gtw = MULTI ? nullptr : static_cast<const cpx*>(cfg.gtw);
+        thread_phasor(sc_ph, t, p);   // (table of THIS block: written one iteration ago, two barriers back)
         fwd_pass1<true>(lds, cur, sp->rpow, p[0], p[1], nullptr, gtw);
         cur = nxt;
         THR_STAMP(2);
-        // The next block's phasor (root-table gather + sincosf, ~1 k cycles).  The older half of
-        // the waves reaches the barrier first and would idle there: it computes the phasor
-        // before the barrier; the younger half does it after -- which also staggers the two
-        // halves by about one LDS phase through the barrier-free passes that follow.
-        const bool early_half = cfg.stagger == 0 || threadIdx.x < NT / 2;
-        if (more && early_half) shift_phasor(shifts + b_next, twn, t, p);
         THR_STAMP(3);
         if (dyn && t == 0) *sc_dyn = wi_dyn;
         THR_LOOP_BARRIER();
@@ -144,7 +149,9 @@ __global__ __launch_bounds__(NT) void k_correlate(
         if (dyn && wi_nxt2 < n_work) b_next2 = work_list[wi_nxt2];
         wi = wi_nxt;
         wi_nxt = wi_nxt2;
-        if (more && !early_half) shift_phasor(shifts + b_next, twn, t, p);
+        // the next block's phasor table: every thread has read this block's table before the
+        // barrier above, and reads the new one only after the two barriers that follow
+        if (more) phasor_table(shifts + b_next, twn, t, sc_ph);
 #ifdef THR_DEV_ABLATE
         if (cfg.stagger >= 2 && threadIdx.x >= NT / 2) {
             if (cfg.stagger == 2) __builtin_amdgcn_s_sleep(16);
