@@ -9,7 +9,7 @@ from thrifty_amd import _native as F, synth
 
 
 def one(rng, k):
-    n = int(rng.choice([1024, 4096, 16384, 16384, 16384, 32768, 65536]))
+    n = int(rng.choice([1024, 2048, 4096, 8192, 16384, 16384, 16384, 32768, 65536, 512]))
     kind = rng.integers(0, 3)
     if kind == 0:
         bits = int(rng.integers(6, 11))
@@ -38,8 +38,17 @@ def one(rng, k):
     # carrier inside the window (signed bins)
     lo_b, hi_b = (min(window), max(window)) if window != (0, -1) else (-n // 4, n // 4)
     nb = 5
-    blocks, _ = synth.synth_blocks(rng, nb, n, tpl / max(1e-9, np.max(np.abs(tpl))), win, signal_frac=0.8,
-                                   carrier_bins=(lo_b + 0.3, hi_b - 0.3))
+    blocks, truth = synth.synth_blocks(rng, nb, n, tpl / max(1e-9, np.max(np.abs(tpl))), win, signal_frac=0.8,
+                                       carrier_bins=(lo_b + 0.3, hi_b - 0.3))
+    # a window that contains bin 0 makes the quantiser's DC spike the "carrier" of a noise-only
+    # block: a delta to which the Dirichlet-lobe fit is ill-conditioned (the reference's own
+    # offset moves under a one-ulp change of its inputs, and the noise-only correlation peak that
+    # follows it can flip): only bin and verdicts are compared on such blocks
+    try:
+        a, b = onp.window_to_indices(window[0], window[1], n)
+        dc_in_window = a == 0 or b >= n       # starts at bin 0 or wraps past it
+    except ValueError:
+        dc_in_window = False                  # (both sides refuse the window below)
     desc = "n=%d h=%d w=%d kind=%d window=%s cthr=%s xthr=%s" % (n, h, w, kind, window, cthr, xthr)
     try:
         eng = F.Engine(n, h, tpl, cthr, window, xthr, max_batch=int(rng.integers(1, 7)))
@@ -70,6 +79,8 @@ def one(rng, k):
             bad.append("blk %d: carrier verdict (energy %g noise %g thr %g)" % (
                 i, res.carrier.energy, res.carrier.noise, res.carrier.threshold)); continue
         if not res.carrier.detected:
+            continue
+        if dc_in_window and not truth["has_signal"][i]:
             continue
         if abs(r["carrier_offset"] - res.carrier.offset) > 1e-3:
             bad.append("blk %d: carrier offset %g vs %g" % (i, r["carrier_offset"], res.carrier.offset))
