@@ -176,6 +176,8 @@ __global__ __launch_bounds__(NT) void k_preshift(const void* __restrict__ sample
     __syncthreads();
     const size_t blk_bytes = cfg.blk_stride;
     int parity = 0;
+    cpx tw0[R1], tw1[R1];   // block-invariant pass-1 twiddles of this thread's two columns
+    pass1_twiddles(lds, tw0, tw1);
 
     RawSamples<FMT> cur;
     if (int(blockIdx.x) < n_blocks)
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(NT) void k_preshift(const void* __restrict__ sample
             nxt.load(static_cast<const unsigned char*>(samples) + size_t(b + gridDim.x) * blk_bytes,
                      opaque_tid());
         // (the previous block's last LDS reads -- pass 3 or pass C -- precede a reduction barrier)
-        fwd_pass1<false>(lds, cur, nullptr, cpx{}, cpx{});
+        fwd_pass1_pre(lds, cur, tw0, tw1);
         cur = nxt;
         __syncthreads();
         fwd_pass2(lds);
