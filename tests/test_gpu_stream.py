@@ -39,7 +39,10 @@ def framed(raw, n, h, first, count):
     (16384, 4096, 10, 1.0),     # fast path, BASELINE C2 geometry
     (16384, 4920, 10, 1.0),     # example-config history (stride not a multiple of 64 bytes)
     (32768, 4096, 11, 1.0),     # long path, R0 = 2
-    (4096, 1024, 9, 1.0),       # generic path
+    (4096, 1024, 9, 1.0),       # short-block LDS path (4 blocks per workgroup)
+    (8192, 2050, 10, 1.0),      # short blocks, block starts only 4-byte aligned (stride 12284 B)
+    (2048, 502, 8, 1.0),        # 8 blocks per workgroup, stride 3092 B
+    (1024, 254, 7, 1.0),        # 16 blocks per workgroup
 ])
 def test_stream_framing_equals_host_framing(n, h, bits, sps):
     tpl = synth.gold_template(bits, 2, sps)
