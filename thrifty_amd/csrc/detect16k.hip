@@ -58,7 +58,16 @@ __device__ __forceinline__ void thread_phasor(const cpx* sc_ph, int t, cpx (&p)[
 
 // MULTI: more than one template -- the shifted spectrum is parked in a
 // per-workgroup global scratch row (L2-resident) instead of 64 live VGPRs.
-template <int FMT, bool WANT_STD, bool MULTI, bool DUMP>
+// RLO / RHI (>= 0; -1, -1 = no assumption): the peak search visits the lags in 16 rows of 1024.
+// A variant with RLO, RHI is launched only when rows < RLO and rows > 15 - RHI lie entirely
+// outside the unique window [corr_lo, corr_hi) (with one lag of margin for the peak's
+// neighbours) and rows RLO + 1 .. 14 - RHI entirely inside it (launch_correlate_16k checks):
+// the outside rows then cost nothing -- not even their share of pass C, whose unused outputs
+// the compiler drops -- and the inside rows skip the window test.  Uniform run-time branches for
+// the same purpose cost more schedule than they save (profiles/README.md); the two geometries
+// instantiated are BASELINE's (history 4096, 1023-sample template: 1, 2) and the example
+// detector.cfg's (history 4920, 4914-sample template: 0, 4); any other runs the generic form.
+template <int FMT, bool WANT_STD, bool MULTI, bool DUMP, int RLO = -1, int RHI = -1>
 __global__ __launch_bounds__(NT) void k_correlate(
     const void* __restrict__ samples, DevCfg cfg, const cpx* __restrict__ tables,
     const cpx* __restrict__ twn, const f4* __restrict__ tspec,
@@ -280,8 +289,24 @@ __global__ __launch_bounds__(NT) void k_correlate(
             const unsigned win_w = unsigned(cfg.corr_hi - cfg.corr_lo);
             static_for<R1>([&](auto K) {
                 constexpr int n1 = decltype(K)::value;
+                constexpr bool GEOM = RLO >= 0 && RHI >= 0 && !WANT_STD;
+                if constexpr (GEOM && (n1 < RLO || n1 > 15 - RHI)) {   // row outside the window
+                    pw0[n1] = 0.f;
+                    pw1[n1] = 0.f;
+                    return;
+                }
                 pw0[n1] = cnorm(c0[brev(n1, R1)]);
                 pw1[n1] = cnorm(c1[brev(n1, R1)]);
+                if constexpr (GEOM && n1 > RLO && n1 < 15 - RHI) {     // row inside the window
+                    const int n = n1 * S1 + 2 * t;
+                    const bool t0 = pw0[n1] > bestp;
+                    bestp = t0 ? pw0[n1] : bestp;
+                    bestn = t0 ? n : bestn;
+                    const bool t1 = pw1[n1] > bestp;
+                    bestp = t1 ? pw1[n1] : bestp;
+                    bestn = t1 ? n + 1 : bestn;
+                    return;
+                }
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int n = n1 * S1 + 2 * t + e;
@@ -386,6 +411,37 @@ correlate_fn correlate_variant(int fmt, bool want_std, bool multi, bool dump) {
                             : pick_correlate2<THR_IN_C64>(want_std, multi, dump);
 }
 #endif
+
+// window geometries with a specialised peak search (one template, no stddev term, no dumps)
+struct RowGeom {
+    int lo, hi;
+};
+constexpr RowGeom kRowGeoms[] = {{1, 2}, {0, 4}};
+constexpr int kNumRowGeoms = int(sizeof(kRowGeoms) / sizeof(kRowGeoms[0]));
+
+// true if rows < lo and > 15 - hi lie outside [corr_lo - 1, corr_hi] and rows lo+1 .. 14-hi inside
+// [corr_lo, corr_hi)
+bool geom_applies(const RowGeom& g, const DevCfg& cfg) {
+    const bool low_out = g.lo == 0 || g.lo * S1 - 1 < cfg.corr_lo - 1;   // last lag of row lo - 1
+    const bool high_out = g.hi == 0 || (16 - g.hi) * S1 > cfg.corr_hi;   // first lag of row 16 - hi
+    const bool inside = (g.lo + 1) * S1 >= cfg.corr_lo && (15 - g.hi) * S1 <= cfg.corr_hi;
+    return low_out && high_out && inside;
+}
+
+correlate_fn geom_variant(int fmt, int g) {
+#ifdef THR_DEV_MINIMAL
+    (void)fmt;
+    (void)g;
+    return nullptr;
+#else
+    if (fmt == THR_IN_U8)
+        return g == 0 ? &k_correlate<THR_IN_U8, false, false, false, kRowGeoms[0].lo, kRowGeoms[0].hi>
+                      : &k_correlate<THR_IN_U8, false, false, false, kRowGeoms[1].lo, kRowGeoms[1].hi>;
+    return g == 0 ? &k_correlate<THR_IN_C64, false, false, false, kRowGeoms[0].lo, kRowGeoms[0].hi>
+                  : &k_correlate<THR_IN_C64, false, false, false, kRowGeoms[1].lo, kRowGeoms[1].hi>;
+#endif
+}
+static_assert(kNumRowGeoms == 2, "geom_variant() enumerates the geometries by hand");
 }  // namespace
 
 hipError_t prepare_16k_carrier();   // detect16k_carrier.hip
@@ -403,6 +459,14 @@ hipError_t prepare_16k() {
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
                     if (e != hipSuccess) return e;
                 }
+    for (int fmt = 0; fmt < 2; ++fmt)
+        for (int g = 0; g < kNumRowGeoms; ++g) {
+            correlate_fn fn = geom_variant(fmt, g);
+            if (fn == nullptr) continue;
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+            if (e != hipSuccess) return e;
+        }
     return hipSuccess;
 }
 
@@ -415,6 +479,12 @@ hipError_t launch_correlate_16k(int fmt, const void* samples, const DevCfg& cfg,
                                 hipStream_t stream) {
     const bool dump = dump_xhat != nullptr || dump_corr != nullptr;
     correlate_fn fn = correlate_variant(fmt, cfg.cor_want_std != 0, cfg.n_templates > 1, dump);
+    if (!dump && cfg.cor_want_std == 0 && cfg.n_templates == 1 && cfg.ablate == 0)
+        for (int g = 0; g < kNumRowGeoms; ++g)
+            if (geom_applies(kRowGeoms[g], cfg) && geom_variant(fmt, g) != nullptr) {
+                fn = geom_variant(fmt, g);
+                break;
+            }
     hipLaunchKernelGGL(fn, dim3(grid), dim3(NT), LDS_BYTES, stream, samples, cfg,
                        reinterpret_cast<const cpx*>(tables), reinterpret_cast<const cpx*>(twn),
                        reinterpret_cast<const f4*>(tspec), shifts, work_list, work_count,
