@@ -227,10 +227,10 @@ int build_constants(thr_handle* h) {
             tab[1536 + k1 * 32 + mp] = unit_root((long long)k1 * mp, h->lng ? 16384 : n);
     HIP_TRY(hipMalloc(&h->d_tables, tab.size() * sizeof(float2)));
     HIP_TRY(hipMemcpy(h->d_tables, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice));
-    // --- pass-1 / pass-B twiddles W_16384^(k1 q) of k_correlate as one L2-resident table in
-    //     global memory (THR_GTW=0: the factored LDS tables A[k1][n2] * Bt[k1][m'] instead)
+    // --- pass-1 / pass-B twiddles W_16384^(k1 q) of k_correlate (one template) and of the
+    //     short-block kernels as one L2-resident table in global memory
     h->dev.gtw = nullptr;
-    if (h->small || (h->fast && !(getenv("THR_GTW") && atoi(getenv("THR_GTW")) == 0))) {
+    if (h->small || h->fast) {
         std::vector<float2> g(16 * 1024);
         for (int k1 = 0; k1 < 16; ++k1)
             for (int q = 0; q < 1024; ++q) g[k1 * 1024 + q] = unit_root((long long)k1 * q, 16384);

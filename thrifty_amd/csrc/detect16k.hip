@@ -145,9 +145,10 @@ __global__ __launch_bounds__(NT) void k_correlate(
         THR_STAMP(1);
         // (the previous block's pass-C LDS reads all precede its reduction barrier)
         // (multi-template: 64 more live VGPRs for the spectrum -- the L2-table path would spill)
-        const cpx* gtw = MULTI ? nullptr : static_cast<const cpx*>(cfg.gtw);
+        constexpr bool GTW = !MULTI;
+        const cpx* gtw = static_cast<const cpx*>(cfg.gtw);
         thread_phasor(sc_ph, t, p);   // (table of THIS block: written one iteration ago, two barriers back)
-        fwd_pass1<true>(lds, cur, sp->rpow, p[0], p[1], nullptr, gtw);
+        fwd_pass1<true, GTW>(lds, cur, sp->rpow, p[0], p[1], nullptr, gtw);
         cur = nxt;
         THR_STAMP(2);
         THR_STAMP(3);
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(NT) void k_correlate(
             __builtin_amdgcn_sched_barrier(0);
             THR_STAMP(7);
             THR_ABLATE_AT(14, { __syncthreads(); continue; });
-            inv_passB(lds, gtw);
+            inv_passB<GTW>(lds, gtw);
             THR_STAMP(8);
             THR_LOOP_BARRIER();
             THR_STAMP(9);

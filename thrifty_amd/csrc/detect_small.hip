@@ -415,7 +415,7 @@ __global__ __launch_bounds__(NT) void k_correlate_small(
             // whose pass-C readers are behind the previous reduction barrier)
             inv_passA(lds, z);
             __builtin_amdgcn_sched_barrier(0);
-            inv_passB(lds, gtw, k1 * GE::TROW);
+            inv_passB<true>(lds, gtw, k1 * GE::TROW);
             __syncthreads();
             cpx c[32];
             small_passC<R1>(lds, g2, tb2, c);

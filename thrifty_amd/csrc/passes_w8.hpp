@@ -83,10 +83,12 @@ struct RawSamples<THR_IN_C64> {
 // ------------------------------------------------------------ forward passes
 // Pass 1 (radix 16 over n1, two adjacent m per thread) -> LDS.
 // If PH: pre-rotate x[n1] by rpow[n1] and fold the per-m phasor p0/p1 into the twiddle.
-// gtw (optional): W_16384^(k1 * q), [16][1024], in global memory (L2-resident): the twiddle
-// of output k1 for the thread's two points is ONE coalesced 16-byte load instead of two LDS
-// reads and a complex product A[k1][n2] * Bt[k1][m'].
-template <bool PH, class RAW>
+// GTW: the twiddles come from `gtw` = W_16384^(k1 * q), [16][1024], in global memory
+// (L2-resident): the twiddle of output k1 for the thread's two points is ONE coalesced 16-byte
+// load instead of two LDS reads and a complex product A[k1][n2] * Bt[k1][m'].  A COMPILE-TIME
+// choice: with both forms compiled in behind a run-time test of the pointer, k_correlate was
+// 8.5 % slower (1.845 vs 1.69 ms per 32768 blocks).
+template <bool PH, bool GTW = false, class RAW = void>
 __device__ __forceinline__ void fwd_pass1(cpx* lds, const RAW& raw,
                                           const float2* __restrict__ rpow, cpx p0, cpx p1,
                                           float* energy = nullptr,
@@ -122,7 +124,7 @@ __device__ __forceinline__ void fwd_pass1(cpx* lds, const RAW& raw,
             }
         } else {
             cpx w0, w1;
-            if (gtw != nullptr) {
+            if constexpr (GTW) {
                 const f4 ww = reinterpret_cast<const f4*>(gtw)[k1 * 512 + t];
                 w0 = cpx{ww.x, ww.y};
                 w1 = cpx{ww.z, ww.w};
@@ -253,6 +255,7 @@ __device__ __forceinline__ void inv_passA(cpx* lds, cpx* z) {
 // tw_row >= 0: row of the gtw table to use instead of k1 (block_len R1 * 1024 < 16384: LDS row
 // r holds sub-sequence k1 = r mod R1 of one of the 16 / R1 blocks, whose twiddle
 // W_N^(k1 q) = W_16384^(k1 (16 / R1) q) is table row k1 * 16 / R1 -- detect_small.hip)
+template <bool GTW = false>
 __device__ __forceinline__ void inv_passB(cpx* lds, const cpx* __restrict__ gtw = nullptr,
                                           int tw_row = -1) {
     const int t = opaque_tid();
@@ -261,7 +264,7 @@ __device__ __forceinline__ void inv_passB(cpx* lds, const cpx* __restrict__ gtw 
     cpx v[R2];
 #pragma unroll
     for (int k2 = 0; k2 < R2; ++k2) v[k2] = base[k2 * CHUNK];
-    if (gtw != nullptr) {
+    if constexpr (GTW) {
         // twiddles W_N^(k1 (32 n2 + n3)) straight from the L2-resident table: issued before the
         // butterfly, consumed after it
         const cpx* tw = gtw + (tw_row >= 0 ? tw_row : k1) * 1024 + n3;
