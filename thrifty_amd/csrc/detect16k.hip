@@ -145,10 +145,12 @@ __global__ __launch_bounds__(NT) void k_correlate(
         THR_STAMP(1);
         // (the previous block's pass-C LDS reads all precede its reduction barrier)
         // (multi-template: 64 more live VGPRs for the spectrum -- the L2-table path would spill)
+        // pass 1 always takes its twiddles from the L2 table; pass B only with one template (with
+        // several, the spectrum stays live across the template loop and the table form spills)
         constexpr bool GTW = !MULTI;
         const cpx* gtw = static_cast<const cpx*>(cfg.gtw);
         thread_phasor(sc_ph, t, p);   // (table of THIS block: written one iteration ago, two barriers back)
-        fwd_pass1<true, GTW>(lds, cur, sp->rpow, p[0], p[1], nullptr, gtw);
+        fwd_pass1<true, true>(lds, cur, sp->rpow, p[0], p[1], nullptr, gtw);
         cur = nxt;
         THR_STAMP(2);
         THR_STAMP(3);

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(NT) void k_preshift(const void* __restrict__ sample
         }
         inv_passA(lds, z);
         __builtin_amdgcn_sched_barrier(0);
-        inv_passB(lds);
+        inv_passB<true>(lds, static_cast<const cpx*>(cfg.gtw));   // twiddles from the L2 table (-0.6 %)
         __syncthreads();
         cpx c0[R1], c1[R1];
         inv_passC(lds, c0, c1);
