@@ -128,7 +128,7 @@ struct thr_handle {
     int compact_tiles_cap = 0;
     // PreshiftDetector variant (thr_create_preshift): bank of pre-shifted template spectra
     int preshift_num = 0;       // 0 = default detector
-    float2* d_gtw = nullptr;    // optional combined twiddle table (THR_GTW)
+    float2* d_gtw = nullptr;    // combined twiddle table W_16384^(k1 q), L2-resident
     float2* d_bank = nullptr;   // [num][N]; 16384: [k3][k1][k2] gather layout, else natural order
     // host-buffer entry points (thr_detect / _stream / _card): two sets of staging buffers so
     // that the H2D copy of chunk i + 1 (copy stream) runs under the kernels of chunk i (lazy)

@@ -33,7 +33,7 @@ struct DevCfg {
     int car_prune;     // pruned FFT#1 (16384 path): 0 off, 1 window+margin inside bins [0,128),
                        // 2 any window of <= 122 bins (samples pre-shifted by win_lo - 3)
     unsigned long long* timeline;  // dev only (-DTHR_TIMELINE): [8 waves][16] s_memtime stamps
-    const void* gtw;   // [16][1024] W_16384^(k1 q) for k_correlate's passes 1 and B (null: THR_GTW=0, LDS tables)
+    const void* gtw;   // [16][1024] W_16384^(k1 q) for k_correlate's passes 1 and B (kernels compiled for the LDS-table form ignore it)
     int variant;       // 0 reference Detector, 1 PreshiftDetector, 2 fastdet-compatible (power-domain verdicts)
     int dyn_sched;     // THR_DYN (default 1): k_correlate takes blocks from a global counter (see kernel)
     int stagger;       // THR_STAGGER (default 1): younger half of k_correlate's waves computes the next
