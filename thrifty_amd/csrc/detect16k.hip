@@ -33,7 +33,7 @@ using namespace k16;
 //     p(2t) = [c0 exp(2 pi i s 128 w / N)] * [exp(2 pi i s 2 l / N)],   p(2t + 1) = p(2t) * exp(2 pi i s / N)
 // -- 8 wave factors, 64 lane factors and the one-sample step: 73 exactly formed numbers per
 // block (integer part of s through the root table, fractional part through a small-angle
-// sincosf).  73 threads form one each for the NEXT block and park them in LDS; every thread then
+// polynomial).  73 threads form one each for the NEXT block and park them in LDS; every thread then
 // needs two LDS reads and two complex products instead of two sincosf + gathers of its own.
 constexpr int PH_OFF = 896;   // bytes into the scratch area: [896, 896 + 73 * 8)
 __device__ __forceinline__ void phasor_table(const ShiftParams* __restrict__ sp,
@@ -45,7 +45,8 @@ __device__ __forceinline__ void phasor_table(const ShiftParams* __restrict__ sp,
         const int q = (si * m) & (N - 1);
         const cpx wq = cconj(twn[q]);  // exp(+2 pi i q / N)
         float sn, cs;
-        sincosf(6.283185307179586f * (sf * float(m)), &sn, &cs);
+        // |2 pi sf m| <= 2 pi * (0.5 / N) * 896 = 0.172 rad
+        sincos_small(6.283185307179586f * (sf * float(m)), &sn, &cs);
         cpx v = cmul(wq, cpx{cs, sn});
         if (t >= 64 && t < 72) v = cmul(v, cpx{sp->c0.x, sp->c0.y});
         sc_ph[t] = v;
@@ -228,8 +229,12 @@ __global__ __launch_bounds__(NT) void k_correlate(
         // that its L2 latency hides under pass C, the statistics and the reduction.
         f4 tq[R3 / 2];
         {
-            const f4* ts = tspec + opaque_tid();
-            static_for<R3 / 2>([&](auto J) { tq[decltype(J)::value] = ts[decltype(J)::value * NT]; });
+            const char* ts = reinterpret_cast<const char*>(tspec);
+            const unsigned off = unsigned(opaque_tid()) * 16u;
+            static_for<R3 / 2>([&](auto J) {
+                tq[decltype(J)::value] =
+                    *reinterpret_cast<const f4*>(ts + (off + unsigned(decltype(J)::value * (NT * 16))));
+            });
         }
         for (int tpl = 0; tpl < n_tpl; ++tpl) {
             // ---- X * conj(T)/N in digit-reversed register order
@@ -248,8 +253,8 @@ __global__ __launch_bounds__(NT) void k_correlate(
                     x0 = xh[brev(2 * j, R3)];
                     x1 = xh[brev(2 * j + 1, R3)];
                 }
-                z[brev(2 * j, R3)] = cmul(x0, cpx{q.x, q.y});
-                z[brev(2 * j + 1, R3)] = cmul(x1, cpx{q.z, q.w});
+                cmul2(x0, cpx{q.x, q.y}, x1, cpx{q.z, q.w}, z[brev(2 * j, R3)],
+                      z[brev(2 * j + 1, R3)]);
             });
             // pass A overwrites exactly the chunk this thread read in pass 3 (or, for
             // tpl > 0, rows whose pass-C readers are behind the previous reduction barrier)

@@ -4,8 +4,8 @@
 // v_pk_add_f32 and a rotation by a compile-time twiddle is v_pk_mul + v_pk_fma with
 // op_sel swizzles -- no register shuffling.  On CDNA4 a packed op costs the same
 // VALU cycles as its two scalar halves (32 lane-ops/clk/SIMD either way), so the
-// aim is simply the fewest lane-ops and zero v_mov: products with run-time twiddles
-// are written as 4 scalar mul/fma, and multiplications by -+i are folded into the
+// aim is simply the fewest issue slots and zero v_mov: products with run-time twiddles
+// are two packed instructions (cmul below), and multiplications by -+i are folded into the
 // radix-4 butterflies as a v_pk_fma with a (+-1, -+1) constant.  This translation unit must be
 // compiled with -fno-slp-vectorize (the SLP vectorizer re-packs the scalar forms
 // and pays for it in v_mov/v_pk_mov -- measured ~40 % extra VALU).
@@ -22,29 +22,41 @@ namespace thr {
 typedef float cpx __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-#ifdef THR_PK_CMUL
-// (dev A/B, measured: k_correlate 0.570 ms either way, pruned carrier kernel -2 %.)
-// Run-time complex products as TWO packed instructions: the broadcast of a.x / a.y, the
-// swap of b and the sign are all VOP3P modifiers (op_sel, op_sel_hi, neg_lo/neg_hi), which
-// the compiler does not fold by itself (it materialises (-b.y, b.x) with v_xor + v_mov).
-// Same roundings as the scalar form below (one mul, one fma per component): bit-identical.
-__device__ __forceinline__ cpx cmul(cpx a, cpx b) {
-    cpx t, r;
+// Run-time complex products as TWO packed instructions: the broadcast of a.x / a.y, the swap of
+// b and the sign are all VOP3P modifiers (op_sel, op_sel_hi, neg_lo / neg_hi), which the compiler
+// does not fold by itself (it materialises (-b.y, b.x) with v_xor + v_mov, or -- the form used
+// until round 2 -- emits four scalar mul / fma).  Same roundings as the scalar form (one mul, one
+// fma per component): bit-identical results.  Measured (MI355X, 2 waves per SIMD): k_correlate
+// -1.3 % (-3.9 % with four templates), pruned carrier kernel -3 %.  -DTHR_SCALAR_CMUL restores
+// the scalar form (A/B).
+#ifndef THR_SCALAR_CMUL
+__device__ __forceinline__ cpx cmul_lo(cpx a, cpx b) {   // (a.x b.x, a.x b.y)
+    cpx t;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+    return t;
+}
+__device__ __forceinline__ cpx cmul_hi(cpx a, cpx b, cpx t) {   // t + (-a.y b.y, a.y b.x)
+    cpx r;
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
         : "=v"(r)
         : "v"(a), "v"(b), "v"(t));
     return r;
 }
-// a * conj(b)
-__device__ __forceinline__ cpx cmulc(cpx a, cpx b) {
-    cpx t, r;
+__device__ __forceinline__ cpx cmulc_lo(cpx a, cpx b) {   // (a.x b.x, -a.x b.y)
+    cpx t;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+    return t;
+}
+__device__ __forceinline__ cpx cmulc_hi(cpx a, cpx b, cpx t) {   // t + (a.y b.y, a.y b.x)
+    cpx r;
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]"
         : "=v"(r)
         : "v"(a), "v"(b), "v"(t));
     return r;
 }
+__device__ __forceinline__ cpx cmul(cpx a, cpx b) { return cmul_hi(a, b, cmul_lo(a, b)); }
+// a * conj(b)
+__device__ __forceinline__ cpx cmulc(cpx a, cpx b) { return cmulc_hi(a, b, cmulc_lo(a, b)); }
 #else
 __device__ __forceinline__ cpx cmul(cpx a, cpx b) {
     cpx r;
@@ -60,6 +72,17 @@ __device__ __forceinline__ cpx cmulc(cpx a, cpx b) {
     return r;
 }
 #endif
+// two independent products.  (Interleaving them -- mul, mul, fma, fma, which saves the wait state
+// a packed result costs when the very next instruction consumes it -- was measured 4 % SLOWER in
+// k_correlate than the plain sequence, s_nop included.)
+__device__ __forceinline__ void cmul2(cpx a0, cpx b0, cpx a1, cpx b1, cpx& r0, cpx& r1) {
+    r0 = cmul(a0, b0);
+    r1 = cmul(a1, b1);
+}
+__device__ __forceinline__ void cmulc2(cpx a0, cpx b0, cpx a1, cpx b1, cpx& r0, cpx& r1) {
+    r0 = cmulc(a0, b0);
+    r1 = cmulc(a1, b1);
+}
 __device__ __forceinline__ cpx cconj(cpx a) { return cpx{a.x, -a.y}; }
 __device__ __forceinline__ float cnorm(cpx a) { return fmaf(a.x, a.x, a.y * a.y); }
 // a + DIR*i*b  (DIR = +1 or -1) as ONE v_pk_fma_f32: b.yx * (-+1, +-1) + a.  The swap is an
@@ -97,9 +120,11 @@ __device__ __forceinline__ cpx rot32(cpx z) {
     } else if constexpr (q == 16) {
         return -z;
     } else if constexpr (q == 8) {
-        return DIR > 0 ? cpx{-z.y, z.x} : cpx{z.y, -z.x};
+        // +-i z = z.yx * (-+1, +-1): ONE v_pk_mul_f32 (the swap is an op_sel modifier) instead of
+        // a v_xor and the v_movs that re-pair the halves
+        return z.yx * (DIR > 0 ? cpx{-1.0f, 1.0f} : cpx{1.0f, -1.0f});
     } else if constexpr (q == 24) {
-        return DIR > 0 ? cpx{z.y, -z.x} : cpx{-z.y, z.x};
+        return z.yx * (DIR > 0 ? cpx{1.0f, -1.0f} : cpx{-1.0f, 1.0f});
     } else {
         constexpr float C = cos32(q);
         constexpr float S = (DIR > 0 ? 1.0f : -1.0f) * sin32(q);

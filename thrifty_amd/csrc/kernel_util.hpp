@@ -19,6 +19,33 @@ __device__ __forceinline__ int opaque_tid() {
     return t;
 }
 
+// A wave-uniform pointer the optimiser cannot see through, back in SGPRs (two v_mov + two
+// v_readfirstlane): address arithmetic on it stays scalar AND stays inside the persistent block
+// loop -- hoisted, a kernel's row bases (15 x 2 SGPRs for one twiddle table) are spilled to VGPR
+// lanes and read back with v_readlane every iteration.
+template <class T>
+__device__ __forceinline__ const T* opaque_uniform(const T* p) {
+    unsigned lo = unsigned(reinterpret_cast<unsigned long long>(p));
+    unsigned hi = unsigned(reinterpret_cast<unsigned long long>(p) >> 32);
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    return reinterpret_cast<const T*>((static_cast<unsigned long long>(hi) << 32) | lo);
+}
+
+// sin / cos for |x| <= 0.2 rad: Taylor to x^7 / x^6 (truncation < 4e-13 / 2e-11, far below the
+// float rounding of the result) -- 10 VALU ops instead of sincosf's ~60 with its large-argument
+// reduction compiled in.  (The 73 shift-phasor factors of a 16384-sample block: |x| <= 0.172.)
+__device__ __forceinline__ void sincos_small(float x, float* s, float* c) {
+    const float x2 = x * x;
+    float ps = fmaf(x2, -1.0f / 5040.0f, 1.0f / 120.0f);
+    ps = fmaf(x2, ps, -1.0f / 6.0f);
+    *s = fmaf(x * x2, ps, x);
+    float pc = fmaf(x2, -1.0f / 720.0f, 1.0f / 24.0f);
+    pc = fmaf(x2, pc, -0.5f);
+    *c = fmaf(x2, pc, 1.0f);
+}
+
 // Dev-only phase ablation (-DTHR_DEV_ABLATE, env THR_ABLATE=n): leave each block after phase n
 // so that cumulative phase costs can be read off the kernel time (results are garbage).
 #ifdef THR_DEV_ABLATE
@@ -131,19 +158,49 @@ __device__ __forceinline__ void block_reduce(float (&s)[NS], double (&out)[NS],
     m = t;
 }
 
-// The same with no sums: one u64 max, ONE barrier (same scratch layout and parity rule).
+// max of two keys whose high word is the bit pattern of a float that is not negative (a power,
+// +inf and NaN patterns included): read as IEEE doubles such keys are non-negative and finite
+// (exponent field <= 0x7FC) and order exactly like the integers, so ONE v_max_f64 does what
+// v_cmp_gt_u64 + two v_cndmask do (fp64 denormals are never flushed in HIP kernels).
+__device__ __forceinline__ unsigned long long max_power_key(unsigned long long a,
+                                                            unsigned long long b) {
+    unsigned long long r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned long long wave_max_power_key(unsigned long long v) {
+#define THR_STEP(CTRL, MASK)                                                       \
+    {                                                                              \
+        const unsigned lo = dpp_u32<CTRL, MASK>(0u, (unsigned)v);                  \
+        const unsigned hi = dpp_u32<CTRL, MASK>(0u, (unsigned)(v >> 32));          \
+        v = max_power_key(((unsigned long long)hi << 32) | lo, v);                 \
+    }
+    THR_STEP(DPP_ROW_SHR1, 0xf)
+    THR_STEP(DPP_ROW_SHR2, 0xf)
+    THR_STEP(DPP_ROW_SHR4, 0xf)
+    THR_STEP(DPP_ROW_SHR8, 0xf)
+    THR_STEP(DPP_ROW_BCAST15, 0xa)
+    THR_STEP(DPP_ROW_BCAST31, 0xc)
+#undef THR_STEP
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// The same with no sums: one max of power keys (max_power_key), ONE barrier (same scratch layout
+// and parity rule).
 template <int NW>
 __device__ __forceinline__ void block_reduce_max(unsigned long long& m, unsigned char* scratch,
                                                  int parity) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned long long* su =
         reinterpret_cast<unsigned long long*>(scratch + parity * red_slot_bytes<NW>()) + 3 * NW;
-    m = wave_max(m);
+    m = wave_max_power_key(m);
     if (lane == 0) su[wv] = m;
     THR_LOOP_BARRIER();
-    unsigned long long t = 0;
+    unsigned long long t = su[0];
 #pragma unroll
-    for (int w = 0; w < NW; ++w) t = su[w] > t ? su[w] : t;
+    for (int w = 1; w < NW; ++w) t = max_power_key(su[w], t);
     m = t;
 }
 

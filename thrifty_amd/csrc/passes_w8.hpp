@@ -102,8 +102,7 @@ __device__ __forceinline__ void fwd_pass1(cpx* lds, const RAW& raw,
         if (energy != nullptr) e += cnorm(v0[n1]) + cnorm(v1[n1]);  // time-domain sum |x|^2
         if constexpr (PH) {
             const cpx r = cpx{rpow[n1].x, rpow[n1].y};
-            v0[n1] = cmul(v0[n1], r);
-            v1[n1] = cmul(v1[n1], r);
+            cmul2(v0[n1], r, v1[n1], r, v0[n1], v1[n1]);
         }
     }
     if (energy != nullptr) *energy = e;
@@ -113,33 +112,33 @@ __device__ __forceinline__ void fwd_pass1(cpx* lds, const RAW& raw,
     const cpx* tA = lds + OFF_A;
     const cpx* tB = lds + OFF_B;
     f4* out = reinterpret_cast<f4*>(lds + n2 * CHUNK + mp);
+    const char* gbase = reinterpret_cast<const char*>(gtw);
     static_for<R1>([&](auto K) {
         constexpr int k1 = decltype(K)::value;
         constexpr int src = brev(k1, R1);
         cpx y0 = v0[src], y1 = v1[src];
         if constexpr (k1 == 0) {
             if constexpr (PH) {
-                y0 = cmul(y0, p0);
-                y1 = cmul(y1, p1);
+                cmul2(y0, p0, y1, p1, y0, y1);
             }
         } else {
             cpx w0, w1;
             if constexpr (GTW) {
-                const f4 ww = reinterpret_cast<const f4*>(gtw)[k1 * 512 + t];
+                // (uniform row base + 32-bit lane offset: the saddr form of global_load, no
+                // 64-bit VALU address arithmetic per row)
+                const f4 ww = *reinterpret_cast<const f4*>(
+                    gbase + (unsigned(t) * 16u + unsigned(k1 * 8192)));
                 w0 = cpx{ww.x, ww.y};
                 w1 = cpx{ww.z, ww.w};
             } else {
                 const cpx a = tA[k1 * 32 + n2];
                 const f4 bb = *reinterpret_cast<const f4*>(tB + k1 * 32 + mp);
-                w0 = cmul(a, cpx{bb.x, bb.y});
-                w1 = cmul(a, cpx{bb.z, bb.w});
+                cmul2(a, cpx{bb.x, bb.y}, a, cpx{bb.z, bb.w}, w0, w1);
             }
             if constexpr (PH) {
-                w0 = cmul(w0, p0);
-                w1 = cmul(w1, p1);
+                cmul2(w0, p0, w1, p1, w0, w1);
             }
-            y0 = cmul(y0, w0);
-            y1 = cmul(y1, w1);
+            cmul2(y0, w0, y1, w1, y0, y1);
         }
         out[k1 * (ROW / 2)] = f4{y0.x, y0.y, y1.x, y1.y};
     });
@@ -158,8 +157,7 @@ __device__ __forceinline__ void pass1_twiddles(const cpx* lds, cpx (&w0)[R1], cp
     for (int k1 = 1; k1 < R1; ++k1) {
         const cpx a = tA[k1 * 32 + n2];
         const f4 bb = *reinterpret_cast<const f4*>(tB + k1 * 32 + mp);
-        w0[k1] = cmul(a, cpx{bb.x, bb.y});
-        w1[k1] = cmul(a, cpx{bb.z, bb.w});
+        cmul2(a, cpx{bb.x, bb.y}, a, cpx{bb.z, bb.w}, w0[k1], w1[k1]);
     }
 }
 
@@ -185,8 +183,7 @@ __device__ __forceinline__ void fwd_pass1_pre(cpx* lds, const RAW& raw, const cp
         constexpr int src = brev(k1, R1);
         cpx y0 = v0[src], y1 = v1[src];
         if constexpr (k1 != 0) {
-            y0 = cmul(y0, w0[k1]);
-            y1 = cmul(y1, w1[k1]);
+            cmul2(y0, w0[k1], y1, w1[k1], y0, y1);
         }
         out[k1 * (ROW / 2)] = f4{y0.x, y0.y, y1.x, y1.y};
     });
@@ -204,11 +201,16 @@ __device__ __forceinline__ void fwd_pass2(cpx* lds) {
 #pragma unroll
     for (int n2 = 0; n2 < R2; ++n2) v[n2] = base[n2 * CHUNK];
     dft_dif<R2, -1>(v);
-    static_for<KEEP>([&](auto K) {
-        constexpr int k2 = decltype(K)::value;
-        cpx y = v[brev(k2, R2)];
-        if constexpr (k2 != 0) y = cmul(y, tC[k2 * 32]);
-        base[k2 * CHUNK] = y;
+    static_assert(KEEP % 2 == 0, "outputs are twiddled in pairs");
+    static_for<KEEP / 2>([&](auto K) {
+        constexpr int k2 = 2 * decltype(K)::value;
+        cpx y0 = v[brev(k2, R2)], y1 = v[brev(k2 + 1, R2)];
+        if constexpr (k2 != 0)
+            cmul2(y0, tC[k2 * 32], y1, tC[(k2 + 1) * 32], y0, y1);
+        else
+            y1 = cmul(y1, tC[32]);
+        base[k2 * CHUNK] = y0;
+        base[(k2 + 1) * CHUNK] = y1;
     });
 }
 
@@ -244,8 +246,10 @@ __device__ __forceinline__ void inv_passA(cpx* lds, cpx* z) {
     static_for<R3 / 2>([&](auto J) {
         constexpr int j = decltype(J)::value;
         cpx y0 = v[brev(2 * j, R3)], y1 = v[brev(2 * j + 1, R3)];
-        if constexpr (j != 0) y0 = cmulc(y0, tC[(2 * j) * 32]);
-        y1 = cmulc(y1, tC[(2 * j + 1) * 32]);
+        if constexpr (j != 0)
+            cmulc2(y0, tC[(2 * j) * 32], y1, tC[(2 * j + 1) * 32], y0, y1);
+        else
+            y1 = cmulc(y1, tC[32]);
         dst[j] = f4{y0.x, y0.y, y1.x, y1.y};
     });
 }
@@ -272,9 +276,12 @@ __device__ __forceinline__ void inv_passB(cpx* lds, const cpx* __restrict__ gtw 
 #pragma unroll
         for (int n2 = 0; n2 < R2; ++n2) w[n2] = tw[n2 * 32];
         dft_dif<R2, +1>(v);
-        static_for<R2>([&](auto K) {
-            constexpr int n2 = decltype(K)::value;
-            base[n2 * CHUNK] = cmulc(v[brev(n2, R2)], w[n2]);
+        static_for<R2 / 2>([&](auto K) {
+            constexpr int n2 = 2 * decltype(K)::value;
+            cpx y0, y1;
+            cmulc2(v[brev(n2, R2)], w[n2], v[brev(n2 + 1, R2)], w[n2 + 1], y0, y1);
+            base[n2 * CHUNK] = y0;
+            base[(n2 + 1) * CHUNK] = y1;
         });
         return;
     }
