@@ -49,14 +49,13 @@ __global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples
         cur.load(static_cast<const unsigned char*>(samples) + size_t(blockIdx.x) * blk_bytes,
                  opaque_tid());
     for (int b = blockIdx.x; b < n_blocks; b += gridDim.x) {
-        // next block's samples: issued now, consumed one iteration later
-        RawSamples<FMT> nxt = cur;
-        if (b + int(gridDim.x) < n_blocks)
-            nxt.load(static_cast<const unsigned char*>(samples) + size_t(b + gridDim.x) * blk_bytes,
-                     opaque_tid());
         // (previous block's pass-3 LDS reads all precede its reduction barrier)
         fwd_pass1_pre(lds, cur, tw0, tw1);
-        cur = nxt;
+        // next block's samples, into the registers pass 1 has just consumed: issued now, used
+        // one iteration later (no second register set, no copies)
+        if (b + int(gridDim.x) < n_blocks)
+            cur.load(static_cast<const unsigned char*>(samples) + size_t(b + gridDim.x) * blk_bytes,
+                     opaque_tid());
         __syncthreads();
         THR_ABLATE_AT(1, continue);
         // passes 2 and 3 of row k1 are done by the same half-wave: no barrier between them
@@ -200,10 +199,6 @@ __global__ __launch_bounds__(NT) void k_carrier_pruned(const void* __restrict__ 
         cur.load(static_cast<const unsigned char*>(samples) + size_t(blockIdx.x) * blk_bytes,
                  opaque_tid());
     for (int b = blockIdx.x; b < n_blocks; b += gridDim.x) {
-        RawSamples<FMT> nxt = cur;
-        if (b + int(gridDim.x) < n_blocks)
-            nxt.load(static_cast<const unsigned char*>(samples) + size_t(b + gridDim.x) * blk_bytes,
-                     opaque_tid());
         float sums[1];
         if constexpr (SHIFTED) {
             cpx p0 = ph[0], p1 = ph[1];
@@ -212,7 +207,10 @@ __global__ __launch_bounds__(NT) void k_carrier_pruned(const void* __restrict__ 
         } else {
             fwd_pass1_pre(lds, cur, tw0, tw1, &sums[0]);
         }
-        cur = nxt;
+        // next block's samples, into the registers pass 1 has just consumed
+        if (b + int(gridDim.x) < n_blocks)
+            cur.load(static_cast<const unsigned char*>(samples) + size_t(b + gridDim.x) * blk_bytes,
+                     opaque_tid());
         __syncthreads();
         fwd_pass2<PRUNE_K2>(lds);
         __builtin_amdgcn_sched_barrier(0);

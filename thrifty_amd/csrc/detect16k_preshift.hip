@@ -184,13 +184,12 @@ __global__ __launch_bounds__(NT) void k_preshift(const void* __restrict__ sample
         cur.load(static_cast<const unsigned char*>(samples) + size_t(blockIdx.x) * blk_bytes,
                  opaque_tid());
     for (int b = blockIdx.x; b < n_blocks; b += gridDim.x) {
-        RawSamples<FMT> nxt = cur;
-        if (b + int(gridDim.x) < n_blocks)
-            nxt.load(static_cast<const unsigned char*>(samples) + size_t(b + gridDim.x) * blk_bytes,
-                     opaque_tid());
         // (the previous block's last LDS reads -- pass 3 or pass C -- precede a reduction barrier)
         fwd_pass1_pre(lds, cur, tw0, tw1);
-        cur = nxt;
+        // next block's samples, into the registers pass 1 has just consumed
+        if (b + int(gridDim.x) < n_blocks)
+            cur.load(static_cast<const unsigned char*>(samples) + size_t(b + gridDim.x) * blk_bytes,
+                     opaque_tid());
         __syncthreads();
         fwd_pass2(lds);
         __builtin_amdgcn_sched_barrier(0);

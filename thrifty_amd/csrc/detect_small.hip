@@ -279,15 +279,14 @@ __global__ __launch_bounds__(NT) void k_carrier_small(const void* __restrict__ s
         const int g = t / GE::TB, tb = t % GE::TB;
         const int b = gi * GE::G + g;
         const bool valid = b < n_blocks;   // (tail group: the extra lanes redo the last block, store nothing)
-        // next group's samples: issued now, consumed one iteration later
-        RawSmall<FMT, R1> nxt = cur;
-        if (gi + int(gridDim.x) < n_groups) {
-            const int bn = min((gi + int(gridDim.x)) * GE::G + g, n_blocks - 1);
-            nxt.load(static_cast<const unsigned char*>(samples) + size_t(bn) * blk_bytes, tb);
-        }
         // (the previous group's pass-3 LDS reads all precede its reduction barrier)
         small_pass1<R1, false>(lds, cur, g, tb, nullptr, cpx{}, nullptr, gtw, nullptr, R1 > 1 ? tw : nullptr);
-        cur = nxt;
+        // next group's samples, into the registers pass 1 has just consumed: issued now, used one
+        // iteration later
+        if (gi + int(gridDim.x) < n_groups) {
+            const int bn = min((gi + int(gridDim.x)) * GE::G + g, n_blocks - 1);
+            cur.load(static_cast<const unsigned char*>(samples) + size_t(bn) * blk_bytes, tb);
+        }
         __syncthreads();
         fwd_pass2(lds);
         __builtin_amdgcn_sched_barrier(0);

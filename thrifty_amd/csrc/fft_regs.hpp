@@ -55,6 +55,15 @@ __device__ __forceinline__ cpx cmulc_hi(cpx a, cpx b, cpx t) {   // t + (a.y b.y
     return r;
 }
 __device__ __forceinline__ cpx cmul(cpx a, cpx b) { return cmul_hi(a, b, cmul_lo(a, b)); }
+// a * u with a wave-uniform u read straight from its SGPR pair (no v_mov_b64 into VGPRs first)
+__device__ __forceinline__ cpx cmul_uniform(cpx a, cpx u) {
+    cpx t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(u));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=v"(r)
+        : "v"(a), "s"(u), "v"(t));
+    return r;
+}
 // a * conj(b)
 __device__ __forceinline__ cpx cmulc(cpx a, cpx b) { return cmulc_hi(a, b, cmulc_lo(a, b)); }
 #else
@@ -71,6 +80,7 @@ __device__ __forceinline__ cpx cmulc(cpx a, cpx b) {
     r.y = fmaf(a.y, b.x, -(a.x * b.y));
     return r;
 }
+__device__ __forceinline__ cpx cmul_uniform(cpx a, cpx u) { return cmul(a, u); }
 #endif
 // two independent products.  (Interleaving them -- mul, mul, fma, fma, which saves the wait state
 // a packed result costs when the very next instruction consumes it -- was measured 4 % SLOWER in

@@ -55,9 +55,14 @@ template <>
 struct RawSamples<THR_IN_U8> {
     unsigned q[R1];
     __device__ __forceinline__ void load(const void* __restrict__ blk, int t) {
-        const unsigned* p = reinterpret_cast<const unsigned*>(blk) + t;
+        // (block base uniform + 32-bit lane offset: the saddr form of global_load -- no 64-bit
+        // VALU address arithmetic; rows 2j and 2j + 1 share an offset register, 2048 apart in the
+        // instruction's immediate)
+        const char* p = reinterpret_cast<const char*>(blk);
 #pragma unroll
-        for (int n1 = 0; n1 < R1; ++n1) q[n1] = p[n1 * (S1 / 2)];
+        for (int n1 = 0; n1 < R1; ++n1)
+            q[n1] = *reinterpret_cast<const unsigned*>(
+                p + (unsigned(t) * 4u + unsigned((n1 >> 1) * (S1 * 4))) + (n1 & 1) * (S1 * 2));
     }
     __device__ __forceinline__ void get(int n1, cpx& a, cpx& b) const {
         const unsigned w = q[n1];
@@ -102,7 +107,8 @@ __device__ __forceinline__ void fwd_pass1(cpx* lds, const RAW& raw,
         if (energy != nullptr) e += cnorm(v0[n1]) + cnorm(v1[n1]);  // time-domain sum |x|^2
         if constexpr (PH) {
             const cpx r = cpx{rpow[n1].x, rpow[n1].y};
-            cmul2(v0[n1], r, v1[n1], r, v0[n1], v1[n1]);
+            v0[n1] = cmul_uniform(v0[n1], r);   // (rpow: the same for every thread, scalar loads)
+            v1[n1] = cmul_uniform(v1[n1], r);
         }
     }
     if (energy != nullptr) *energy = e;
