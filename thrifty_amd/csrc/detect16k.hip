@@ -290,58 +290,69 @@ __global__ __launch_bounds__(NT) void k_correlate(
 #endif
 
             // ---- |corr|^2, windowed first-max, optional std sums
-            // per-thread first-max in float (lags visited in increasing n, strict '>'), one
-            // 64-bit key per thread only for the cross-lane reduction
+            // The maximum first, the lag afterwards: per thread one v_max3 per two lags, per wave
+            // a DPP max; then the lanes that hold the wave's maximum name their first lag with
+            // it (lags scanned downwards, so the lowest one sticks), a DPP min picks the wave's
+            // first, and one 64-bit key per wave -- (power, -lag) -- goes through LDS.  (Tracking
+            // (power, lag) per lag costs a compare and two selects each, 132 VALU slots per block
+            // with the reduction; this form 85.)  NaN powers are never candidates (v_max and
+            // v_cmp_eq ignore them), like the strict '>' of a running maximum.
             float sums[2] = {0.f, 0.f};     // sum |corr|, sum |corr|^2 over [0, corr_len): WANT_STD only
-            float pw0[R1], pw1[R1];
-            float bestp = -1.0f;
-            int bestn = 0;
+            float pw0[R1], pw1[R1];         // powers (the peak's neighbours are picked from them)
+            float ew0[R1], ew1[R1];         // the same inside the unique window, -1 outside
+            float tmax = -1.0f;
             const unsigned win_w = unsigned(cfg.corr_hi - cfg.corr_lo);
+            constexpr bool GEOM = RLO >= 0 && RHI >= 0 && !WANT_STD;
             static_for<R1>([&](auto K) {
                 constexpr int n1 = decltype(K)::value;
-                constexpr bool GEOM = RLO >= 0 && RHI >= 0 && !WANT_STD;
                 if constexpr (GEOM && (n1 < RLO || n1 > 15 - RHI)) {   // row outside the window
-                    pw0[n1] = 0.f;
-                    pw1[n1] = 0.f;
+                    pw0[n1] = pw1[n1] = 0.f;
+                    ew0[n1] = ew1[n1] = -1.f;
                     return;
                 }
                 pw0[n1] = cnorm(c0[brev(n1, R1)]);
                 pw1[n1] = cnorm(c1[brev(n1, R1)]);
                 if constexpr (GEOM && n1 > RLO && n1 < 15 - RHI) {     // row inside the window
+                    ew0[n1] = pw0[n1];
+                    ew1[n1] = pw1[n1];
+                } else {
                     const int n = n1 * S1 + 2 * t;
-                    const bool t0 = pw0[n1] > bestp;
-                    bestp = t0 ? pw0[n1] : bestp;
-                    bestn = t0 ? n : bestn;
-                    const bool t1 = pw1[n1] > bestp;
-                    bestp = t1 ? pw1[n1] : bestp;
-                    bestn = t1 ? n + 1 : bestn;
-                    return;
-                }
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int n = n1 * S1 + 2 * t + e;
-                    const float pw = e ? pw1[n1] : pw0[n1];
-                    const bool take = unsigned(n - cfg.corr_lo) < win_w && pw > bestp;
-                    bestp = take ? pw : bestp;
-                    bestn = take ? n : bestn;
+                    ew0[n1] = unsigned(n - cfg.corr_lo) < win_w ? pw0[n1] : -1.f;
+                    ew1[n1] = unsigned(n + 1 - cfg.corr_lo) < win_w ? pw1[n1] : -1.f;
                     if constexpr (WANT_STD) {
                         if (n < cfg.corr_len) {
-                            sums[1] += pw;
-                            sums[0] += __builtin_amdgcn_sqrtf(pw);
+                            sums[1] += pw0[n1];
+                            sums[0] += __builtin_amdgcn_sqrtf(pw0[n1]);
+                        }
+                        if (n + 1 < cfg.corr_len) {
+                            sums[1] += pw1[n1];
+                            sums[0] += __builtin_amdgcn_sqrtf(pw1[n1]);
                         }
                     }
                 }
+                tmax = __builtin_fmaxf(tmax, __builtin_fmaxf(ew0[n1], ew1[n1]));
             });
+            const float wmax = wave_max_f32(tmax);
+            int first = 63;    // 2 n1 + e of the thread's first lag with the wave's maximum
+            static_for<R1>([&](auto K) {
+                constexpr int n1 = R1 - 1 - decltype(K)::value;
+                if constexpr (GEOM && (n1 < RLO || n1 > 15 - RHI)) return;
+                first = ew1[n1] == wmax ? 2 * n1 + 1 : first;
+                first = ew0[n1] == wmax ? 2 * n1 : first;
+            });
+            const unsigned lag = first == 63 ? 0xFFFFFFFFu
+                                             : unsigned((first >> 1) * S1 + 2 * t + (first & 1));
+            const unsigned wlag = wave_min_u32(lag);
+            // (no lag of this wave inside the window: wmax = -1, and key 0 loses to every other)
             unsigned long long best =
-                bestp < 0.f ? 0ull
-                            : ((unsigned long long)__float_as_uint(bestp) << 32) |
-                                  (0xFFFFFFFFu - unsigned(bestn));
+                wmax < 0.f ? 0ull
+                           : ((unsigned long long)__float_as_uint(wmax) << 32) | (0xFFFFFFFFu - wlag);
             double tot[2] = {0, 0};
             THR_STAMP(11);
             if constexpr (WANT_STD)
                 block_reduce<2, NT / 64>(sums, tot, best, sc_red, parity);
             else
-                block_reduce_max<NT / 64>(best, sc_red, parity);
+                block_reduce_wave_keys<NT / 64>(best, sc_red, parity);
             THR_STAMP(12);
             parity ^= 1;
             const int pk = int(0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu));

@@ -187,6 +187,49 @@ __device__ __forceinline__ unsigned long long wave_max_power_key(unsigned long l
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// Wave-wide float maximum / unsigned minimum on the DPP path (result in every lane).
+__device__ __forceinline__ float wave_max_f32(float v) {
+    // (identity -1: the callers' values are powers, or -1 for "no candidate")
+#define THR_STEP(CTRL, MASK) \
+    v = __builtin_fmaxf(v, __uint_as_float(dpp_u32<CTRL, MASK>(0xBF800000u, __float_as_uint(v))))
+    THR_STEP(DPP_ROW_SHR1, 0xf);
+    THR_STEP(DPP_ROW_SHR2, 0xf);
+    THR_STEP(DPP_ROW_SHR4, 0xf);
+    THR_STEP(DPP_ROW_SHR8, 0xf);
+    THR_STEP(DPP_ROW_BCAST15, 0xa);
+    THR_STEP(DPP_ROW_BCAST31, 0xc);
+#undef THR_STEP
+    return __uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+#define THR_STEP(CTRL, MASK) \
+    { const unsigned o = dpp_u32<CTRL, MASK>(0xFFFFFFFFu, v); v = o < v ? o : v; }
+    THR_STEP(DPP_ROW_SHR1, 0xf)
+    THR_STEP(DPP_ROW_SHR2, 0xf)
+    THR_STEP(DPP_ROW_SHR4, 0xf)
+    THR_STEP(DPP_ROW_SHR8, 0xf)
+    THR_STEP(DPP_ROW_BCAST15, 0xa)
+    THR_STEP(DPP_ROW_BCAST31, 0xc)
+#undef THR_STEP
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// Block maximum of one power key per WAVE (already uniform in the wave): ONE barrier, same
+// scratch layout and parity rule as block_reduce.
+template <int NW>
+__device__ __forceinline__ void block_reduce_wave_keys(unsigned long long& m, unsigned char* scratch,
+                                                       int parity) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long* su =
+        reinterpret_cast<unsigned long long*>(scratch + parity * red_slot_bytes<NW>()) + 3 * NW;
+    if (lane == 0) su[wv] = m;
+    THR_LOOP_BARRIER();
+    unsigned long long t = su[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) t = max_power_key(su[w], t);
+    m = t;
+}
+
 // The same with no sums: one max of power keys (max_power_key), ONE barrier (same scratch layout
 // and parity rule).
 template <int NW>
