@@ -611,24 +611,34 @@ int run_batch_long(thr_handle* h, const void* d_samples, int format,
                                     h->d_shifts, h->d_work_list, h->d_work_count, out,
                                     h->d_corr_stats, h->stream));   // (sub-batch-local indices)
         }
-        // correlate stage in chunks of work-list slots: one chunk's d_k0 exchange stays in the
-        // Infinity Cache between the sub-transform kernel (VALU/LDS-bound) and the combination
-        // (bandwidth-bound)
-        for (int base = 0; base < nb; base += h->long_chunk) {
-            const int cap = std::min(h->long_chunk, nb - base);
-            {
-                ProfScope p(h, 2);
-                HIP_TRY(thr::launch_correlate_long(
-                    format, in, nb, h->dev, h->d_tables, h->d_twn, h->d_tspec, h->d_shifts,
-                    h->d_work_list, h->d_work_count, h->d_dsub, h->d_xhat_scratch,
-                    dump_xhat ? dump_xhat + size_t(off) * n : nullptr, std::min(nb * r0, h->n_cu), base,
-                    cap, h->stream));
-            }
+        // correlate stage: one fused launch (sub-transforms + combination per workgroup) does
+        // every batch with at least one carrier-positive block per workgroup; smaller ones fall
+        // to the two-kernel form, in chunks of work-list slots (one chunk's d_k0 exchange stays
+        // in the Infinity Cache between the two kernels).  Each form returns at once when the
+        // batch is the other's (the work count lives on the device).
+        const int fused_grid = std::min(nb, h->n_cu);
+        float2* dcorr = dump_corr ? dump_corr + size_t(off) * n : nullptr;
+        float2* dxhat = dump_xhat ? dump_xhat + size_t(off) * n : nullptr;
+        {
+            ProfScope p(h, 2);
+            HIP_TRY(thr::launch_correlate_long(true, format, in, h->dev, h->d_tables, h->d_twn,
+                                               h->d_tspec, h->d_shifts, h->d_work_list,
+                                               h->d_work_count, h->d_dsub, h->d_xhat_scratch, dxhat,
+                                               h->d_corr_stats, dcorr, dump_template, fused_grid, 0,
+                                               nb, fused_grid, h->stream));
+        }
+        for (int base = 0; base < fused_grid; base += h->long_chunk) {   // (fewer than fused_grid slots)
+            const int cap = std::min(h->long_chunk, fused_grid - base);
             ProfScope p(h, 4);
+            HIP_TRY(thr::launch_correlate_long(false, format, in, h->dev, h->d_tables, h->d_twn,
+                                               h->d_tspec, h->d_shifts, h->d_work_list,
+                                               h->d_work_count, h->d_dsub, h->d_xhat_scratch, dxhat,
+                                               h->d_corr_stats, dcorr, dump_template,
+                                               std::min(nb * r0, h->n_cu), base, cap, fused_grid,
+                                               h->stream));
             HIP_TRY(thr::launch_combine_long(h->dev, h->d_twn, h->d_work_list, h->d_work_count,
-                                             h->d_dsub, h->d_corr_stats,
-                                             dump_corr ? dump_corr + size_t(off) * n : nullptr,
-                                             dump_template, base, cap, h->stream));
+                                             h->d_dsub, h->d_corr_stats, dcorr, dump_template, base,
+                                             cap, fused_grid, h->stream));
         }
         {
             ProfScope p(h, 3);
@@ -844,7 +854,9 @@ static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out
             h->long_chunk = std::min(h->long_batch, thr::long_chunk_blocks(n, s->n_templates));
             if (getenv("THR_LONG_CHUNK")) h->long_chunk = std::max(1, std::min(h->long_batch, atoi(getenv("THR_LONG_CHUNK"))));
             const size_t lc = size_t(h->long_chunk);
-            CREATE_TRY(hipMalloc(&h->d_dsub, lc * s->n_templates * size_t(n) * sizeof(float2)));
+            // (one chunk of the two-kernel form, or one row per workgroup of the fused form)
+            const size_t rows = std::max(lc, size_t(std::min(h->long_batch, h->n_cu)));
+            CREATE_TRY(hipMalloc(&h->d_dsub, rows * s->n_templates * size_t(n) * sizeof(float2)));
             CREATE_TRY(hipMalloc(&h->d_xhat_scratch, size_t(h->n_cu) * 16384 * sizeof(float2)));
         }
         if (!h->fast && !h->lng) {

@@ -113,16 +113,22 @@ hipError_t launch_carrier_long(int fmt, const void* samples, int n_blocks, const
                                const float2* tables, const float2* twn, float* win_pow,
                                float* partial, CarStats* stats, float2* dump_fft, int grid,
                                hipStream_t stream);
-// one chunk of work-list slots [base, base + cap): sub-transforms -> dsub, then the combination
-hipError_t launch_correlate_long(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,
+// correlate stage.  fused: ONE launch over the whole work list; the workgroup that runs a block's
+// R0 sub-transforms combines them too (dsub: one row of T x block_len per workgroup); it leaves
+// batches with fewer carrier-positive blocks than `grid` alone.  !fused: one chunk of work-list
+// slots [base, base + cap): sub-transforms -> dsub, then launch_combine_long; both return at once
+// when the work count is >= fused_grid (the fused launch has done the batch).
+hipError_t launch_correlate_long(bool fused, int fmt, const void* samples, const DevCfg& cfg,
                                  const float2* tables, const float2* twn, const float4* tspec,
                                  const ShiftParams* shifts, const int* work_list,
                                  const int* work_count, float2* dsub, float4* xhat_scratch,
-                                 float2* dump_xhat, int grid, int base, int cap, hipStream_t stream);
+                                 float2* dump_xhat, CorrStats* corr_stats, float2* dump_corr,
+                                 int dump_template, int grid, int base, int cap, int fused_grid,
+                                 hipStream_t stream);
 hipError_t launch_combine_long(const DevCfg& cfg, const float2* twn, const int* work_list,
                                const int* work_count, const float2* dsub, CorrStats* corr_stats,
                                float2* dump_corr, int dump_template, int base, int cap,
-                               hipStream_t stream);
+                               int fused_grid, hipStream_t stream);
 int long_chunk_blocks(int block_len, int n_templates);
 
 // detect_small.hip (block_len = 1024, 2048, 4096, 8192: 16 / R1 blocks per workgroup in LDS)

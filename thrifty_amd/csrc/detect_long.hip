@@ -58,14 +58,15 @@ struct RawLong {
     // Infinity Cache for each of them.
     static constexpr bool HELD = FMT == THR_IN_U8 && GEN;
     unsigned w[HELD ? R0 : 1][HELD ? R1 : 1];
-    __device__ __forceinline__ void fetch() {
+    __device__ __forceinline__ void fetch() { fetch_from(blk, t); }
+    __device__ __forceinline__ void fetch_from(const void* src, int tt) {
         if constexpr (HELD) {
 #pragma unroll
             for (int n0 = 0; n0 < R0; ++n0)
 #pragma unroll
                 for (int n1 = 0; n1 < R1; ++n1)
-                    w[n0][n1] = reinterpret_cast<const unsigned*>(blk)[size_t(n0) * (M / 2) +
-                                                                       size_t(n1) * (S1 / 2) + t];
+                    w[n0][n1] = reinterpret_cast<const unsigned*>(src)[size_t(n0) * (M / 2) +
+                                                                       size_t(n1) * (S1 / 2) + tt];
         }
     }
     __device__ __forceinline__ void prepare() {
@@ -474,23 +475,299 @@ __global__ __launch_bounds__(256) void k_select(int r0, DevCfg cfg, const float*
     }
 }
 
+constexpr int CMB_T = 512;   // threads of the combination (== NT: the fused form runs it in place)
+
+// corr[n0 M + m] = sum_k0 W_R0^(-n0 k0) conj(W_NL^(m k0)) d_k0[m]; windowed first-max, sums
+template <int R0>
+__device__ __forceinline__ void combine_at(const cpx* __restrict__ d, const cpx* __restrict__ twn,
+                                           int m, int nl_mask, cpx (&out)[R0]) {
+    cpx u[R0];
+    u[0] = d[m];
+#pragma unroll
+    for (int k0 = 1; k0 < R0; ++k0) u[k0] = cmulc(d[size_t(k0) * M + m], twn[(m * k0) & nl_mask]);
+    dft_dif<R0, +1>(u);
+#pragma unroll
+    for (int n0 = 0; n0 < R0; ++n0) out[n0] = u[brev(n0, R0)];
+}
+
+// HBM / Infinity-Cache-bound byte work (8 R0 M bytes read per (slot, template), ~30 flop per
+// 32 bytes): 512 threads, two adjacent lags per thread and step (one 16-byte load per
+// sub-transform).  (Measured and dropped: running it on a second stream under the
+// sub-transforms of the next chunk -- 1.74 M blocks/s at N = 65536 against 1.71 M serial; with
+// the raw block held in registers by k_correlate_sub, 230 VGPRs, the two kernels no longer fit
+// on a CU together and serial order wins: 1.78 M against 1.18 M.)
+// The combination twiddles that are the same for every thread: stab[i (R0 - 1) + k0 - 1] =
+// W_NL^(1024 i k0), i = 0 .. 15 -- 16 (R0 - 1) numbers in LDS, written once per kernel.
+template <int R0>
+__device__ __forceinline__ void combine_table(cpx* stab, const cpx* __restrict__ twn) {
+    const int i = threadIdx.x;
+    if (i < 16 * (R0 - 1))
+        stab[i] = twn[(2 * CMB_T * (i / (R0 - 1)) * (i % (R0 - 1) + 1)) & (R0 * M - 1)];
+}
+
+// End of a combination: the R0 running maxima of a thread meet in one (power, -lag) key, the
+// workgroup reduces it (ONE barrier), and three threads write the peak and its two neighbours
+// (recombined from the parked rows `d`: one lag each, nobody waits for them).
+template <int R0, bool WANT_STD>
+__device__ __forceinline__ void combine_finish(const DevCfg& cfg, const cpx* __restrict__ twn,
+                                               const cpx* d, int b, int tpl,
+                                               CorrStats* __restrict__ corr_stats,
+                                               const float (&bp)[R0], const int (&bn)[R0],
+                                               float (&sums)[2], int tid, unsigned char* scratch,
+                                               int parity) {
+    const int NL = R0 * M, nl_mask = NL - 1;
+    unsigned long long best = 0;
+#pragma unroll
+    for (int n0 = 0; n0 < R0; ++n0) {
+        // key 0 for "no lag inside the window" (bp = -1: the only negative power), as mask
+        // arithmetic: a 64-bit select here becomes a branch, and LLVM sinks the arithmetic of the
+        // other R0 - 1 chains below it -- with every radix-R0 intermediate spilled across
+        const unsigned bits = __float_as_uint(bp[n0]);
+        const unsigned valid = ~unsigned(int(bits) >> 31);
+        const unsigned long long key =
+            ((unsigned long long)(bits & valid) << 32) | ((0xFFFFFFFFu - unsigned(bn[n0])) & valid);
+        best = key > best ? key : best;
+    }
+    double tot[2] = {0, 0};
+    if constexpr (WANT_STD) {
+        block_reduce<2, CMB_T / 64>(sums, tot, best, scratch, parity);
+    } else {
+        block_reduce_max<CMB_T / 64>(best, scratch, parity);
+    }
+    if (tid < 3) {
+        CorrStats* cs = corr_stats + size_t(b) * cfg.n_templates + tpl;
+        const int pk = int(0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu));
+        const int n = pk - 1 + tid;
+        float v = 0.f;
+        if (n >= 0 && n < NL) {
+            cpx c[R0];
+            combine_at<R0>(d, twn, n % M, nl_mask, c);
+            cpx sel = c[0];
+#pragma unroll
+            for (int n0 = 1; n0 < R0; ++n0) sel = (n / M == n0) ? c[n0] : sel;
+            v = cnorm(sel);
+        }
+        cs->m2[tid] = v;
+        if (tid == 0) {
+            cs->pm2 = __uint_as_float(unsigned(best >> 32));
+            cs->pk = pk;
+            cs->sum_mag = (float)tot[0];
+            cs->sum_mag2 = (float)tot[1];
+        }
+    }
+}
+
+// One (block, template): combine the R0 sub-transform outputs `d` ([R0][M]), windowed first-max,
+// optional std sums, the peak's neighbours -> corr_stats.  All CMB_T threads of the workgroup.
+template <int R0, bool WANT_STD, bool DUMPC>
+__device__ __forceinline__ void combine_impl(const DevCfg& cfg, const cpx* __restrict__ twn,
+                                             const cpx* stab, const cpx* d, int b, int tpl,
+                                             CorrStats* __restrict__ corr_stats,
+                                             cpx* __restrict__ dump_corr, unsigned char* scratch,
+                                             int parity) {
+    const int T = cfg.n_templates;
+    const int NL = R0 * M, nl_mask = NL - 1;
+    float sums[2] = {0.f, 0.f};
+    const unsigned win_w = unsigned(cfg.corr_hi - cfg.corr_lo);
+    // The thread's lags are n = n0 M + m (+ 1), m = 2 tid + 1024 i, i = 0 .. 15: inside one n0 they
+    // come in increasing order, so a running (power, lag) per n0 with a strict '>' keeps the
+    // first maximum; the R0 of them meet in one key at the end.
+    float bp[R0];
+    int bn[R0];
+#pragma unroll
+    for (int n0 = 0; n0 < R0; ++n0) { bp[n0] = -1.f; bn[n0] = 0; }
+    // Combination twiddles W_NL^(m k0) = W_NL^(2 tid k0) * W_NL^(1024 i k0): the first factor is
+    // gathered once per block (2 (R0 - 1) loads), the second is the same for every thread (stab,
+    // LDS broadcast) -- one complex product per use instead of a gather from the 8 NL-byte root
+    // table.  And the loads of UN steps are issued together: with one workgroup per CU (the fused
+    // form) nothing else hides their latency.
+    const int tid = opaque_tid();   // (keeps the per-thread twiddles out of the caller's block loop)
+    cpx wb0[R0], wb1[R0];
+#pragma unroll
+    for (int k0 = 1; k0 < R0; ++k0) {
+        wb0[k0] = twn[(2 * tid * k0) & nl_mask];
+        wb1[k0] = twn[((2 * tid + 1) * k0) & nl_mask];
+    }
+    constexpr int STEPS = M / (2 * CMB_T), UN = 4;
+    static_assert(STEPS % UN == 0, "combination steps come in groups of UN");
+#pragma unroll 1
+    for (int i0 = 0; i0 < STEPS; i0 += UN) {
+        f4 q[UN][R0];
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int k0 = 0; k0 < R0; ++k0)
+                q[u][k0] = *reinterpret_cast<const f4*>(d + size_t(k0) * M + 2 * tid +
+                                                        2 * CMB_T * (i0 + u));
+        cpx s[UN][R0];
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int k0 = 1; k0 < R0; ++k0) s[u][k0] = stab[(i0 + u) * (R0 - 1) + k0 - 1];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int m = 2 * tid + 2 * CMB_T * (i0 + u);
+            cpx u0[R0], u1[R0];
+            u0[0] = cpx{q[u][0].x, q[u][0].y};
+            u1[0] = cpx{q[u][0].z, q[u][0].w};
+#pragma unroll
+            for (int k0 = 1; k0 < R0; ++k0) {
+                u0[k0] = cmulc(cpx{q[u][k0].x, q[u][k0].y}, cmul(wb0[k0], s[u][k0]));
+                u1[k0] = cmulc(cpx{q[u][k0].z, q[u][k0].w}, cmul(wb1[k0], s[u][k0]));
+            }
+            dft_dif<R0, +1>(u0);
+            dft_dif<R0, +1>(u1);
+#pragma unroll
+            for (int n0 = 0; n0 < R0; ++n0) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const cpx c = e ? u1[brev(n0, R0)] : u0[brev(n0, R0)];
+                    const int n = n0 * M + m + e;
+                    const float pw = cnorm(c);
+                    const bool take = (unsigned(n - cfg.corr_lo) < win_w) & (pw > bp[n0]);   // (&: no branch)
+                    bp[n0] = take ? pw : bp[n0];
+                    bn[n0] = take ? n : bn[n0];
+                    if constexpr (WANT_STD) {
+                        if (n < cfg.corr_len) {
+                            sums[1] += pw;
+                            sums[0] += __builtin_amdgcn_sqrtf(pw);
+                        }
+                    }
+                    if constexpr (DUMPC) dump_corr[size_t(b) * NL + n] = c;
+                }
+            }
+        }
+    }
+    combine_finish<R0, WANT_STD>(cfg, twn, d, b, tpl, corr_stats, bp, bn, sums, tid, scratch, parity);
+}
+
+template <int R0>
+__device__ __forceinline__ void combine_block(const DevCfg& cfg, const cpx* __restrict__ twn,
+                                              const cpx* stab, const cpx* d, int b, int tpl,
+                                              CorrStats* __restrict__ corr_stats,
+                                              cpx* __restrict__ dump_corr, int dump_template,
+                                              unsigned char* scratch, int parity) {
+    // (the two run-time options once per block, not once per lag)
+    if (dump_corr != nullptr && tpl == dump_template)
+        combine_impl<R0, true, true>(cfg, twn, stab, d, b, tpl, corr_stats, dump_corr, scratch, parity);
+    else if (cfg.cor_want_std)
+        combine_impl<R0, true, false>(cfg, twn, stab, d, b, tpl, corr_stats, nullptr, scratch, parity);
+    else
+        combine_impl<R0, false, false>(cfg, twn, stab, d, b, tpl, corr_stats, nullptr, scratch, parity);
+}
+
+// The fused form's combination, in the thread that produced the rows: after pass C of a block's
+// LAST sub-transform a thread holds d_{R0-1}[m] for its 32 lags m = n1 1024 + 2t (+ 1) in
+// registers (c0, c1), and the same lags of d_0 .. d_{R0-2} are what IT wrote to `rows` when those
+// sub-transforms ended -- own writes, program order, no barrier.  They come back four n1 at a time,
+// the next four requested before the current four are combined; the caller ends with
+// combine_finish.  wb0 / wb1: W_NL^((2t + e) k0), the thread's own factors of the combination
+// twiddles (kept for the whole kernel).  (No std sums, no stage dump:
+// batches that want either take the from-memory form -- one variant here, on purpose: with three
+// behind a run-time choice LLVM hoists their common arithmetic above the branch and spills all
+// 128 combined lags.)
+template <int R0>
+__device__ __forceinline__ void combine_own(const DevCfg& cfg, const cpx* stab, const f4* rows,
+                                            const cpx* c0, const cpx* c1, const cpx (&wb0)[R0],
+                                            const cpx (&wb1)[R0], float (&bp)[R0], int (&bn)[R0]) {
+    const unsigned win_w = unsigned(cfg.corr_hi - cfg.corr_lo);
+#pragma unroll
+    for (int n0 = 0; n0 < R0; ++n0) { bp[n0] = -1.f; bn[n0] = 0; }
+    const int tid = opaque_tid();
+    constexpr int G = 2;     // n1 per group
+    constexpr int AHEAD = 2; // groups requested ahead of the one being combined (their latency --
+                             // rows this CU wrote tens of microseconds ago, long out of L2 -- is
+                             // 1.5 - 2 us, a group's arithmetic 0.7 us)
+    constexpr int NG = R1 / G;
+    f4 q[AHEAD + 1][G][R0 - 1];
+    auto request = [&](auto GRP) {
+        constexpr int g = decltype(GRP)::value;
+        constexpr int buf = g % (AHEAD + 1);
+        static_for<G>([&](auto JI) {
+            constexpr int j = decltype(JI)::value;
+            static_for<R0 - 1>([&](auto KI) {
+                constexpr int k0 = decltype(KI)::value;
+                q[buf][j][k0] = rows[size_t(k0) * (M / 2) + (g * G + j) * (S1 / 2) + tid];
+            });
+        });
+    };
+    static_for<AHEAD>([&](auto GI) { request(GI); });
+    static_for<NG>([&](auto GI) {
+        constexpr int g = decltype(GI)::value;
+        constexpr int buf = g % (AHEAD + 1);
+        if constexpr (g + AHEAD < NG) request(std::integral_constant<int, g + AHEAD>{});
+        __builtin_amdgcn_sched_barrier(0);   // (AHEAD groups ahead, not all sixteen rows at once)
+        static_for<G>([&](auto JI) {
+            constexpr int n1 = g * G + decltype(JI)::value;
+            constexpr int j = decltype(JI)::value;
+            const int m = n1 * S1 + 2 * tid;
+            cpx u0[R0], u1[R0];
+            u0[0] = cpx{q[buf][j][0].x, q[buf][j][0].y};
+            u1[0] = cpx{q[buf][j][0].z, q[buf][j][0].w};
+#pragma unroll
+            for (int k0 = 1; k0 < R0; ++k0) {
+                const cpx s = stab[n1 * (R0 - 1) + k0 - 1];
+                const cpx a0 = k0 < R0 - 1 ? cpx{q[buf][j][k0 < R0 - 1 ? k0 : 0].x, q[buf][j][k0 < R0 - 1 ? k0 : 0].y}
+                                           : c0[brev(n1, R1)];
+                const cpx a1 = k0 < R0 - 1 ? cpx{q[buf][j][k0 < R0 - 1 ? k0 : 0].z, q[buf][j][k0 < R0 - 1 ? k0 : 0].w}
+                                           : c1[brev(n1, R1)];
+                u0[k0] = cmulc(a0, cmul(wb0[k0], s));
+                u1[k0] = cmulc(a1, cmul(wb1[k0], s));
+            }
+            dft_dif<R0, +1>(u0);
+            dft_dif<R0, +1>(u1);
+#pragma unroll
+            for (int n0 = 0; n0 < R0; ++n0) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const cpx c = e ? u1[brev(n0, R0)] : u0[brev(n0, R0)];
+                    const int n = n0 * M + m + e;
+                    const float pw = cnorm(c);
+                    const bool take = (unsigned(n - cfg.corr_lo) < win_w) & (pw > bp[n0]);   // (&: no branch)
+                    bp[n0] = take ? pw : bp[n0];
+                    bn[n0] = take ? n : bn[n0];
+                }
+            }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
 // =========================================================================
 // correlation stage of one sub-transform: shift, FFT, x template, inverse -> d_k0[m]
 // =========================================================================
-template <int FMT, int R0, bool DUMP>
+// FUSED: one launch over the whole work list; a workgroup runs the R0 sub-transforms of a block
+// back to back (block-major order), parks their outputs in ITS OWN exchange rows (dsub row
+// blockIdx.x: written and read back by the same CU, L2 / Infinity-Cache traffic that overlaps
+// the other CUs' transforms) and combines them at once -- no second kernel, no chunking, and the
+// bandwidth-bound combination of one CU runs under the VALU/LDS-bound transforms of the others.
+// Needs at least one block per workgroup (n_work >= gridDim.x); smaller batches spread the
+// sub-transforms of a block over several workgroups and take the two-kernel form (!FUSED, then
+// k_combine), which returns at once when the fused kernel has done the batch.
+// MULTI = false (fused only): exactly one template, no std sums, no stage dump -- the last
+// sub-transform's outputs are combined straight from the registers of the thread that produced
+// them (combine_own); otherwise (several templates: the shifted spectrum stays live across the
+// template loop, 64 VGPRs) the rows are combined from memory after it (combine_block), as the
+// two-kernel form does.
+template <int FMT, int R0, bool DUMP, bool FUSED, bool MULTI = true>
 __global__ __launch_bounds__(NT) void k_correlate_sub(
     const void* __restrict__ samples, DevCfg cfg, const cpx* __restrict__ tables,
     const cpx* __restrict__ twn, const f4* __restrict__ tspec,
     const ShiftParams* __restrict__ shifts, const int* __restrict__ work_list,
-    const int* __restrict__ work_count, int slot_base, int slot_cap,
-    f4* __restrict__ dsub,           // [slot - slot_base][tpl][k0][M/2] float4
-    f4* __restrict__ xhat_scratch, cpx* __restrict__ dump_xhat) {
+    const int* __restrict__ work_count, int slot_base, int slot_cap, int fused_grid,
+    f4* dsub,           // [slot - slot_base | workgroup][tpl][k0][M/2] float4
+    f4* __restrict__ xhat_scratch, cpx* __restrict__ dump_xhat, CorrStats* __restrict__ corr_stats,
+    cpx* __restrict__ dump_corr, int dump_template) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cpx* lds = reinterpret_cast<cpx*>(smem_raw);
     unsigned char* sc_red = reinterpret_cast<unsigned char*>(lds + OFF_S);
     float2* sc_rp0 = reinterpret_cast<float2*>(sc_red + 2 * red_slot_bytes<NT / 64>());  // 2 x (16 + R0)
 
     load_tables(lds, tables);
+    // (scratch map: [0, 512) reductions, [512, 832) item factors, [1024, 1024 + 128 (R0 - 1)) the
+    // combination's uniform twiddles)
+    cpx* stab = reinterpret_cast<cpx*>(sc_red + 1024);
+    if constexpr (FUSED) combine_table<R0>(stab, twn);
     __syncthreads();
     const int NL = R0 * M, nl_mask = NL - 1;
     const size_t blk_bytes = cfg.blk_stride;
@@ -502,9 +779,23 @@ __global__ __launch_bounds__(NT) void k_correlate_sub(
     // runs in chunks small enough for the d_k0 exchange to stay in the Infinity Cache
     // (`work_list` already points at slot_base)
     const int n_work = max(0, min(*work_count - slot_base, slot_cap));
-    const int T = cfg.n_templates;
+    const int T = MULTI ? cfg.n_templates : 1;
+    if constexpr (FUSED) {
+        if (n_work < int(gridDim.x)) return;        // (the two-kernel form does this batch)
+    } else {
+        if (*work_count >= fused_grid) return;      // (the fused kernel has done it)
+    }
 
-    const bool per_block = n_work >= int(gridDim.x);
+    const bool per_block = FUSED || n_work >= int(gridDim.x);
+    int parity = 0;
+    cpx wb0[R0], wb1[R0];   // combine_own's per-thread twiddle factors
+    if constexpr (FUSED && !MULTI) {
+#pragma unroll
+        for (int k0 = 1; k0 < R0; ++k0) {
+            wb0[k0] = twn[(2 * int(threadIdx.x) * k0) & nl_mask];
+            wb1[k0] = twn[((2 * int(threadIdx.x) + 1) * k0) & nl_mask];
+        }
+    }
     const int n_iter = per_block ? ((n_work - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x)) * R0
                                  : (n_work * R0 - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x);
     for (int it = 0; it < n_iter; ++it) {
@@ -520,7 +811,9 @@ __global__ __launch_bounds__(NT) void k_correlate_sub(
         float2* sc_g = sc_rp + 16;
         item_factors<R0>(sc_rp, sc_g, sp, twn, k0, nl_mask);
         // per-thread phasor for m' = 2t, 2t+1: c0 * exp(2 pi i s m'/NL) [per block] * W_NL^(m' k0)
-        if (b != ph_block) {
+        // (fused: a workgroup's items are whole blocks, k0 = 0 .. R0 - 1 -- stated as such, the
+        // per-block registers are dead during the combination that follows the last k0)
+        if (FUSED ? k0 == 0 : b != ph_block) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int m = 2 * t + e;
@@ -539,7 +832,9 @@ __global__ __launch_bounds__(NT) void k_correlate_sub(
         raw.g = sc_g;
         raw.t = t;
         raw.k0 = k0;
-        if (b != raw_block) {   // block-major work order: once per R0 sub-transforms
+        // block-major work order: the raw block is fetched once per R0 sub-transforms -- fused: the
+        // workgroup's first block here, every later one at the end of the block before it (below)
+        if (FUSED ? it == 0 : b != raw_block) {
             raw.fetch();
             raw_block = b;
         }
@@ -579,112 +874,86 @@ __global__ __launch_bounds__(NT) void k_correlate_sub(
             __syncthreads();
             cpx c0[R1], c1[R1];
             inv_passC(lds, c0, c1);
-            f4* out = dsub + ((size_t(slot) * T + tpl) * R0 + k0) * (M / 2) + t;
+            const int row = FUSED ? int(blockIdx.x) : slot;
+            f4* out = dsub + ((size_t(row) * T + tpl) * R0 + k0) * (M / 2) + t;
+            // (fused, last sub-transform: this row is read back only by the three threads that
+            // recombine the peak's neighbours, behind the reduction barrier)
             static_for<R1>([&](auto K) {
                 constexpr int n1 = decltype(K)::value;
                 out[n1 * (S1 / 2)] = f4{c0[brev(n1, R1)].x, c0[brev(n1, R1)].y, c1[brev(n1, R1)].x,
                                         c1[brev(n1, R1)].y};
             });
+            if constexpr (FUSED && !MULTI) {
+                if (k0 == R0 - 1) {
+#ifdef THR_DEV_ABLATE
+                    if (cfg.ablate == 21) continue;   // dev: the sub-transforms alone
+#endif
+                    const f4* rows = dsub + (size_t(blockIdx.x) * T + tpl) * (size_t(R0) * (M / 2));
+                    float bp[R0];
+                    int bn[R0];
+                    combine_own<R0>(cfg, stab, rows, c0, c1, wb0, wb1, bp, bn);
+                    // the workgroup's next block: its raw words are requested here, between the
+                    // lags and the reduction -- their latency hides under the reduction, the
+                    // neighbour recombination and the next block's preamble (earlier, their 16 R0
+                    // registers would be live through the combination)
+                    // (after the last block: the same block again, harmless -- a branch here
+                    // makes LLVM sink the tails of the R0 lag chains below it, spills and all)
+                    raw.fetch_from(static_cast<const unsigned char*>(samples) +
+                                       size_t(work_list[it + 1 < n_iter ? slot + int(gridDim.x) : slot]) *
+                                           blk_bytes,
+                                   opaque_tid());
+                    float nosums[2] = {0.f, 0.f};
+                    combine_finish<R0, false>(cfg, twn, reinterpret_cast<const cpx*>(rows), b, tpl,
+                                              corr_stats, bp, bn, nosums, opaque_tid(), sc_red, parity);
+                    parity ^= 1;
+                }
+            }
+        }
+        if constexpr (FUSED && MULTI) {
+            if (k0 == R0 - 1) {
+                // all R0 x T rows of this block are written; the barrier makes them visible to the
+                // workgroup (same CU, same L1).  The next block's first stores come several
+                // barriers after these reads.
+                __syncthreads();
+                for (int tpl = 0; tpl < T; ++tpl) {
+                    combine_block<R0>(cfg, twn, stab,
+                                      reinterpret_cast<const cpx*>(dsub) +
+                                          (size_t(blockIdx.x) * T + tpl) * (size_t(R0) * M),
+                                      b, tpl, corr_stats, dump_corr, dump_template, sc_red, parity);
+                    parity ^= 1;
+                }
+            }
+        }
+        if constexpr (FUSED && MULTI) {
+            // the workgroup's next block: its raw words are requested at the end of the block
+            // before it
+            if (k0 == R0 - 1 && it + 1 < n_iter)
+                raw.fetch_from(static_cast<const unsigned char*>(samples) +
+                                   size_t(work_list[slot + int(gridDim.x)]) * blk_bytes, opaque_tid());
         }
     }
 }
 
-// corr[n0 M + m] = sum_k0 W_R0^(-n0 k0) conj(W_NL^(m k0)) d_k0[m]; windowed first-max, sums
-template <int R0>
-__device__ __forceinline__ void combine_at(const cpx* __restrict__ d, const cpx* __restrict__ twn,
-                                           int m, int nl_mask, cpx (&out)[R0]) {
-    cpx u[R0];
-    u[0] = d[m];
-#pragma unroll
-    for (int k0 = 1; k0 < R0; ++k0) u[k0] = cmulc(d[size_t(k0) * M + m], twn[(m * k0) & nl_mask]);
-    dft_dif<R0, +1>(u);
-#pragma unroll
-    for (int n0 = 0; n0 < R0; ++n0) out[n0] = u[brev(n0, R0)];
-}
-
-// HBM / Infinity-Cache-bound byte work (8 R0 M bytes read per (slot, template), ~30 flop per
-// 32 bytes): 512 threads, two adjacent lags per thread and step (one 16-byte load per
-// sub-transform).  (Measured and dropped: running it on a second stream under the
-// sub-transforms of the next chunk -- 1.74 M blocks/s at N = 65536 against 1.71 M serial; with
-// the raw block held in registers by k_correlate_sub, 230 VGPRs, the two kernels no longer fit
-// on a CU together and serial order wins: 1.78 M against 1.18 M.)
-constexpr int CMB_T = 512;
+// Combination as its own kernel: one workgroup per (slot, template) of a chunk.  Batches with
+// fewer carrier-positive blocks than `fused_grid` only -- larger ones are combined by the
+// workgroup that ran the block's sub-transforms (k_correlate_sub<..., FUSED>).
 template <int R0>
 __global__ __launch_bounds__(CMB_T) void k_combine(DevCfg cfg, const cpx* __restrict__ twn,
                                                    const cpx* __restrict__ dsub,
                                                    const int* __restrict__ work_list,
                                                    const int* __restrict__ work_count,
-                                                   int slot_base, CorrStats* __restrict__ corr_stats,
+                                                   int slot_base, int fused_grid,
+                                                   CorrStats* __restrict__ corr_stats,
                                                    cpx* __restrict__ dump_corr, int dump_template) {
     __shared__ __attribute__((aligned(16))) unsigned char scratch[2 * (CMB_T / 64) * 32];
+    __shared__ cpx stab[16 * (R0 - 1)];
     const int T = cfg.n_templates;
     const int slot = blockIdx.x / T, tpl = blockIdx.x % T;   // chunk-local; work_list points at slot_base
-    if (slot_base + slot >= *work_count) return;
-    const int b = work_list[slot];
-    const int NL = R0 * M, nl_mask = NL - 1;
-    const cpx* d = dsub + (size_t(slot) * T + tpl) * NL;
-    float sums[2] = {0.f, 0.f};
-    const unsigned win_w = unsigned(cfg.corr_hi - cfg.corr_lo);
-    // n0-major order would visit lags out of order; ties are resolved through the key instead
-    unsigned long long best = 0;
-    for (int m = 2 * threadIdx.x; m < M; m += 2 * CMB_T) {
-        cpx u0[R0], u1[R0];
-        {
-            const f4 q = *reinterpret_cast<const f4*>(d + m);
-            u0[0] = cpx{q.x, q.y};
-            u1[0] = cpx{q.z, q.w};
-        }
-#pragma unroll
-        for (int k0 = 1; k0 < R0; ++k0) {
-            const f4 q = *reinterpret_cast<const f4*>(d + size_t(k0) * M + m);
-            u0[k0] = cmulc(cpx{q.x, q.y}, twn[(m * k0) & nl_mask]);
-            u1[k0] = cmulc(cpx{q.z, q.w}, twn[((m + 1) * k0) & nl_mask]);
-        }
-        dft_dif<R0, +1>(u0);
-        dft_dif<R0, +1>(u1);
-#pragma unroll
-        for (int n0 = 0; n0 < R0; ++n0) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const cpx c = e ? u1[brev(n0, R0)] : u0[brev(n0, R0)];
-                const int n = n0 * M + m + e;
-                const float pw = cnorm(c);
-                if (unsigned(n - cfg.corr_lo) < win_w) {
-                    const unsigned long long key =
-                        ((unsigned long long)__float_as_uint(pw) << 32) | (0xFFFFFFFFu - unsigned(n));
-                    best = key > best ? key : best;
-                }
-                if (cfg.cor_want_std && n < cfg.corr_len) {
-                    sums[1] += pw;
-                    sums[0] += __builtin_amdgcn_sqrtf(pw);
-                }
-                if (dump_corr != nullptr && tpl == dump_template) dump_corr[size_t(b) * NL + n] = c;
-            }
-        }
-    }
-    double tot[2];
-    block_reduce<2, CMB_T / 64>(sums, tot, best, scratch, 0);
-    if (threadIdx.x == 0) {
-        CorrStats* cs = corr_stats + size_t(b) * T + tpl;
-        const int pk = int(0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu));
-        cs->pm2 = __uint_as_float(unsigned(best >> 32));
-        cs->pk = pk;
-        for (int dd = 0; dd < 3; ++dd) {
-            const int n = pk - 1 + dd;
-            float v = 0.f;
-            if (n >= 0 && n < NL) {
-                cpx c[R0];
-                combine_at<R0>(d, twn, n % M, nl_mask, c);
-                cpx sel = c[0];
-#pragma unroll
-                for (int n0 = 1; n0 < R0; ++n0) sel = (n / M == n0) ? c[n0] : sel;
-                v = cnorm(sel);
-            }
-            cs->m2[dd] = v;
-        }
-        cs->sum_mag = (float)tot[0];
-        cs->sum_mag2 = (float)tot[1];
-    }
+    if (*work_count >= fused_grid || slot_base + slot >= *work_count) return;
+    combine_table<R0>(stab, twn);
+    __syncthreads();
+    combine_block<R0>(cfg, twn, stab, dsub + (size_t(slot) * T + tpl) * (R0 * M), work_list[slot],
+                      tpl, corr_stats, dump_corr, dump_template, scratch, 0);
 }
 
 template <int R0>
@@ -702,10 +971,18 @@ hipError_t prepare_r0() {
         reinterpret_cast<const void*>(&k_carrier_dit<THR_IN_C64, R0>),
         reinterpret_cast<const void*>(&k_carrier_sub_pruned<THR_IN_U8, R0>),
         reinterpret_cast<const void*>(&k_carrier_sub_pruned<THR_IN_C64, R0>),
-        reinterpret_cast<const void*>(&k_correlate_sub<THR_IN_U8, R0, false>),
-        reinterpret_cast<const void*>(&k_correlate_sub<THR_IN_U8, R0, true>),
-        reinterpret_cast<const void*>(&k_correlate_sub<THR_IN_C64, R0, false>),
-        reinterpret_cast<const void*>(&k_correlate_sub<THR_IN_C64, R0, true>)};
+        reinterpret_cast<const void*>(&k_correlate_sub<THR_IN_U8, R0, false, false>),
+        reinterpret_cast<const void*>(&k_correlate_sub<THR_IN_U8, R0, true, false>),
+        reinterpret_cast<const void*>(&k_correlate_sub<THR_IN_C64, R0, false, false>),
+        reinterpret_cast<const void*>(&k_correlate_sub<THR_IN_C64, R0, true, false>),
+        reinterpret_cast<const void*>(&k_correlate_sub<THR_IN_U8, R0, false, true>),
+        reinterpret_cast<const void*>(&k_correlate_sub<THR_IN_U8, R0, true, true>),
+        reinterpret_cast<const void*>(&k_correlate_sub<THR_IN_C64, R0, false, true>),
+        reinterpret_cast<const void*>(&k_correlate_sub<THR_IN_C64, R0, true, true>),
+        reinterpret_cast<const void*>(&k_correlate_sub<THR_IN_U8, R0, false, true, false>),
+        reinterpret_cast<const void*>(&k_correlate_sub<THR_IN_U8, R0, true, true, false>),
+        reinterpret_cast<const void*>(&k_correlate_sub<THR_IN_C64, R0, false, true, false>),
+        reinterpret_cast<const void*>(&k_correlate_sub<THR_IN_C64, R0, true, true, false>)};
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return e;
@@ -754,35 +1031,60 @@ hipError_t carrier_r0(int fmt, const void* samples, int n_blocks, const DevCfg& 
     return hipGetLastError();
 }
 
-template <int R0>
-hipError_t correlate_r0(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,
-                        const float2* tables, const float2* twn, const float4* tspec,
-                        const ShiftParams* shifts, const int* work_list, const int* work_count,
-                        float2* dsub, float4* xhat_scratch, float2* dump_xhat, int grid, int base,
-                        int cap, hipStream_t stream) {
+template <int FMT, int R0>
+hipError_t correlate_launch(bool fused, const void* samples, const DevCfg& cfg, const float2* tables,
+                            const float2* twn, const float4* tspec, const ShiftParams* shifts,
+                            const int* work_list, const int* work_count, float2* dsub,
+                            float4* xhat_scratch, float2* dump_xhat, CorrStats* corr_stats,
+                            float2* dump_corr, int dump_template, int grid, int base, int cap,
+                            int fused_grid, hipStream_t stream) {
     typedef void (*fn_t)(const void*, DevCfg, const cpx*, const cpx*, const f4*, const ShiftParams*,
-                         const int*, const int*, int, int, f4*, f4*, cpx*);
+                         const int*, const int*, int, int, int, f4*, f4*, cpx*, CorrStats*, cpx*, int);
     const bool dump = dump_xhat != nullptr;
-    fn_t fn = fmt == THR_IN_U8
-                  ? (dump ? &k_correlate_sub<THR_IN_U8, R0, true> : &k_correlate_sub<THR_IN_U8, R0, false>)
-                  : (dump ? &k_correlate_sub<THR_IN_C64, R0, true> : &k_correlate_sub<THR_IN_C64, R0, false>);
-    // ONE slot chunk [base, base + cap): dsub / partial_x2 hold one chunk (see long_chunk_blocks);
-    // the caller loops over the chunks and follows each with launch_combine_long
-    hipLaunchKernelGGL(fn, dim3(std::min(grid, cap * R0)), dim3(NT), LDS_BYTES, stream, samples, cfg,
+    fn_t fn = !fused ? (dump ? &k_correlate_sub<FMT, R0, true, false> : &k_correlate_sub<FMT, R0, false, false>)
+              : (cfg.n_templates > 1 || cfg.cor_want_std != 0 || dump_corr != nullptr)
+                  ? (dump ? &k_correlate_sub<FMT, R0, true, true> : &k_correlate_sub<FMT, R0, false, true>)
+                  : (dump ? &k_correlate_sub<FMT, R0, true, true, false>
+                          : &k_correlate_sub<FMT, R0, false, true, false>);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(NT), LDS_BYTES, stream, samples, cfg,
                        reinterpret_cast<const cpx*>(tables), reinterpret_cast<const cpx*>(twn),
                        reinterpret_cast<const f4*>(tspec), shifts, work_list + base, work_count, base,
-                       cap, reinterpret_cast<f4*>(dsub), reinterpret_cast<f4*>(xhat_scratch),
-                       reinterpret_cast<cpx*>(dump_xhat));
+                       cap, fused_grid, reinterpret_cast<f4*>(dsub), reinterpret_cast<f4*>(xhat_scratch),
+                       reinterpret_cast<cpx*>(dump_xhat), corr_stats, reinterpret_cast<cpx*>(dump_corr),
+                       dump_template);
     return hipGetLastError();
+}
+
+// fused: ONE launch over the whole work list, `grid` workgroups, dsub holds `grid` rows.
+// !fused: ONE slot chunk [base, base + cap) (dsub holds one chunk, see long_chunk_blocks); the
+// caller follows it with launch_combine_long.
+template <int R0>
+hipError_t correlate_r0(bool fused, int fmt, const void* samples, const DevCfg& cfg,
+                        const float2* tables, const float2* twn, const float4* tspec,
+                        const ShiftParams* shifts, const int* work_list, const int* work_count,
+                        float2* dsub, float4* xhat_scratch, float2* dump_xhat, CorrStats* corr_stats,
+                        float2* dump_corr, int dump_template, int grid, int base, int cap,
+                        int fused_grid, hipStream_t stream) {
+    const int g = fused ? grid : std::min(grid, cap * R0);
+    return fmt == THR_IN_U8
+               ? correlate_launch<THR_IN_U8, R0>(fused, samples, cfg, tables, twn, tspec, shifts,
+                                                 work_list, work_count, dsub, xhat_scratch, dump_xhat,
+                                                 corr_stats, dump_corr, dump_template, g, base, cap,
+                                                 fused_grid, stream)
+               : correlate_launch<THR_IN_C64, R0>(fused, samples, cfg, tables, twn, tspec, shifts,
+                                                  work_list, work_count, dsub, xhat_scratch, dump_xhat,
+                                                  corr_stats, dump_corr, dump_template, g, base, cap,
+                                                  fused_grid, stream);
 }
 
 template <int R0>
 hipError_t combine_r0(const DevCfg& cfg, const float2* twn, const int* work_list,
-                      const int* work_count, const float2* dsub, CorrStats* corr_stats, float2* dump_corr, int dump_template, int base, int cap,
+                      const int* work_count, const float2* dsub, CorrStats* corr_stats,
+                      float2* dump_corr, int dump_template, int base, int cap, int fused_grid,
                       hipStream_t stream) {
     hipLaunchKernelGGL(k_combine<R0>, dim3(cap * cfg.n_templates), dim3(CMB_T), 0, stream, cfg,
                        reinterpret_cast<const cpx*>(twn), reinterpret_cast<const cpx*>(dsub),
-                       work_list + base, work_count, base, corr_stats,
+                       work_list + base, work_count, base, fused_grid, corr_stats,
                        reinterpret_cast<cpx*>(dump_corr), dump_template);
     return hipGetLastError();
 }
@@ -806,27 +1108,31 @@ hipError_t launch_carrier_long(int fmt, const void* samples, int n_blocks, const
                                dump_fft, grid, stream);
 }
 
-hipError_t launch_correlate_long(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,
+hipError_t launch_correlate_long(bool fused, int fmt, const void* samples, const DevCfg& cfg,
                                  const float2* tables, const float2* twn, const float4* tspec,
                                  const ShiftParams* shifts, const int* work_list,
                                  const int* work_count, float2* dsub, float4* xhat_scratch,
-                                 float2* dump_xhat, int grid, int base, int cap, hipStream_t stream) {
+                                 float2* dump_xhat, CorrStats* corr_stats, float2* dump_corr,
+                                 int dump_template, int grid, int base, int cap, int fused_grid,
+                                 hipStream_t stream) {
     return cfg.block_len == 2 * M
-               ? correlate_r0<2>(fmt, samples, n_blocks, cfg, tables, twn, tspec, shifts, work_list,
-                                 work_count, dsub, xhat_scratch, dump_xhat, grid, base, cap, stream)
-               : correlate_r0<4>(fmt, samples, n_blocks, cfg, tables, twn, tspec, shifts, work_list,
-                                 work_count, dsub, xhat_scratch, dump_xhat, grid, base, cap, stream);
+               ? correlate_r0<2>(fused, fmt, samples, cfg, tables, twn, tspec, shifts, work_list,
+                                 work_count, dsub, xhat_scratch, dump_xhat, corr_stats, dump_corr,
+                                 dump_template, grid, base, cap, fused_grid, stream)
+               : correlate_r0<4>(fused, fmt, samples, cfg, tables, twn, tspec, shifts, work_list,
+                                 work_count, dsub, xhat_scratch, dump_xhat, corr_stats, dump_corr,
+                                 dump_template, grid, base, cap, fused_grid, stream);
 }
 
 hipError_t launch_combine_long(const DevCfg& cfg, const float2* twn, const int* work_list,
                                const int* work_count, const float2* dsub, CorrStats* corr_stats,
                                float2* dump_corr, int dump_template, int base, int cap,
-                               hipStream_t stream) {
+                               int fused_grid, hipStream_t stream) {
     return cfg.block_len == 2 * M
                ? combine_r0<2>(cfg, twn, work_list, work_count, dsub, corr_stats, dump_corr,
-                               dump_template, base, cap, stream)
+                               dump_template, base, cap, fused_grid, stream)
                : combine_r0<4>(cfg, twn, work_list, work_count, dsub, corr_stats, dump_corr,
-                               dump_template, base, cap, stream);
+                               dump_template, base, cap, fused_grid, stream);
 }
 
 // blocks per correlate-stage chunk: the d_k0 exchange (8 * block_len * T bytes per block) of one
