@@ -436,7 +436,7 @@ def main():
         rename = {}
         if pnum:   # the fused kernel is timed in k_correlate's event slot
             rename["k_correlate"] = "k_preshift"
-        if n > 16384:   # long blocks: the correlate slot times the sub-transform kernel, per chunk
+        if n > 16384:   # long blocks: the correlate slot times the fused sub-transform + combination kernel
             rename.update({"k_correlate": "k_correlate_sub", "k_carrier": "k_carrier_dit+k_select_dit"})
         prof = {rename.get(k, k): v for k, v in prof.items() if v[1] > 0}
         dom = max(prof, key=lambda k: prof[k][0]) if prof else None
@@ -446,7 +446,7 @@ def main():
         else:
             avg_ms = dom_ms / dom_cnt
             # blocks one launch of the dominant kernel processes (dense mix: every block reaches
-            # it); the long-block correlate stage launches once per chunk of work-list slots
+            # it)
             units = B * max(profiled_steps, 1) / dom_cnt
         achieved = bytes_per_block * units / (avg_ms * 1e-3) / 1e9
         traffic = None

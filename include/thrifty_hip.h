@@ -234,8 +234,11 @@ int thr_compact_device(thr_handle* h, const thr_record* d_in, size_t n_records,
  * packets out of most steps); 0 disables.  thr_profile_read() syncs and returns accumulated
  * milliseconds and launch counts per kernel slot and resets the accumulators.
  * Slots: 0 = carrier (FFT#1 + peak), 1 = fit, 2 = correlate (FFT#2..peak; long blocks: the
- * sub-transform kernel, one launch per chunk of work-list slots), 3 = finish (SoA),
- * 4 = combine (long blocks only: radix-R0 combination + peak, one launch per chunk).
+ * fused kernel -- a block's R0 sub-transforms and their combination in one workgroup, one
+ * launch per sub-batch), 3 = finish (SoA), 4 = long blocks only: the two-kernel form
+ * (sub-transforms, then combination, per chunk of work-list slots) that takes the sub-batches
+ * with fewer carrier-positive blocks than workgroups; both forms are launched every time and
+ * the one the batch does not belong to returns at once.
  */
 #define THR_N_KERNEL_SLOTS 5
 int thr_profile_enable(thr_handle* h, int on);

@@ -138,7 +138,7 @@ def test_device_resident_path_and_compaction(golden):
     rec = out.cpu().numpy().view(F.RECORD_DTYPE)
     check_against_golden(rec, g)
     prof = eng.profile_read()
-    assert all(cnt == 1 and ms > 0 for k, (ms, cnt) in prof.items() if k != "k_combine"), prof
+    assert all(cnt == 1 and ms > 0 for k, (ms, cnt) in prof.items() if not k.endswith("(small batches)")), prof   # (slot 4: long blocks only)
     kept = torch.zeros_like(out)
     torch.cuda.synchronize()
     n_kept = eng.compact_device(out.data_ptr(), len(g["blocks"]), kept.data_ptr())

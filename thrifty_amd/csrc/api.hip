@@ -704,7 +704,7 @@ const char* thr_last_error(void) { return g_last_error.c_str(); }
 
 const char* thr_kernel_name(int slot) {
     static const char* names[THR_N_KERNEL_SLOTS] = {"k_carrier", "k_fit",    "k_correlate",
-                                                    "k_finish",  "k_combine"};
+                                                    "k_finish",  "k_correlate_sub+k_combine (small batches)"};
     return (slot >= 0 && slot < THR_N_KERNEL_SLOTS) ? names[slot] : "";
 }
 

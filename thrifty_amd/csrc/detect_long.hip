@@ -505,17 +505,9 @@ __device__ __forceinline__ void combine_table(cpx* stab, const cpx* __restrict__
         stab[i] = twn[(2 * CMB_T * (i / (R0 - 1)) * (i % (R0 - 1) + 1)) & (R0 * M - 1)];
 }
 
-// End of a combination: the R0 running maxima of a thread meet in one (power, -lag) key, the
-// workgroup reduces it (ONE barrier), and three threads write the peak and its two neighbours
-// (recombined from the parked rows `d`: one lag each, nobody waits for them).
-template <int R0, bool WANT_STD>
-__device__ __forceinline__ void combine_finish(const DevCfg& cfg, const cpx* __restrict__ twn,
-                                               const cpx* d, int b, int tpl,
-                                               CorrStats* __restrict__ corr_stats,
-                                               const float (&bp)[R0], const int (&bn)[R0],
-                                               float (&sums)[2], int tid, unsigned char* scratch,
-                                               int parity) {
-    const int NL = R0 * M, nl_mask = NL - 1;
+// the R0 running maxima of a thread as one (power, -lag) key
+template <int R0>
+__device__ __forceinline__ unsigned long long combine_key(const float (&bp)[R0], const int (&bn)[R0]) {
     unsigned long long best = 0;
 #pragma unroll
     for (int n0 = 0; n0 < R0; ++n0) {
@@ -528,33 +520,86 @@ __device__ __forceinline__ void combine_finish(const DevCfg& cfg, const cpx* __r
             ((unsigned long long)(bits & valid) << 32) | ((0xFFFFFFFFu - unsigned(bn[n0])) & valid);
         best = key > best ? key : best;
     }
+    return best;
+}
+
+// The peak and its two neighbours, recombined from the parked rows by three threads (one lag
+// each): request() issues their loads -- R0 row values and R0 - 1 root-table twiddles, one
+// round trip of ~2 us -- and complete() turns them into the CorrStats entries.  The fused
+// kernel calls complete() one barrier into the NEXT sub-transform: wave 0 then reaches that
+// barrier without having waited for the round trip, and nobody else waits for wave 0.
+template <int R0>
+struct PeakTail {
+    cpx dv[R0], wv[R0];
+    unsigned long long best = 0;
+    int b = -1, tpl = 0;
+    __device__ __forceinline__ void request(const cpx* __restrict__ twn, const cpx* d, int b_, int tpl_,
+                                            unsigned long long best_, int tid) {
+        b = b_;
+        tpl = tpl_;
+        best = best_;
+        if (tid < 3) {
+            const int NL = R0 * M;
+            const int n = int(0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu)) - 1 + tid;
+            const int m = (n >= 0 && n < NL) ? n % M : 0;
+#pragma unroll
+            for (int k0 = 0; k0 < R0; ++k0) {
+                dv[k0] = d[size_t(k0) * M + m];
+                wv[k0] = twn[(m * k0) & (NL - 1)];
+            }
+        }
+    }
+    __device__ __forceinline__ void complete(const DevCfg& cfg, CorrStats* __restrict__ corr_stats,
+                                             int tid, float sum_mag, float sum_mag2) {
+        if (b >= 0 && tid < 3) {
+            const int NL = R0 * M;
+            CorrStats* cs = corr_stats + size_t(b) * cfg.n_templates + tpl;
+            const int pk = int(0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu));
+            const int n = pk - 1 + tid;
+            float v = 0.f;
+            if (n >= 0 && n < NL) {
+                cpx u[R0];
+                u[0] = dv[0];
+#pragma unroll
+                for (int k0 = 1; k0 < R0; ++k0) u[k0] = cmulc(dv[k0], wv[k0]);
+                dft_dif<R0, +1>(u);
+                cpx sel = u[0];
+#pragma unroll
+                for (int n0 = 1; n0 < R0; ++n0) sel = (n / M == n0) ? u[brev(n0, R0)] : sel;
+                v = cnorm(sel);
+            }
+            cs->m2[tid] = v;
+            if (tid == 0) {
+                cs->pm2 = __uint_as_float(unsigned(best >> 32));
+                cs->pk = pk;
+                cs->sum_mag = sum_mag;
+                cs->sum_mag2 = sum_mag2;
+            }
+        }
+        b = -1;
+    }
+};
+
+// End of a combination: the R0 running maxima of a thread meet in one (power, -lag) key, the
+// workgroup reduces it (ONE barrier), and three threads write the peak and its two neighbours
+// (recombined from the parked rows `d`: one lag each, nobody waits for them).
+template <int R0, bool WANT_STD>
+__device__ __forceinline__ void combine_finish(const DevCfg& cfg, const cpx* __restrict__ twn,
+                                               const cpx* d, int b, int tpl,
+                                               CorrStats* __restrict__ corr_stats,
+                                               const float (&bp)[R0], const int (&bn)[R0],
+                                               float (&sums)[2], int tid, unsigned char* scratch,
+                                               int parity) {
+    unsigned long long best = combine_key<R0>(bp, bn);
     double tot[2] = {0, 0};
     if constexpr (WANT_STD) {
         block_reduce<2, CMB_T / 64>(sums, tot, best, scratch, parity);
     } else {
         block_reduce_max<CMB_T / 64>(best, scratch, parity);
     }
-    if (tid < 3) {
-        CorrStats* cs = corr_stats + size_t(b) * cfg.n_templates + tpl;
-        const int pk = int(0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu));
-        const int n = pk - 1 + tid;
-        float v = 0.f;
-        if (n >= 0 && n < NL) {
-            cpx c[R0];
-            combine_at<R0>(d, twn, n % M, nl_mask, c);
-            cpx sel = c[0];
-#pragma unroll
-            for (int n0 = 1; n0 < R0; ++n0) sel = (n / M == n0) ? c[n0] : sel;
-            v = cnorm(sel);
-        }
-        cs->m2[tid] = v;
-        if (tid == 0) {
-            cs->pm2 = __uint_as_float(unsigned(best >> 32));
-            cs->pk = pk;
-            cs->sum_mag = (float)tot[0];
-            cs->sum_mag2 = (float)tot[1];
-        }
-    }
+    PeakTail<R0> tail;
+    tail.request(twn, d, b, tpl, best, tid);
+    tail.complete(cfg, corr_stats, tid, (float)tot[0], (float)tot[1]);
 }
 
 // One (block, template): combine the R0 sub-transform outputs `d` ([R0][M]), windowed first-max,
@@ -674,6 +719,7 @@ __device__ __forceinline__ void combine_own(const DevCfg& cfg, const cpx* stab, 
 #pragma unroll
     for (int n0 = 0; n0 < R0; ++n0) { bp[n0] = -1.f; bn[n0] = 0; }
     const int tid = opaque_tid();
+    const int rel = 2 * tid - cfg.corr_lo;
     constexpr int G = 2;     // n1 per group
     constexpr int AHEAD = 2; // groups requested ahead of the one being combined (their latency --
                              // rows this CU wrote tens of microseconds ago, long out of L2 -- is
@@ -700,13 +746,15 @@ __device__ __forceinline__ void combine_own(const DevCfg& cfg, const cpx* stab, 
         static_for<G>([&](auto JI) {
             constexpr int n1 = g * G + decltype(JI)::value;
             constexpr int j = decltype(JI)::value;
-            const int m = n1 * S1 + 2 * tid;
             cpx u0[R0], u1[R0];
             u0[0] = cpx{q[buf][j][0].x, q[buf][j][0].y};
             u1[0] = cpx{q[buf][j][0].z, q[buf][j][0].w};
+            cpx sv[R0];   // (the uniform factors of this n1 together: one wait, not one per read)
+#pragma unroll
+            for (int k0 = 1; k0 < R0; ++k0) sv[k0] = stab[n1 * (R0 - 1) + k0 - 1];
 #pragma unroll
             for (int k0 = 1; k0 < R0; ++k0) {
-                const cpx s = stab[n1 * (R0 - 1) + k0 - 1];
+                const cpx s = sv[k0];
                 const cpx a0 = k0 < R0 - 1 ? cpx{q[buf][j][k0 < R0 - 1 ? k0 : 0].x, q[buf][j][k0 < R0 - 1 ? k0 : 0].y}
                                            : c0[brev(n1, R1)];
                 const cpx a1 = k0 < R0 - 1 ? cpx{q[buf][j][k0 < R0 - 1 ? k0 : 0].z, q[buf][j][k0 < R0 - 1 ? k0 : 0].w}
@@ -721,16 +769,19 @@ __device__ __forceinline__ void combine_own(const DevCfg& cfg, const cpx* stab, 
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const cpx c = e ? u1[brev(n0, R0)] : u0[brev(n0, R0)];
-                    const int n = n0 * M + m + e;
+                    // lag n = n0 M + n1 1024 + 2 tid + e: inside the window iff
+                    // unsigned(rel + constant) < win_w; remembered as the inline constant 2 n1 + e
                     const float pw = cnorm(c);
-                    const bool take = (unsigned(n - cfg.corr_lo) < win_w) & (pw > bp[n0]);   // (&: no branch)
+                    const bool take = (unsigned(rel + (n0 * M + n1 * S1 + e)) < win_w) & (pw > bp[n0]);   // (&: no branch)
                     bp[n0] = take ? pw : bp[n0];
-                    bn[n0] = take ? n : bn[n0];
+                    bn[n0] = take ? 2 * n1 + e : bn[n0];
                 }
             }
         });
         __builtin_amdgcn_sched_barrier(0);
     });
+#pragma unroll
+    for (int n0 = 0; n0 < R0; ++n0) bn[n0] = n0 * M + (bn[n0] >> 1) * S1 + 2 * tid + (bn[n0] & 1);
 }
 
 // =========================================================================
@@ -788,6 +839,7 @@ __global__ __launch_bounds__(NT) void k_correlate_sub(
 
     const bool per_block = FUSED || n_work >= int(gridDim.x);
     int parity = 0;
+    PeakTail<R0> tail;      // fused, one template: the previous block's peak, completed a barrier later
     cpx wb0[R0], wb1[R0];   // combine_own's per-thread twiddle factors
     if constexpr (FUSED && !MULTI) {
 #pragma unroll
@@ -841,6 +893,7 @@ __global__ __launch_bounds__(NT) void k_correlate_sub(
         raw.prepare();
         fwd_pass1<true>(lds, raw, sc_rp, p[0], p[1]);
         __syncthreads();
+        if constexpr (FUSED && !MULTI) tail.complete(cfg, corr_stats, opaque_tid(), 0.f, 0.f);
         fwd_pass2(lds);
         __builtin_amdgcn_sched_barrier(0);
         cpx xh[R3];
@@ -891,7 +944,19 @@ __global__ __launch_bounds__(NT) void k_correlate_sub(
                     const f4* rows = dsub + (size_t(blockIdx.x) * T + tpl) * (size_t(R0) * (M / 2));
                     float bp[R0];
                     int bn[R0];
+#ifdef THR_DEV_ABLATE
+                    if (cfg.ablate == 23) {   // dev: no lag loop (finish only)
+#pragma unroll
+                        for (int n0 = 0; n0 < R0; ++n0) { bp[n0] = c0[n0].x; bn[n0] = n0; }
+                    } else
+#endif
                     combine_own<R0>(cfg, stab, rows, c0, c1, wb0, wb1, bp, bn);
+#ifdef THR_DEV_ABLATE
+                    if (cfg.ablate == 22) {   // dev: lag loop, no reduction / neighbours
+                        if (bp[0] + bp[1] == 1.2345f) corr_stats[b].pk = bn[0] + bn[1];
+                        continue;
+                    }
+#endif
                     // the workgroup's next block: its raw words are requested here, between the
                     // lags and the reduction -- their latency hides under the reduction, the
                     // neighbour recombination and the next block's preamble (earlier, their 16 R0
@@ -902,10 +967,10 @@ __global__ __launch_bounds__(NT) void k_correlate_sub(
                                        size_t(work_list[it + 1 < n_iter ? slot + int(gridDim.x) : slot]) *
                                            blk_bytes,
                                    opaque_tid());
-                    float nosums[2] = {0.f, 0.f};
-                    combine_finish<R0, false>(cfg, twn, reinterpret_cast<const cpx*>(rows), b, tpl,
-                                              corr_stats, bp, bn, nosums, opaque_tid(), sc_red, parity);
+                    unsigned long long best = combine_key<R0>(bp, bn);
+                    block_reduce_max<CMB_T / 64>(best, sc_red, parity);
                     parity ^= 1;
+                    tail.request(twn, reinterpret_cast<const cpx*>(rows), b, tpl, best, opaque_tid());
                 }
             }
         }
@@ -932,6 +997,7 @@ __global__ __launch_bounds__(NT) void k_correlate_sub(
                                    size_t(work_list[slot + int(gridDim.x)]) * blk_bytes, opaque_tid());
         }
     }
+    if constexpr (FUSED && !MULTI) tail.complete(cfg, corr_stats, opaque_tid(), 0.f, 0.f);   // (the last block's)
 }
 
 // Combination as its own kernel: one workgroup per (slot, template) of a chunk.  Batches with
