@@ -3,6 +3,7 @@
 import csv
 import glob
 import os
+import re
 import sys
 from collections import defaultdict
 
@@ -10,6 +11,12 @@ root = sys.argv[1]
 
 
 def short(name):
+    # the long-block correlate kernel exists in a fused form (sub-transforms + combination, does
+    # the batch) and a two-kernel form (launched too, returns at once for large batches): 4th
+    # template argument
+    m = re.search(r"k_correlate_sub<\w+, \w+, \w+, (\w+)", name)
+    if m:
+        return "k_correlate_sub" if m.group(1) in ("true", "1") else "k_correlate_sub(two-kernel form)"
     for k in ("k_carrier_pruned", "k_carrier_dit", "k_carrier_sub_pruned", "k_carrier_sub", "k_carrier_small",
               "k_carrier", "k_select_dit", "k_select", "k_fit_preshift", "k_fit", "k_finish",
               "k_correlate_sub", "k_correlate_small", "k_correlate", "k_combine", "k_preshift",
