@@ -92,3 +92,45 @@ def test_long_multi_template_and_c64_input():
                 assert bool(r["flags"] & F.FLAG_CORR) == res.corr.detected
                 np.testing.assert_allclose(r["corr_energy"], res.corr.energy, rtol=1e-4)
                 np.testing.assert_allclose(r["corr_offset"], res.corr.offset, atol=1e-4)
+
+
+@pytest.mark.parametrize("n,n_tpl,fmt_c64,total", [
+    (65536, 1, False, 900),     # fused kernel, several blocks per workgroup (combine_own, PeakTail carry-over)
+    (65536, 1, True, 600),      # ... complex64 input
+    (32768, 1, False, 1200),    # R0 = 2
+    (65536, 3, False, 600),     # several templates: rows combined from memory after the template loop
+])
+def test_large_batches_equal_small_batches(n, n_tpl, fmt_c64, total):
+    """One sub-batch with more carrier-positive blocks than workgroups takes the fused kernel with
+    several blocks per workgroup (next-block prefetch, the peak written one barrier into the next
+    block, the workgroup's last block after the loop); batches of <= 3 blocks take one block per
+    workgroup or the two-kernel form.  Same arithmetic, so the records must be byte-identical --
+    and the small-batch form is the one the oracle tests above pin."""
+    h = 4096
+    tpls = np.stack([synth.gold_template(11, 2 + i, 2.0 if n == 65536 else 1.0)
+                     for i in range(n_tpl)]).astype(np.float64)
+    win = onp.unique_window(n, h, tpls.shape[1])
+    rng = np.random.default_rng(n + n_tpl + total)
+    distinct = 48
+    base, _ = synth.synth_blocks(rng, distinct, n, tpls[0], win, signal_frac=0.75)
+    order = rng.integers(0, distinct, total)          # carrier-less blocks scattered through the batch
+    blocks = base[order]
+    inp = np.stack([block_data.raw_to_complex(b) for b in base])[order] if fmt_c64 else blocks
+    idx = np.arange(total) * 2 + 5
+    tp = tpls if n_tpl > 1 else tpls[0]
+    big = F.Engine(n, h, tp, (0, 15, 0), (7, 110), (0, 15, 0), max_batch=total).detect(inp, idx)
+    small = F.Engine(n, h, tp, (0, 15, 0), (7, 110), (0, 15, 0), max_batch=3).detect(inp, idx)
+    assert int(((big["flags"][:, 0] & F.FLAG_CARRIER) != 0).sum()) > 300    # (more than 256 workgroups' worth)
+    assert big.tobytes() == small.tobytes()
+    # and a spot check against the oracle on the distinct blocks
+    orc = onp.OracleDetector(n, h, tpls[0], (0, 15, 0), (7, 110), (0, 15, 0))
+    for j in range(6):
+        i = int(np.flatnonzero(order == j)[0]) if (order == j).any() else None
+        if i is None:
+            continue
+        (res,) = orc.detect_u8(int(idx[i]), blocks[i])
+        r = big[i, 0]
+        assert bool(r["flags"] & F.FLAG_CARRIER) == res.carrier.detected
+        if res.carrier.detected:
+            assert r["corr_sample"] == res.corr.sample
+            np.testing.assert_allclose(r["corr_energy"], res.corr.energy, rtol=1e-4)
