@@ -103,8 +103,8 @@ struct RawLong {
             pair(n0, n1, x, y);
             if constexpr (GEN) {
                 const cpx wg = cpx{g[n0].x, g[n0].y};
-                a += cmul(x, wg);
-                b += cmul(y, wg);
+                a = cmul_acc(a, x, wg);
+                b = cmul_acc(b, y, wg);
             } else {
                 const int q = (n0 * k0 * (4 / R0)) & 3;  // W_R0^(n0 k0) as quarter turns
                 a += rot_quarter_neg(x, q);

@@ -55,6 +55,12 @@ __device__ __forceinline__ cpx cmulc_hi(cpx a, cpx b, cpx t) {   // t + (a.y b.y
     return r;
 }
 __device__ __forceinline__ cpx cmul(cpx a, cpx b) { return cmul_hi(a, b, cmul_lo(a, b)); }
+// acc + a * b, two packed fma (the accumulation rides on the first)
+__device__ __forceinline__ cpx cmul_acc(cpx acc, cpx a, cpx b) {
+    cpx t;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(t) : "v"(a), "v"(b), "v"(acc));
+    return cmul_hi(a, b, t);
+}
 // a * u with a wave-uniform u read straight from its SGPR pair (no v_mov_b64 into VGPRs first)
 __device__ __forceinline__ cpx cmul_uniform(cpx a, cpx u) {
     cpx t, r;
@@ -81,6 +87,7 @@ __device__ __forceinline__ cpx cmulc(cpx a, cpx b) {
     return r;
 }
 __device__ __forceinline__ cpx cmul_uniform(cpx a, cpx u) { return cmul(a, u); }
+__device__ __forceinline__ cpx cmul_acc(cpx acc, cpx a, cpx b) { return acc + cmul(a, b); }
 #endif
 // two independent products.  (Interleaving them -- mul, mul, fma, fma, which saves the wait state
 // a packed result costs when the very next instruction consumes it -- was measured 4 % SLOWER in
