@@ -42,7 +42,7 @@ __global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples
     const size_t blk_bytes = cfg.blk_stride;  // dense: N * sample size; raw streams: 2 (N - H)
     int parity = 0;
     cpx tw0[R1], tw1[R1];   // block-invariant pass-1 twiddles of this thread's two columns
-    pass1_twiddles(lds, tw0, tw1);
+    pass1_twiddles(lds, tw0, tw1, pass1_scale<RawSamples<FMT>>());
 
     RawSamples<FMT> cur;
     if (int(blockIdx.x) < n_blocks)
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(NT) void k_carrier_pruned(const void* __restrict__ 
     const size_t blk_bytes = cfg.blk_stride;  // dense: N * sample size; raw streams: 2 (N - H)
     int parity = 0;
     cpx tw0[R1], tw1[R1];   // block-invariant pass-1 twiddles (unshifted variant only)
-    if constexpr (!SHIFTED) pass1_twiddles(lds, tw0, tw1);
+    if constexpr (!SHIFTED) pass1_twiddles(lds, tw0, tw1, pass1_scale<RawSamples<FMT>>());
 
     RawSamples<FMT> cur;
     if (int(blockIdx.x) < n_blocks)

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(NT) void k_preshift(const void* __restrict__ sample
     const size_t blk_bytes = cfg.blk_stride;
     int parity = 0;
     cpx tw0[R1], tw1[R1];   // block-invariant pass-1 twiddles of this thread's two columns
-    pass1_twiddles(lds, tw0, tw1);
+    pass1_twiddles(lds, tw0, tw1, pass1_scale<RawSamples<FMT>>());
 
     RawSamples<FMT> cur;
     if (int(blockIdx.x) < n_blocks)

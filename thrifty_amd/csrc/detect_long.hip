@@ -326,6 +326,13 @@ struct RawDecim<THR_IN_U8, R0> {
         a = cpx{fmaf(float(v & 0xffu), sc, of), fmaf(float((v >> 8) & 0xffu), sc, of)};
         b = cpx{fmaf(float((v >> 16) & 0xffu), sc, of), fmaf(float(v >> 24), sc, of)};
     }
+    static constexpr bool kBytes = true;   // (fwd_pass1_pre: affine map after the butterfly)
+    __device__ __forceinline__ unsigned word(int n1) const { return q[n1]; }
+    __device__ __forceinline__ void get_bytes(int n1, cpx& a, cpx& b) const {
+        const unsigned v = q[n1];
+        a = cpx{float(v & 0xffu), float((v >> 8) & 0xffu)};
+        b = cpx{float((v >> 16) & 0xffu), float(v >> 24)};
+    }
 };
 template <int R0>
 struct RawDecim<THR_IN_C64, R0> {
@@ -340,6 +347,7 @@ struct RawDecim<THR_IN_C64, R0> {
         b = p[size_t(n1) * S1 * R0 + R0];
         __builtin_amdgcn_sched_barrier(0);  // see RawLong: keep the loads from being hoisted en bloc
     }
+    static constexpr bool kBytes = false;
 };
 
 template <int FMT, int R0>
@@ -357,7 +365,7 @@ __global__ __launch_bounds__(NT) void k_carrier_dit(const void* __restrict__ sam
     const int win_w = cfg.win_count + 6, win_base = cfg.win_lo - 3;
     int parity = 0;
     cpx tw0[R1], tw1[R1];   // block-invariant pass-1 twiddles of this thread's two columns
-    pass1_twiddles(lds, tw0, tw1);
+    pass1_twiddles(lds, tw0, tw1, pass1_scale<RawDecim<FMT, R0>>());
     for (int b = blockIdx.x; b < n_blocks; b += gridDim.x) {
       RawDecim<FMT, R0> raw;
       raw.fetch(static_cast<const unsigned char*>(samples) + size_t(b) * blk_bytes, opaque_tid());

@@ -70,6 +70,14 @@ struct RawSamples<THR_IN_U8> {
         a = cpx{fmaf(float(w & 0xffu), sc, of), fmaf(float((w >> 8) & 0xffu), sc, of)};
         b = cpx{fmaf(float((w >> 16) & 0xffu), sc, of), fmaf(float(w >> 24), sc, of)};
     }
+    // the raw bytes (fwd_pass1_pre applies the quantiser's affine map after the radix-16 butterfly)
+    static constexpr bool kBytes = true;
+    __device__ __forceinline__ unsigned word(int n1) const { return q[n1]; }
+    __device__ __forceinline__ void get_bytes(int n1, cpx& a, cpx& b) const {
+        const unsigned w = q[n1];
+        a = cpx{float(w & 0xffu), float((w >> 8) & 0xffu)};
+        b = cpx{float((w >> 16) & 0xffu), float(w >> 24)};
+    }
 };
 
 template <>
@@ -83,6 +91,7 @@ struct RawSamples<THR_IN_C64> {
         a = cpx{w.x, w.y};
         b = cpx{w.z, w.w};
     }
+    static constexpr bool kBytes = false;
 };
 
 // ------------------------------------------------------------ forward passes
@@ -152,34 +161,63 @@ __device__ __forceinline__ void fwd_pass1(cpx* lds, const RAW& raw,
 
 // Pass-1 twiddles W_N^(k1 m) of a thread's two columns m = 2t, 2t+1 (k1 = 1..15): they do not
 // depend on the block, so a persistent kernel WITHOUT a frequency shift forms them once (60
-// VGPRs) instead of two LDS reads and a complex product per output and block.
-__device__ __forceinline__ void pass1_twiddles(const cpx* lds, cpx (&w0)[R1], cpx (&w1)[R1]) {
+// VGPRs) instead of two LDS reads and a complex product per output and block.  `scale`: 1/128
+// for u8 input (fwd_pass1_pre transforms the raw bytes; a power of two: exact).
+__device__ __forceinline__ void pass1_twiddles(const cpx* lds, cpx (&w0)[R1], cpx (&w1)[R1],
+                                               float scale = 1.0f) {
     const int t = opaque_tid();
     const int n2 = t >> 4, mp = 2 * (t & 15);
     const cpx* tA = lds + OFF_A;
     const cpx* tB = lds + OFF_B;
-    w0[0] = w1[0] = cpx{1.f, 0.f};
+    w0[0] = w1[0] = cpx{scale, 0.f};
 #pragma unroll
     for (int k1 = 1; k1 < R1; ++k1) {
-        const cpx a = tA[k1 * 32 + n2];
+        const cpx a = tA[k1 * 32 + n2] * cpx{scale, scale};
         const f4 bb = *reinterpret_cast<const f4*>(tB + k1 * 32 + mp);
         cmul2(a, cpx{bb.x, bb.y}, a, cpx{bb.z, bb.w}, w0[k1], w1[k1]);
     }
 }
+template <class RAW>
+constexpr float pass1_scale() { return RAW::kBytes ? 1.0f / 128.0f : 1.0f; }
 
-// Pass 1 without a frequency shift, twiddles from registers (pass1_twiddles).
+// Pass 1 without a frequency shift, twiddles from registers (pass1_twiddles<scale>).
+// u8 input (RAW::kBytes): the radix-16 butterfly runs on the RAW BYTES and the quantiser's affine
+// map x = (u - 127.4f) / 128 comes after it -- the transform is linear: the factor 1/128 sits in
+// the twiddles (pass1_twiddles' scale) and the offset lands in output k1 = 0 alone, 16 (-127.4f / 128)
+// per component; 64 fewer VALU ops per thread and block than mapping every byte.  It is also the
+// more exact order: the adds of the butterfly are integer arithmetic in float (sums <= 16 * 255,
+// exact), the offset never meets the rotations.  Energy: sum |x|^2 of the thread's 64 bytes
+// from two integer dot products per word (v_dot4_u32_u8: sum u^2 and sum u, exact) and
+// (S2 - 2 c S1 + 64 c^2) / 128^2 in double.
 template <class RAW>
 __device__ __forceinline__ void fwd_pass1_pre(cpx* lds, const RAW& raw, const cpx (&w0)[R1],
                                               const cpx (&w1)[R1], float* energy = nullptr) {
     const int t = opaque_tid();
     cpx v0[R1], v1[R1];
-    float e = 0.f;
+    if constexpr (RAW::kBytes) {
+        unsigned s1 = 0, s2 = 0;
 #pragma unroll
-    for (int n1 = 0; n1 < R1; ++n1) {
-        raw.get(n1, v0[n1], v1[n1]);
-        if (energy != nullptr) e += cnorm(v0[n1]) + cnorm(v1[n1]);  // time-domain sum |x|^2
+        for (int n1 = 0; n1 < R1; ++n1) {
+            raw.get_bytes(n1, v0[n1], v1[n1]);
+            if (energy != nullptr) {
+                const unsigned w = raw.word(n1);
+                s2 = __builtin_amdgcn_udot4(w, w, s2, false);
+                s1 = __builtin_amdgcn_udot4(w, 0x01010101u, s1, false);
+            }
+        }
+        if (energy != nullptr) {
+            constexpr double c = double(127.4f);
+            *energy = float((double(s2) - 2.0 * c * double(s1) + 4.0 * R1 * c * c) * (1.0 / 16384.0));
+        }
+    } else {
+        float e = 0.f;
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) {
+            raw.get(n1, v0[n1], v1[n1]);
+            if (energy != nullptr) e += cnorm(v0[n1]) + cnorm(v1[n1]);  // time-domain sum |x|^2
+        }
+        if (energy != nullptr) *energy = e;
     }
-    if (energy != nullptr) *energy = e;
     dft_dif<R1, -1>(v0);
     dft_dif<R1, -1>(v1);
     const int n2 = t >> 4, mp = 2 * (t & 15);
@@ -190,6 +228,10 @@ __device__ __forceinline__ void fwd_pass1_pre(cpx* lds, const RAW& raw, const cp
         cpx y0 = v0[src], y1 = v1[src];
         if constexpr (k1 != 0) {
             cmul2(y0, w0[k1], y1, w1[k1], y0, y1);
+        } else if constexpr (RAW::kBytes) {
+            constexpr float sc = 1.0f / 128.0f, of16 = R1 * (-127.4f / 128.0f);
+            y0 = __builtin_elementwise_fma(y0, cpx{sc, sc}, cpx{of16, of16});
+            y1 = __builtin_elementwise_fma(y1, cpx{sc, sc}, cpx{of16, of16});
         }
         out[k1 * (ROW / 2)] = f4{y0.x, y0.y, y1.x, y1.y};
     });
