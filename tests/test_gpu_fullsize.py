@@ -1,8 +1,8 @@
 """BASELINE.json's full workload (configs[1]: 1 Mi blocks of 16384 samples, 1023-chip Gold
 template, H = 4096) checked through size-independent properties -- the oracle would need
 ~15 minutes for it, so parity at this size rests on: recovery of the generator's ground
-truth, invariance under batch split / order / repetition, the SoA identity, u8 == c64
-input, and compaction bookkeeping.  Inputs: bench.py's on-device generator."""
+truth, invariance under batch split / order / repetition, the SoA identity, u8 vs c64
+input (same indices and verdicts, floats to rounding), and compaction bookkeeping.  Inputs: bench.py's on-device generator."""
 import numpy as np
 import pytest
 
