@@ -214,24 +214,29 @@ __global__ __launch_bounds__(NT) void k_carrier_pruned(const void* __restrict__ 
         __syncthreads();
         fwd_pass2<PRUNE_K2>(lds);
         __builtin_amdgcn_sched_barrier(0);
-        // pass 3, output k3 = 0 only: the plain sum of the chunk; threads with k2 < 8
+        // pass 3, output k3 = 0 only: the plain sum of a chunk -- 16 x PRUNE_K2 = 128 chunks of 32,
+        // FOUR threads per chunk (8 terms each, then a quad sum on the DPP path): every lane of
+        // every wave has a quarter of a sum to do, instead of a quarter of the lanes a whole one
+        static_assert(PRUNE_K2 * R1 * 4 == NT, "four threads per kept chunk");
         const int t = opaque_tid();
-        const int k2 = t & 31;
-        const int k = (t >> 5) + 16 * k2;  // pruned-domain bin (valid when k2 < PRUNE_K2)
+        const int k2 = (t >> 2) & (PRUNE_K2 - 1), k1 = t >> 5, part = t & 3;
+        const int k = k1 + 16 * k2;  // pruned-domain bin
         unsigned long long best = 0;
-        if (k2 < PRUNE_K2) {
-            const f4* src = reinterpret_cast<const f4*>(lds + (t >> 5) * ROW + k2 * CHUNK);
+        {
+            const f4* src = reinterpret_cast<const f4*>(lds + k1 * ROW + k2 * CHUNK) + part * (R3 / 8);
             f4 acc = src[0];
 #pragma unroll
-            for (int j = 1; j < R3 / 2; ++j) acc += src[j];
-            const cpx x = cpx{acc.x + acc.z, acc.y + acc.w};
+            for (int j = 1; j < R3 / 8; ++j) acc += src[j];
+            const cpx x = cpx{quad_sum(acc.x + acc.z), quad_sum(acc.y + acc.w)};
             const float p = cnorm(x);
-            sc_bins[k] = p;
             const unsigned wi = unsigned(k - win_off) & unsigned(N - 1);
             // the key carries |X| (not |X|^2): the reference takes argmax over float32 magnitudes,
             // where powers an ulp apart can collide -- the first bin then wins, here as there
-            if (wi < unsigned(cfg.win_count))
-                best = ((unsigned long long)__float_as_uint(sqrtf(p)) << 32) | (0xFFFFFFFFu - wi);
+            if (part == 0) {
+                sc_bins[k] = p;
+                if (wi < unsigned(cfg.win_count))
+                    best = ((unsigned long long)__float_as_uint(sqrtf(p)) << 32) | (0xFFFFFFFFu - wi);
+            }
         }
         double tot[1];
         block_reduce<1, NT / 64>(sums, tot, best, sc_red, parity);

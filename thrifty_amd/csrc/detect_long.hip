@@ -379,16 +379,17 @@ __global__ __launch_bounds__(NT) void k_carrier_dit(const void* __restrict__ sam
         __syncthreads();
         fwd_pass2<8>(lds);
         __builtin_amdgcn_sched_barrier(0);
-        const int k2 = t & 31;
-        if (k2 < 8) {
-            const f4* src = reinterpret_cast<const f4*>(lds + (t >> 5) * ROW + k2 * CHUNK);
+        // (four threads per kept chunk, 8 terms each, then a quad sum: as k_carrier_pruned)
+        {
+            const int k2 = (t >> 2) & 7, k1 = t >> 5, part = t & 3;
+            const f4* src = reinterpret_cast<const f4*>(lds + k1 * ROW + k2 * CHUNK) + part * (R3 / 8);
             f4 acc = src[0];
 #pragma unroll
-            for (int j = 1; j < R3 / 2; ++j) acc += src[j];
-            const int k = (t >> 5) + 16 * k2;
+            for (int j = 1; j < R3 / 8; ++j) acc += src[j];
+            const cpx x = cpx{quad_sum(acc.x + acc.z), quad_sum(acc.y + acc.w)};
+            const int k = k1 + 16 * k2;
             const unsigned wi = unsigned(k - win_base);
-            if (wi < unsigned(win_w))
-                win_f[(size_t(b) * R0 + r) * win_w + wi] = cpx{acc.x + acc.z, acc.y + acc.w};
+            if (part == 0 && wi < unsigned(win_w)) win_f[(size_t(b) * R0 + r) * win_w + wi] = x;
         }
         double tot[1];
         unsigned long long dummy = 0;

@@ -92,6 +92,13 @@ __device__ __forceinline__ unsigned dpp_u32(unsigned identity, unsigned v) {
 constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114,
               DPP_ROW_SHR8 = 0x118, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
 
+// sum over the four lanes of a quad (every lane gets it): quad_perm [1,0,3,2], then [2,3,0,1]
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __uint_as_float(dpp_u32<0xB1, 0xf>(0u, __float_as_uint(v)));
+    v += __uint_as_float(dpp_u32<0x4E, 0xf>(0u, __float_as_uint(v)));
+    return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #define THR_STEP(CTRL, MASK) v += __uint_as_float(dpp_u32<CTRL, MASK>(0u, __float_as_uint(v)))
     THR_STEP(DPP_ROW_SHR1, 0xf);
