@@ -104,7 +104,7 @@ __global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples
             bestm < 0.f ? 0ull
                         : ((unsigned long long)__float_as_uint(bestm) << 32) | (0xFFFFFFFFu - bestwi);
         double tot[2];
-        block_reduce<WANT_STD ? 2 : 1, NT / 64>(reinterpret_cast<float(&)[WANT_STD ? 2 : 1]>(sums),
+        block_reduce<WANT_STD ? 2 : 1, NT / 64, true>(reinterpret_cast<float(&)[WANT_STD ? 2 : 1]>(sums),
                                        reinterpret_cast<double(&)[WANT_STD ? 2 : 1]>(tot), best,
                                        sc_red, parity);
         parity ^= 1;
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(NT) void k_carrier_pruned(const void* __restrict__ 
             }
         }
         double tot[1];
-        block_reduce<1, NT / 64>(sums, tot, best, sc_red, parity);
+        block_reduce<1, NT / 64, true>(sums, tot, best, sc_red, parity);   // (key: |X| bits, -bin)
         parity ^= 1;
         const int wi = int(0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu));
         int peak_idx = wi + cfg.win_lo;

@@ -130,41 +130,6 @@ __device__ __forceinline__ unsigned long long wave_max(unsigned long long v) {
     return ((unsigned long long)hi << 32) | lo;
 }
 
-// Combined block reduction: NS float sums (returned as double) + one u64 max,
-// ONE barrier.  `scratch` is double-buffered by `parity` (flip it on every call)
-// so a fast wave's next reduction cannot overwrite slots a slow wave still reads.
-template <int NW>
-constexpr int red_slot_bytes() { return NW * 32; }  // per parity: NW waves x (3 doubles + u64)
-template <int NS, int NW>
-__device__ __forceinline__ void block_reduce(float (&s)[NS], double (&out)[NS],
-                                             unsigned long long& m, unsigned char* scratch,
-                                             int parity) {
-    static_assert(NS <= 3, "scratch layout holds 3 sums");
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    double* sd = reinterpret_cast<double*>(scratch + parity * red_slot_bytes<NW>());
-    unsigned long long* su = reinterpret_cast<unsigned long long*>(sd + 3 * NW);
-#pragma unroll
-    for (int i = 0; i < NS; ++i) s[i] = wave_sum(s[i]);
-    m = wave_max(m);
-    if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < NS; ++i) sd[wv * 3 + i] = (double)s[i];
-        su[wv] = m;
-    }
-    THR_LOOP_BARRIER();
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        double t = 0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) t += sd[w * 3 + i];
-        out[i] = t;
-    }
-    unsigned long long t = 0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) t = su[w] > t ? su[w] : t;
-    m = t;
-}
-
 // max of two keys whose high word is the bit pattern of a float that is not negative (a power,
 // +inf and NaN patterns included): read as IEEE doubles such keys are non-negative and finite
 // (exponent field <= 0x7FC) and order exactly like the integers, so ONE v_max_f64 does what
@@ -192,6 +157,42 @@ __device__ __forceinline__ unsigned long long wave_max_power_key(unsigned long l
     const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
     return ((unsigned long long)hi << 32) | lo;
+}
+
+// Combined block reduction: NS float sums (returned as double) + one u64 max,
+// ONE barrier.  `scratch` is double-buffered by `parity` (flip it on every call)
+// so a fast wave's next reduction cannot overwrite slots a slow wave still reads.
+template <int NW>
+constexpr int red_slot_bytes() { return NW * 32; }  // per parity: NW waves x (3 doubles + u64)
+// POWER_KEY: the keys are power keys (max_power_key above): v_max_f64 instead of 64-bit compares.
+template <int NS, int NW, bool POWER_KEY = false>
+__device__ __forceinline__ void block_reduce(float (&s)[NS], double (&out)[NS],
+                                             unsigned long long& m, unsigned char* scratch,
+                                             int parity) {
+    static_assert(NS <= 3, "scratch layout holds 3 sums");
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double* sd = reinterpret_cast<double*>(scratch + parity * red_slot_bytes<NW>());
+    unsigned long long* su = reinterpret_cast<unsigned long long*>(sd + 3 * NW);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) s[i] = wave_sum(s[i]);
+    m = POWER_KEY ? wave_max_power_key(m) : wave_max(m);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) sd[wv * 3 + i] = (double)s[i];
+        su[wv] = m;
+    }
+    THR_LOOP_BARRIER();
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        double t = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += sd[w * 3 + i];
+        out[i] = t;
+    }
+    unsigned long long t = su[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) t = POWER_KEY ? max_power_key(su[w], t) : (su[w] > t ? su[w] : t);
+    m = t;
 }
 
 // Wave-wide float maximum / unsigned minimum on the DPP path (result in every lane).
