@@ -350,7 +350,7 @@ __global__ __launch_bounds__(NT) void k_correlate(
             double tot[2] = {0, 0};
             THR_STAMP(11);
             if constexpr (WANT_STD)
-                block_reduce<2, NT / 64>(sums, tot, best, sc_red, parity);
+                block_reduce<2, NT / 64, true>(sums, tot, best, sc_red, parity);
             else
                 block_reduce_wave_keys<NT / 64>(best, sc_red, parity);
             THR_STAMP(12);

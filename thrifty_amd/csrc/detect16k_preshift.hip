@@ -218,7 +218,7 @@ __global__ __launch_bounds__(NT) void k_preshift(const void* __restrict__ sample
                         : ((unsigned long long)__float_as_uint(bestp) << 32) | (0xFFFFFFFFu - bestwi);
         constexpr int NC = CAR_STD ? 2 : 1;
         double ctot[2] = {0, 0};
-        block_reduce<NC, NT / 64>(reinterpret_cast<float(&)[NC]>(csums),
+        block_reduce<NC, NT / 64, true>(reinterpret_cast<float(&)[NC]>(csums),
                                   reinterpret_cast<double(&)[NC]>(ctot), best, sc_red, parity);
         const unsigned wi = 0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu);
         int peak_idx = int(wi) + cfg.win_lo;
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(NT) void k_preshift(const void* __restrict__ sample
                                (0xFFFFFFFFu - unsigned(cbestn));
         constexpr int NS = COR_STD ? 3 : 1;
         double tot[3] = {0, 0, 0};
-        block_reduce<NS, NT / 64>(reinterpret_cast<float(&)[NS]>(sums),
+        block_reduce<NS, NT / 64, true>(reinterpret_cast<float(&)[NS]>(sums),
                                   reinterpret_cast<double(&)[NS]>(tot), cbest, sc_red, parity);
         parity ^= 1;
         const int pk = int(0xFFFFFFFFu - unsigned(cbest & 0xFFFFFFFFu));
