@@ -369,6 +369,7 @@ __global__ __launch_bounds__(NT) void k_carrier_dit(const void* __restrict__ sam
     for (int b = blockIdx.x; b < n_blocks; b += gridDim.x) {
       RawDecim<FMT, R0> raw;
       raw.fetch(static_cast<const unsigned char*>(samples) + size_t(b) * blk_bytes, opaque_tid());
+      float energy = 0.f;
 #pragma nounroll
       for (int r = 0; r < R0; ++r) {
         const int t = opaque_tid();
@@ -391,13 +392,22 @@ __global__ __launch_bounds__(NT) void k_carrier_dit(const void* __restrict__ sam
             const unsigned wi = unsigned(k - win_base);
             if (part == 0 && wi < unsigned(win_w)) win_f[(size_t(b) * R0 + r) * win_w + wi] = x;
         }
-        double tot[1];
-        unsigned long long dummy = 0;
-        block_reduce<1, NT / 64>(sums, tot, dummy, sc_red, parity);
-        parity ^= 1;
-        if (t == 0) {
-            partial[(size_t(b) * R0 + r) * 2 + 0] = (float)(tot[0] * double(R0 * M));  // Parseval
-            partial[(size_t(b) * R0 + r) * 2 + 1] = 0.f;
+        // sum |x|^2: the R0 decimated sequences' shares add up in the thread; ONE reduction per
+        // block (k_select_dit adds the R0 partial entries: the total sits in the last, zeros before)
+        energy += sums[0];
+        if (r < R0 - 1) {
+            __syncthreads();   // (this item's pass-3 LDS reads precede the next item's pass-1 writes)
+            if (t == 0) {
+                partial[(size_t(b) * R0 + r) * 2 + 0] = 0.f;
+                partial[(size_t(b) * R0 + r) * 2 + 1] = 0.f;
+            }
+        } else {
+            const double tot = block_sum<NT / 64>(energy, sc_red, parity);
+            parity ^= 1;
+            if (t == 0) {
+                partial[(size_t(b) * R0 + r) * 2 + 0] = (float)(tot * double(R0 * M));  // Parseval
+                partial[(size_t(b) * R0 + r) * 2 + 1] = 0.f;
+            }
         }
       }
     }

@@ -164,6 +164,21 @@ __device__ __forceinline__ unsigned long long wave_max_power_key(unsigned long l
 // so a fast wave's next reduction cannot overwrite slots a slow wave still reads.
 template <int NW>
 constexpr int red_slot_bytes() { return NW * 32; }  // per parity: NW waves x (3 doubles + u64)
+// One float sum over the workgroup (returned as double), ONE barrier; same scratch layout and
+// parity rule as block_reduce.
+template <int NW>
+__device__ __forceinline__ double block_sum(float s, unsigned char* scratch, int parity) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double* sd = reinterpret_cast<double*>(scratch + parity * red_slot_bytes<NW>());
+    s = wave_sum(s);
+    if (lane == 0) sd[wv * 3] = (double)s;
+    THR_LOOP_BARRIER();
+    double t = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t += sd[w * 3];
+    return t;
+}
+
 // POWER_KEY: the keys are power keys (max_power_key above): v_max_f64 instead of 64-bit compares.
 template <int NS, int NW, bool POWER_KEY = false>
 __device__ __forceinline__ void block_reduce(float (&s)[NS], double (&out)[NS],
