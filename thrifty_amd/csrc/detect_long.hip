@@ -370,8 +370,10 @@ __global__ __launch_bounds__(NT) void k_carrier_dit(const void* __restrict__ sam
       RawDecim<FMT, R0> raw;
       raw.fetch(static_cast<const unsigned char*>(samples) + size_t(b) * blk_bytes, opaque_tid());
       float energy = 0.f;
-#pragma nounroll
-      for (int r = 0; r < R0; ++r) {
+      // u8: the loop over the R0 decimated sequences is unrolled -- picking the sequence's pair out
+      // of the held words is then register naming plus one byte permute per word instead of
+      // selects on r; complex64 (loads at use): rolled, or the compiler hoists R0 x 32 loads
+      auto item = [&](int r) __attribute__((always_inline)) {
         const int t = opaque_tid();
         raw.select(r);
         float sums[1];
@@ -409,6 +411,12 @@ __global__ __launch_bounds__(NT) void k_carrier_dit(const void* __restrict__ sam
                 partial[(size_t(b) * R0 + r) * 2 + 1] = 0.f;
             }
         }
+      };
+      if constexpr (FMT == THR_IN_U8) {
+          static_for<R0>([&](auto R) { item(decltype(R)::value); });
+      } else {
+#pragma nounroll
+          for (int r = 0; r < R0; ++r) item(r);
       }
     }
 }
