@@ -921,6 +921,14 @@ __global__ __launch_bounds__(NT) void k_correlate_sub(
         fwd_pass1<true>(lds, raw, sc_rp, p[0], p[1]);
         __syncthreads();
         if constexpr (FUSED && !MULTI) tail.complete(cfg, corr_stats, opaque_tid(), 0.f, 0.f);
+        // template 0's spectrum slice: requested here, used after pass 3 -- at the point of use its
+        // L2 latency stood in front of every sub-transform (1.62 -> 1.38 ms for the fused kernel).
+        // (One template only: with several, the spectrum and the slices together do not fit.)
+        f4 tq[R3 / 2];
+        if constexpr (!MULTI) {
+            const f4* ts = tspec + size_t(k0) * (M / 2) + t;
+            static_for<R3 / 2>([&](auto J) { tq[decltype(J)::value] = ts[decltype(J)::value * NT]; });
+        }
         fwd_pass2(lds);
         __builtin_amdgcn_sched_barrier(0);
         cpx xh[R3];
@@ -939,11 +947,14 @@ __global__ __launch_bounds__(NT) void k_correlate_sub(
         // scratch row between templates measured slower, as in k_correlate)
         for (int tpl = 0; tpl < T; ++tpl) {
             const int t = opaque_tid();
-            const f4* ts = tspec + (size_t(tpl) * R0 + k0) * (M / 2) + t;
+            if (MULTI || tpl > 0) {
+                const f4* ts = tspec + (size_t(tpl) * R0 + k0) * (M / 2) + t;
+                static_for<R3 / 2>([&](auto J) { tq[decltype(J)::value] = ts[decltype(J)::value * NT]; });
+            }
             cpx z[R3];
             static_for<R3 / 2>([&](auto J) {
                 constexpr int j = decltype(J)::value;
-                const f4 q = ts[j * NT];
+                const f4 q = tq[j];
                 z[brev(2 * j, R3)] = cmul(xh[brev(2 * j, R3)], cpx{q.x, q.y});
                 z[brev(2 * j + 1, R3)] = cmul(xh[brev(2 * j + 1, R3)], cpx{q.z, q.w});
             });
