@@ -877,32 +877,42 @@ __global__ __launch_bounds__(NT) void k_correlate_sub(
     }
     const int n_iter = per_block ? ((n_work - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x)) * R0
                                  : (n_work * R0 - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x);
+    // An item's uniform preparation -- its block index (a scalar load), the item factors (two
+    // dependent gathers, then LDS) and, on a new block, the block's shift phasor -- is done ONE
+    // ITEM AHEAD, after the pass-1 barrier of the item before: at the top of an item nothing
+    // waits for a chain of loads any more.
+    auto item_of = [&](int it) {
+        return per_block ? (int(blockIdx.x) + (it / R0) * int(gridDim.x)) * R0 + it % R0
+                         : int(blockIdx.x) + it * int(gridDim.x);
+    };
+    auto block_phasor = [&](const ShiftParams* sp, int t) {
+        // per-thread phasor for m' = 2t, 2t+1: c0 * exp(2 pi i s m'/NL) [per block]
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int m = 2 * t + e;
+            const int q = int(((long long)sp->si_mod * m) & nl_mask);
+            float sn, cs;
+            sincosf(6.283185307179586f * (sp->sf_over_n * float(m)), &sn, &cs);
+            ph[e] = cmul(cmul(cconj(twn[q]), cpx{cs, sn}), cpx{sp->c0.x, sp->c0.y});
+        }
+    };
+    int b_cur = 0;
+    if (n_iter > 0) {
+        const int item0 = item_of(0);
+        b_cur = work_list[item0 / R0];
+        item_factors<R0>(sc_rp0, sc_rp0 + 16, shifts + b_cur, twn, item0 % R0, nl_mask);
+        block_phasor(shifts + b_cur, opaque_tid());
+        ph_block = b_cur;
+    }
     for (int it = 0; it < n_iter; ++it) {
-        const int item = per_block ? (int(blockIdx.x) + (it / R0) * int(gridDim.x)) * R0 + it % R0
-                                   : int(blockIdx.x) + it * int(gridDim.x);
+        const int item = item_of(it);
         const int slot = item / R0, k0 = item % R0;
-        const int b = work_list[slot];
+        const int b = b_cur;
         const int t = opaque_tid();
-        const ShiftParams* sp = shifts + b;
-        // item factors are double-buffered: this item's writers cannot collide with the previous
-        // item's readers, and the buffer written two items ago has barriers in between
+        // item factors are double-buffered: written one item ahead (below), after the pass-1 barrier
+        // of the item that reads the other buffer
         float2* sc_rp = sc_rp0 + (it & 1) * (16 + R0);
         float2* sc_g = sc_rp + 16;
-        item_factors<R0>(sc_rp, sc_g, sp, twn, k0, nl_mask);
-        // per-thread phasor for m' = 2t, 2t+1: c0 * exp(2 pi i s m'/NL) [per block] * W_NL^(m' k0)
-        // (fused: a workgroup's items are whole blocks, k0 = 0 .. R0 - 1 -- stated as such, the
-        // per-block registers are dead during the combination that follows the last k0)
-        if (FUSED ? k0 == 0 : b != ph_block) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int m = 2 * t + e;
-                const int q = int(((long long)sp->si_mod * m) & nl_mask);
-                float sn, cs;
-                sincosf(6.283185307179586f * (sp->sf_over_n * float(m)), &sn, &cs);
-                ph[e] = cmul(cmul(cconj(twn[q]), cpx{cs, sn}), cpx{sp->c0.x, sp->c0.y});
-            }
-            ph_block = b;
-        }
         cpx p[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) p[e] = cmul(ph[e], twn[((2 * t + e) * k0) & nl_mask]);
@@ -921,6 +931,17 @@ __global__ __launch_bounds__(NT) void k_correlate_sub(
         fwd_pass1<true>(lds, raw, sc_rp, p[0], p[1]);
         __syncthreads();
         if constexpr (FUSED && !MULTI) tail.complete(cfg, corr_stats, opaque_tid(), 0.f, 0.f);
+        if (it + 1 < n_iter) {   // the next item's uniform preparation (p of THIS item is formed)
+            const int item_n = item_of(it + 1);
+            const int b_n = work_list[item_n / R0];
+            float2* rp_n = sc_rp0 + ((it + 1) & 1) * (16 + R0);
+            item_factors<R0>(rp_n, rp_n + 16, shifts + b_n, twn, item_n % R0, nl_mask);
+            if (b_n != ph_block) {
+                block_phasor(shifts + b_n, t);
+                ph_block = b_n;
+            }
+            b_cur = b_n;
+        }
         // template 0's spectrum slice: requested here, used after pass 3 -- at the point of use its
         // L2 latency stood in front of every sub-transform (1.62 -> 1.38 ms for the fused kernel).
         // (One template only: with several, the spectrum and the slices together do not fit.)
