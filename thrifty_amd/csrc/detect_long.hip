@@ -891,8 +891,8 @@ __global__ __launch_bounds__(NT) void k_correlate_sub(
         for (int e = 0; e < 2; ++e) {
             const int m = 2 * t + e;
             const int q = int(((long long)sp->si_mod * m) & nl_mask);
-            float sn, cs;
-            sincosf(6.283185307179586f * (sp->sf_over_n * float(m)), &sn, &cs);
+            float sn, cs;   // |2 pi sf m| <= 2 pi (0.5 / NL) 1023 < 0.1 rad
+            sincos_small(6.283185307179586f * (sp->sf_over_n * float(m)), &sn, &cs);
             ph[e] = cmul(cmul(cconj(twn[q]), cpx{cs, sn}), cpx{sp->c0.x, sp->c0.y});
         }
     };
