@@ -44,7 +44,7 @@ THRESH = (0, 15, 0)
 CONFIGS = {
     "c2": dict(n=16384, h=4096, bits=10, sps=1.0, batch=32768, resident=2 << 20, idx=1, streams=2,
                label="block_len=16384 history=4096 1023-chip Gold template (10-bit, 1 sample/chip)"),
-    "c3": dict(n=65536, h=4096, bits=11, sps=2.0, batch=4096, resident=1 << 18, idx=2, streams=2,
+    "c3": dict(n=65536, h=4096, bits=11, sps=2.0, batch=16384, resident=1 << 18, idx=2, streams=2,
                label="block_len=65536 history=4096 2047-chip Gold code at 2 samples/chip (W=4094)"),
 }
 
