@@ -5,8 +5,13 @@
                     [--batch B] [--mix dense|sparse]
 
 One "step" = one pass of the hot path (FFT -> carrier detect -> fit -> shift ->
-FFT -> x conj(T) -> IFFT -> SoA) over one batch of B synthetic IQ blocks that
-are already resident in HBM.  Workloads (BASELINE.json `configs`):
+FFT -> x conj(T) -> IFFT -> SoA) over one batch of synthetic IQ blocks that are
+already resident in HBM.  A step's batch is R launch batches of B blocks (B = the
+engine's max_batch, 32768 at N = 16384); R is chosen after a calibration burst so
+that the K timed steps last at least --min-seconds (default 2 s: a sustained rate
+on a part that clocks to its power budget, not a 40 ms burst).  The default run
+then adds bounded legs for the other single-GPU configs (`configs`: c3, t4,
+sparse), each with its own recomputable roofline.  Workloads (BASELINE.json `configs`):
 
   --config c2 (default, the headline): configs[1] -- block_len 16384, history 4096,
       1023-chip Gold template, K*B (default 32 * 32768 = 1 Mi) blocks per GPU
@@ -42,7 +47,7 @@ THRESH = (0, 15, 0)
 # name -> (block_len, history, Gold register bits, samples per chip, default batch, resident blocks,
 #          BASELINE config index, handles per GPU)
 CONFIGS = {
-    "c2": dict(n=16384, h=4096, bits=10, sps=1.0, batch=32768, resident=2 << 20, idx=1, streams=2,
+    "c2": dict(n=16384, h=4096, bits=10, sps=1.0, batch=32768, resident=1 << 20, idx=1, streams=2,
                label="block_len=16384 history=4096 1023-chip Gold template (10-bit, 1 sample/chip)"),
     "c3": dict(n=65536, h=4096, bits=11, sps=2.0, batch=16384, resident=1 << 18, idx=2, streams=2,
                label="block_len=65536 history=4096 2047-chip Gold code at 2 samples/chip (W=4094)"),
@@ -71,6 +76,13 @@ def parse_args():
                     help="default: reference Detector (the headline); preshift: the reference's "
                          "experimental PreshiftDetector (one fused kernel per block)")
     ap.add_argument("--preshift-num", type=int, default=21, help="bank size of --variant preshift")
+    ap.add_argument("--min-seconds", type=float, default=2.0,
+                    help="lower bound on the timed region: a step becomes R launch batches of --batch "
+                         "blocks, R from a calibration burst, so that K steps last this long (0: R = 1)")
+    ap.add_argument("--legs", default="auto",
+                    help="comma list of extra single-GPU legs after the main one (c3,t4,sparse); "
+                         "'auto' = all three on the default c2 / 1 GPU run, none otherwise; 'none'")
+    ap.add_argument("--leg-seconds", type=float, default=0.75, help="timed region of each extra leg")
     ap.add_argument("--cpu-procs", type=int, default=-1,
                     help="worker processes of the all-cores CPU leg (-1: one per physical core, "
                          "0: skip the leg)")
@@ -267,11 +279,11 @@ def card_to_toad_leg(n_card):
         tmp.write(text)
         tmp.flush()
         warm = Detector(st, block_data.CardStream(io.BytesIO(b"\n".join(text.split(b"\n", 8)[:8]) + b"\n"), n), rxid=0)
-        list(warm.iter_toad_lines())                             # library / device warm-up, not timed
+        list(warm.iter_toad_text())                              # library / device warm-up, not timed
         with open(tmp.name, "rb") as f:
             det = Detector(st, block_data.CardStream(f, n), rxid=0)
             t0 = time.perf_counter()
-            gpu_out = [ln for lines_ in det.iter_toad_lines() for ln in lines_]
+            gpu_out = b"".join(det.iter_toad_text()).decode("ascii").split("\n")[:-1]
             t_gpu = time.perf_counter() - t0
     same = [a.split()[:3] + [a.split()[4], a.split()[8]] for a in gpu_out[:len(cpu_out)]] == \
            [b.split()[:3] + [b.split()[4], b.split()[8]] for b in cpu_out]
@@ -279,7 +291,8 @@ def card_to_toad_leg(n_card):
                       "template, window bins %d..%d) on a synthetic .card stream" % (h, len(tpl), cwin[0], cwin[1]),
             "cpu_blocks_per_s": n_cpu / t_cpu, "cpu_blocks": n_cpu, "cpu_cores": 1,
             "gpu_blocks_per_s": n_card / t_gpu, "gpu_blocks": n_card,
-            "gpu_includes": "host framing, H2D of the base64 text (pageable), device decode, detection, D2H, .toad text",
+            "gpu_includes": "host framing, H2D of the base64 text (pageable), device decode, detection, D2H, .toad "
+                            "text (thr_format_toad); batches ride thr_submit_card / thr_collect, one in flight ahead",
             "detections_cpu": len(cpu_out), "detections_gpu": len(gpu_out),
             "first_lines_agree_on_rxid_time_block_sample_bin": bool(same)}
 
@@ -308,6 +321,220 @@ def preflight(torch, dist, dev, rank, world, local, total, first):
             file=sys.stderr)
 
 
+class Leg(object):
+    """One workload resident in HBM on one GPU: templates, engine handle(s), synthetic u8 blocks,
+    record buffers -- and the loops that run launch batches over them."""
+
+    def __init__(self, torch, F, synth, dev, local, name, T=1, mix="dense", batch=0, resident=0, streams=0,
+                 pnum=0, seed_off=0, first=0):
+        cfg = CONFIGS[name]
+        self.torch, self.F, self.dev, self.name, self.cfg = torch, F, dev, name, cfg
+        self.n, self.h, self.T, self.mix, self.pnum = cfg["n"], cfg["h"], T, mix, pnum
+        self.B = batch or cfg["batch"]
+        self.tpls = np.stack([synth.gold_template(cfg["bits"], 2 + i, cfg["sps"]) for i in range(T)]).astype(np.float64)
+        self.wlen = self.tpls.shape[1]
+        pad = self.h - self.wlen + 1
+        self.window = (pad // 2, (self.n - self.wlen + 1) - (pad - pad // 2))
+        n_handles = max(1, streams or cfg["streams"])
+        self.engs = [F.Engine(self.n, self.h, self.tpls, THRESH, WINDOW_BINS, THRESH, device_id=local,
+                              max_batch=self.B, preshift_num=pnum) for _ in range(n_handles)]
+        self.resident_batches = max(1, (resident or cfg["resident"]) // self.B)
+        self.total = self.resident_batches * self.B
+        self.first = first
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(SEED + cfg["idx"] + 1 + seed_off)
+        t0 = time.perf_counter()
+        self.data = synth_on_device(torch, dev, gen, self.total, self.n, self.tpls[0], self.window,
+                                    1.0 if mix == "dense" else 0.1)
+        torch.cuda.synchronize()
+        self.t_gen = time.perf_counter() - t0
+        self.idx = torch.arange(first, first + self.total, dtype=torch.int64, device=dev)
+        self.rec = torch.zeros((self.total * T, 64), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()     # fills done before the engines' own streams write records
+        self.bytes_per_block = 2 * self.n + 64 * T
+
+    def batch(self, g, eng=None):
+        """launch batch number g (cycles over the resident blocks, alternates over the handles)"""
+        s = (g % self.resident_batches) * self.B
+        (eng or self.engs[g % len(self.engs)]).detect_device(
+            self.data[s:s + self.B].data_ptr(), self.F.THR_IN_U8, self.B,
+            self.rec[s * self.T:].data_ptr(), self.idx[s:].data_ptr())
+
+    def sync(self):
+        for e in self.engs:
+            e.sync()
+
+    def run(self, g0, n_batches, solo_every=0, engs=None):
+        """n_batches launch batches starting at number g0; with solo_every > 0 every
+        solo_every-th batch runs ALONE with HIP events around its kernels (the roofline leg:
+        kernel durations measured while two batches overlap would be inflated by the sharing).
+        Not synchronised at the end.  -> number of solo (profiled) batches"""
+        engs = engs or self.engs
+        solo = 0
+        for g in range(g0, g0 + n_batches):
+            e = engs[g % len(engs)]
+            if solo_every > 0 and g % solo_every == 0:
+                for x in engs:
+                    x.sync()
+                e.profile_enable(1)
+                self.batch(g, e)
+                e.sync()
+                e.profile_enable(0)
+                solo += 1
+            else:
+                self.batch(g, e)
+        return solo
+
+    def timed(self, g0, n_batches, solo_every=0, engs=None):
+        """run() bracketed by device synchronisation -> (seconds, solo batches)"""
+        self.sync()
+        self.torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        solo = self.run(g0, n_batches, solo_every, engs)
+        for x in (engs or self.engs):
+            x.sync()
+        return time.perf_counter() - t0, solo
+
+    def reset_profile(self):
+        for e in self.engs:
+            e.profile_enable(0)
+            e.profile_read()
+
+    def read_profile(self):
+        prof = {}
+        for e in self.engs:
+            for k, (ms, cnt) in e.profile_read().items():
+                prof[k] = (prof.get(k, (0.0, 0))[0] + ms, prof.get(k, (0.0, 0))[1] + cnt)
+            e.profile_enable(0)
+        rename = {}
+        if self.pnum:   # the fused kernel is timed in k_correlate's event slot
+            rename["k_correlate"] = "k_preshift"
+        if self.n > 16384:   # long blocks: the correlate slot times the fused sub-transform + combination kernel
+            rename.update({"k_correlate": "k_correlate_sub", "k_carrier": "k_carrier_dit+k_select_dit"})
+        return {rename.get(k, k): v for k, v in prof.items() if v[1] > 0}
+
+    def roofline(self, prof, solo_batches, fallback_ms):
+        """The recomputable roofline object of the dominant kernel: algorithmic bytes per launch
+        (2N + 64 T per block x blocks per launch) / its mean launch duration."""
+        dom = max(prof, key=lambda k: prof[k][0]) if prof else None
+        dom_ms, dom_cnt = prof[dom] if prof else (0.0, 0)
+        if dom_cnt == 0:   # no profiled batch: fall back to the whole launch batch
+            dom, avg_ms, units = "all kernels of one launch batch", fallback_ms, float(self.B)
+        else:
+            avg_ms = dom_ms / dom_cnt
+            units = self.B * max(solo_batches, 1) / dom_cnt      # blocks one launch of it processes
+        achieved = self.bytes_per_block * units / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                key = self.name + ("_t%d" % self.T if self.T > 1 else "") + ("_sparse" if self.mix != "dense" else "")
+                traffic = json.load(open(tpath)).get(key, {}).get(dom, {}).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms,
+                "launches": dom_cnt, "blocks_per_launch": units,
+                "algorithmic_bytes_per_block": self.bytes_per_block,
+                "algorithmic_bytes_per_launch": self.bytes_per_block * units,
+                "all_kernels_ms": {k: v[0] / max(v[1], 1) for k, v in prof.items()},
+                "all_kernels_launches_per_batch": {k: v[1] / max(solo_batches, 1) for k, v in prof.items()},
+                # the kernels are VALU/LDS-bound, so the honest secondary view (SURVEY 8d): nominal
+                # 5 N log2 N flop per transform done by THIS kernel (+ 6N per pointwise product)
+                # against the fp32 vector peak
+                "compute": _compute_view(dom, self.n, self.T, units, avg_ms)}
+
+    def workload_text(self):
+        return ("BASELINE configs[%d]: %s, %s mix, %d blocks per GPU resident in HBM as u8 IQ"
+                % (4 if (self.T > 1 and self.n == 16384) else self.cfg["idx"], self.cfg["label"], self.mix,
+                   self.total))
+
+    def host_records(self, nblocks):
+        return self.rec.view(self.total, self.T, 64)[:nblocks, 0].cpu().numpy().view(self.F.RECORD_DTYPE).reshape(-1)
+
+    def close(self):
+        for e in self.engs:
+            e.close()
+        self.engs = []
+        del self.data, self.rec, self.idx
+
+
+def _parity_worker(job):
+    """(spawned process) oracle over a slab of blocks -> rows of the exact fields + floats"""
+    os.environ["OMP_NUM_THREADS"] = "1"
+    n, h, blocks, template, lo = job
+    orc = make_oracle(n, h, template)
+    out = []
+    for i in range(len(blocks)):
+        (res,) = orc.detect_u8(lo + i, blocks[i])
+        c = res.corr
+        out.append((res.carrier.bin, bool(res.carrier.detected), int(c.sample) if c else -1,
+                    bool(c.detected) if c else False, float(c.energy) if c else 0.0,
+                    float(c.offset) if c else 0.0))
+    return lo, out
+
+
+def oracle_parity(n, h, blocks_u8, template, gpu_rec, procs):
+    """GPU records against the oracle over `blocks_u8`, the oracle spread over `procs` spawned
+    workers (checker only: nothing here is timed as the product)."""
+    import multiprocessing as mp
+    from thrifty_amd import _native as F
+    for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ[var] = "1"
+    chunk = max(1, min(64, len(blocks_u8) // max(1, 2 * procs)))
+    jobs = [(n, h, blocks_u8[s:s + chunk], template, s) for s in range(0, len(blocks_u8), chunk)]
+    t0 = time.perf_counter()
+    rows = [None] * len(blocks_u8)
+    with mp.get_context("spawn").Pool(procs) as pool:
+        for lo, out in pool.imap_unordered(_parity_worker, jobs):
+            rows[lo:lo + len(out)] = out
+    dt = time.perf_counter() - t0
+    mism = 0
+    for i, (cbin, cdet, samp, det, en, off) in enumerate(rows):
+        r = gpu_rec[i]
+        ok = r["carrier_bin"] == cbin and bool(r["flags"] & F.FLAG_CARRIER) == cdet
+        if ok and cdet:
+            ok = (r["corr_sample"] == samp and bool(r["flags"] & F.FLAG_CORR) == det and
+                  abs(r["corr_energy"] - en) <= 1e-4 * abs(en) and abs(r["corr_offset"] - off) <= 1e-4 + 1e-4 * abs(off))
+        mism += 0 if ok else 1
+    return {"parity_checked": len(rows), "parity_mismatches": mism, "oracle_procs": procs,
+            "oracle_seconds": dt, "oracle_blocks_per_s_all_procs": len(rows) / dt,
+            "fields": "carrier bin, both verdicts, SoA sample index exact; corr energy and sub-sample offset 1e-4"}
+
+
+def extra_leg(torch, F, synth, dev, local, key, seconds, cpu_ok):
+    """One bounded leg of the default run: another single-GPU workload of BASELINE.json's configs,
+    timed over ~`seconds` after a calibration burst, with its own roofline object."""
+    spec = {"c3": dict(name="c3", T=1, mix="dense", batch=16384, resident=2 * 16384),
+            "t4": dict(name="c2", T=4, mix="dense", batch=16384, resident=4 * 16384),
+            "sparse": dict(name="c2", T=1, mix="sparse", batch=32768, resident=4 * 32768)}[key]
+    t_leg = time.perf_counter()
+    leg = Leg(torch, F, synth, dev, local, spec["name"], T=spec["T"], mix=spec["mix"], batch=spec["batch"],
+              resident=spec["resident"], seed_off=17)
+    leg.timed(0, 2)                                           # code load, first-touch
+    dt, _ = leg.timed(0, 4)                                   # calibration burst
+    nb = int(max(8, min(4096, seconds / (dt / 4))))
+    nb -= nb % len(leg.engs)
+    leg.reset_profile()
+    solo_every = max(2, nb // 6)
+    dt, solo = leg.timed(0, nb, solo_every)
+    prof = leg.read_profile()
+    out = {"workload": leg.workload_text(), "value": nb * leg.B / dt, "unit": "blocks/s",
+           "launch_batches": nb, "blocks_per_launch_batch": leg.B, "blocks": nb * leg.B, "seconds": dt,
+           "ms_per_launch_batch": dt / nb * 1e3, "templates": leg.T, "handles_per_gpu": len(leg.engs),
+           "solo_profiled_batches": solo,
+           "roofline": leg.roofline(prof, solo, dt / nb * 1e3), "data_gen_s": leg.t_gen}
+    if key == "c3" and cpu_ok:
+        # the oracle check at benchmark shape: 2048 blocks of ONE 16384-block launch batch
+        ns = 2048
+        procs, _ = physical_cores()
+        out["oracle_parity"] = oracle_parity(leg.n, leg.h, leg.data[:ns].cpu().numpy(), leg.tpls[0],
+                                             leg.host_records(ns), procs)
+    leg.close()
+    out["leg_wall_s"] = time.perf_counter() - t_leg
+    return out
+
+
 def main():
     args = parse_args()
     import torch
@@ -333,85 +560,66 @@ def main():
     if use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
-    B = args.batch or cfg["batch"]
     K, W, T = args.steps, args.warmup, args.templates
-    tpls = np.stack([synth.gold_template(cfg["bits"], 2 + i, cfg["sps"]) for i in range(T)]).astype(np.float64)
-    wlen = tpls.shape[1]
-    pad = h - wlen + 1
-    window = (pad // 2, (n - wlen + 1) - (pad - pad // 2))
-
     pnum = args.preshift_num if args.variant == "preshift" else 0
-    n_handles = max(1, args.streams or cfg["streams"])
-    engs = [F.Engine(n, h, tpls, THRESH, WINDOW_BINS, THRESH, device_id=local,
-                     max_batch=B, preshift_num=pnum) for _ in range(n_handles)]
-    eng = engs[0]
-    if len(engs) == 1:
-        eng.set_stream(torch.cuda.current_stream().cuda_stream)
-
-    # distinct blocks resident in HBM: every step has its own batch up to the config's resident
-    # limit (c2: 2 Mi blocks = 64 GiB of u8); longer runs cycle through them
-    resident_steps = max(1, min(K, cfg["resident"] // B))
-    total = resident_steps * B
+    B = args.batch or cfg["batch"]
+    # distinct blocks resident in HBM: up to the config's limit (c2: 1 Mi blocks = 32 GiB of u8 =
+    # BASELINE's "1M synthetic blocks"); longer runs cycle through them
+    resident = min(cfg["resident"], max(B, K * B)) if args.min_seconds <= 0 else cfg["resident"]
+    leg = Leg(torch, F, synth, dev, local, args.config, T=T, mix=args.mix, batch=B, resident=resident,
+              streams=args.streams, pnum=pnum, seed_off=rank, first=0)
+    total = leg.total
     # contiguous block-index range per rank
     first = rank * total
+    leg.idx += first
+    leg.first = first
+    engs, eng = leg.engs, leg.engs[0]
+    if len(engs) == 1:
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
     if use_dist:
         preflight(torch, dist, dev, rank, world, local, total, first)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(SEED + cfg["idx"] + 1 + rank)
-    frac = 1.0 if args.mix == "dense" else 0.1
-    t_gen = time.perf_counter()
-    data = synth_on_device(torch, dev, gen, total, n, tpls[0], window, frac)
+    kept = torch.zeros_like(leg.rec)
     torch.cuda.synchronize()
-    t_gen = time.perf_counter() - t_gen
-    idx = torch.arange(first, first + total, dtype=torch.int64, device=dev)
-    rec = torch.zeros((total * T, 64), dtype=torch.uint8, device=dev)
-    kept = torch.zeros_like(rec)
-    torch.cuda.synchronize()     # fills done before the engines' own streams write records
 
-    def step(i):
-        s = (i % resident_steps) * B
-        engs[i % len(engs)].detect_device(data[s:s + B].data_ptr(), F.THR_IN_U8, B,
-                                          rec[s * T:].data_ptr(), idx[s:].data_ptr())
-
-    def sync_engines():
-        for e in engs:
-            e.sync()
-
+    # ---- calibration burst = the round-1/2 protocol: 1 Mi blocks (32 launch batches) straight after
+    # a two-batch code-load warm-up -- reported as `value_first_1Mi`, and it sizes a step
+    leg.timed(0, 2)
+    burst_batches = max(2, min(leg.resident_batches, (1 << 20) // B))
+    burst_dt, _ = leg.timed(0, burst_batches)
+    burst_rate = burst_batches * B / burst_dt
+    R = 1
+    if args.min_seconds > 0:
+        R = int(max(1, np.ceil(args.min_seconds * burst_rate / (K * B))))
+    if use_dist:    # every rank must run the same step size: take rank 0's
+        r_t = torch.tensor([R], dtype=torch.int64, device=dev)
+        dist.broadcast(r_t, 0)
+        R = int(r_t.item())
     for i in range(W):
-        step(i)
-    sync_engines()
+        leg.run(i * R, R)
+    leg.sync()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    # Steps alternate over the engine handles (double buffering: the latency-bound k_fit and
-    # the launch gaps of one batch hide under the other batch's kernels).  Kernel durations
-    # measured while two batches overlap would be inflated by the sharing, so with more than
-    # one handle the roofline leg times SOLO steps: every `profile_kernels`-th step of the
-    # timed region runs with the other handle drained (costs the overlap of that step).
-    solo = len(engs) > 1 and args.profile_kernels > 0
-    for e in engs:
-        e.profile_enable(0 if solo else args.profile_kernels)
-        e.profile_read()  # reset accumulators
-    profiled_steps = 0
+    # ---- the timed region: EXACTLY K steps, each R launch batches of B blocks.  Steps alternate
+    # over the engine handles (double buffering: the latency-bound k_fit and the launch gaps of
+    # one batch hide under the other batch's kernels); with more than one handle every
+    # `profile_kernels`-th launch batch runs SOLO with HIP events around its kernels (costs that
+    # batch's overlap; inside the timed region).
+    solo_every = args.profile_kernels if len(engs) > 1 else 0
+    leg.reset_profile()
+    if len(engs) == 1 and args.profile_kernels > 0:
+        eng.profile_enable(args.profile_kernels)
+    profiled = 0
     t0 = time.perf_counter()
     for i in range(K):
-        if solo and i % args.profile_kernels == 0:
-            sync_engines()
-            e = engs[i % len(engs)]
-            e.profile_enable(1)
-            step(i)
-            e.sync()
-            e.profile_enable(0)
-            profiled_steps += 1
-        else:
-            if not solo and args.profile_kernels > 0 and (i // len(engs)) % args.profile_kernels == 0:
-                profiled_steps += 1      # (the handle brackets every n-th of ITS batches)
-            step(i)
+        profiled += leg.run(i * R, R, solo_every)
     if len(engs) > 1:
-        sync_engines()
+        leg.sync()
+    elif args.profile_kernels > 0:
+        profiled = (K * R + args.profile_kernels - 1) // args.profile_kernels
     # K7 + C1: compact detected records, gather them to rank 0 (the only collective)
-    n_kept = eng.compact_device(rec.data_ptr(), total * T, kept.data_ptr())
+    n_kept = eng.compact_device(leg.rec.data_ptr(), total * T, kept.data_ptr())
     gathered = (parallel.gather_records(kept[:n_kept], world, rank, dev, force=use_dist)
                 if use_dist else kept[:n_kept])
     torch.cuda.synchronize()
@@ -419,91 +627,80 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    prof = {}
-    for e in engs:
-        for k, (ms, cnt) in e.profile_read().items():
-            prof[k] = (prof.get(k, (0.0, 0))[0] + ms, prof.get(k, (0.0, 0))[1] + cnt)
-        e.profile_enable(0)
+    prof = leg.read_profile()
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    # ---- one handle alone (what the roofline's solo kernel times belong to), a short leg
+    one_dt, one_n = None, 0
+    if len(engs) > 1 and args.min_seconds > 0:
+        one_n = int(max(8, min(K * R, 0.25 * args.min_seconds * burst_rate / B)))
+        one_dt, _ = leg.timed(0, one_n, 0, engs[:1])
 
     if rank == 0:
-        blocks_total = world * K * B
+        blocks_total = world * K * R * B
         value = blocks_total / dt
-        bytes_per_block = 2 * n + 64 * T
-        rename = {}
-        if pnum:   # the fused kernel is timed in k_correlate's event slot
-            rename["k_correlate"] = "k_preshift"
-        if n > 16384:   # long blocks: the correlate slot times the fused sub-transform + combination kernel
-            rename.update({"k_correlate": "k_correlate_sub", "k_carrier": "k_carrier_dit+k_select_dit"})
-        prof = {rename.get(k, k): v for k, v in prof.items() if v[1] > 0}
-        dom = max(prof, key=lambda k: prof[k][0]) if prof else None
-        dom_ms, dom_cnt = prof[dom] if prof else (0.0, 0)
-        if dom_cnt == 0:  # --profile-kernels 0: fall back to the whole step
-            dom, avg_ms, units = "all kernels of one step", dt / K * 1e3, float(B)
-        else:
-            avg_ms = dom_ms / dom_cnt
-            # blocks one launch of the dominant kernel processes (dense mix: every block reaches
-            # it)
-            units = B * max(profiled_steps, 1) / dom_cnt
-        achieved = bytes_per_block * units / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                key = args.config + ("_t%d" % T if T > 1 else "")
-                traffic = json.load(open(tpath)).get(key, {}).get(dom, {}).get("bytes_per_launch")
-            except Exception:
-                traffic = None
         metric = ("IQ blocks/sec (16384-sample, 1024-chip template)" if n == 16384
-                  else "IQ blocks/sec (%d-sample, %d-sample template)" % (n, wlen))
+                  else "IQ blocks/sec (%d-sample, %d-sample template)" % (n, leg.wlen))
         line = {
             "metric": metric,
             "value": value, "unit": "blocks/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[%d]: %s, %s mix, %d blocks per GPU resident in HBM "
-                                   "as u8 IQ" % (4 if (T > 1 and n == 16384) else cfg["idx"], cfg["label"],
-                                                 args.mix, total),
+            "config": {"workload": leg.workload_text(),
                        "name": args.config,
                        "variant": args.variant if not pnum else "preshift(num=%d)" % pnum,
-                       "blocks_per_step_per_gpu": B, "templates": T,
+                       "blocks_per_step_per_gpu": R * B, "launch_batches_per_step": R,
+                       "blocks_per_launch_batch": B, "templates": T,
                        "carrier_window": list(WINDOW_BINS), "thresholds": "15*snr",
                        "parallelism": "block-shard x%d" % world,
                        "handles_per_gpu": len(engs),
                        "detections_gathered": int(gathered.shape[0])},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_launch_ms": avg_ms, "launches": dom_cnt,
-                         "blocks_per_launch": units,
-                         "algorithmic_bytes_per_block": bytes_per_block,
-                         "algorithmic_bytes_per_launch": bytes_per_block * units,
-                         "all_kernels_ms": {k: v[0] / max(v[1], 1) for k, v in prof.items()},
-                         "all_kernels_launches_per_step": {k: v[1] / max(profiled_steps, 1) for k, v in prof.items()},
-                         # the kernel is VALU/LDS-bound, so the honest secondary view:
-                         # nominal 5 N log2 N flop per transform done by THIS kernel (+ 6N per
-                         # pointwise product) against the fp32 vector peak
-                         "compute": _compute_view(dom, n, T, units, avg_ms)},
-            "data_gen_s": t_gen,
+            # the sustained-rate protocol (wall clock over >= 1 M blocks after warm-up)
+            "timed_region_s": dt, "blocks_timed": blocks_total,
+            "value_first_1Mi": burst_rate,
+            "first_1Mi": {"blocks": burst_batches * B, "seconds": burst_dt,
+                          "note": "rank 0's first %d launch batches after a two-batch code-load warm-up (the "
+                                  "round-1/2 protocol), no gather" % burst_batches},
+            "value_1stream": (one_n * B / one_dt) if one_dt else None,
+            "one_stream": ({"blocks": one_n * B, "seconds": one_dt, "note": "one engine handle alone on rank 0, "
+                            "straight after the timed region"} if one_dt else None),
+            "roofline": leg.roofline(prof, profiled, dt / (K * R) * 1e3),
+            "data_gen_s": leg.t_gen,
         }
+        legs = []
+        if args.legs == "auto":
+            legs = (["c3", "t4", "sparse"] if (world == 1 and args.config == "c2" and T == 1 and not pnum
+                                               and args.mix == "dense") else [])
+        elif args.legs != "none":
+            legs = [x for x in args.legs.split(",") if x]
+        host_blocks = gpu_rec = None
         if world == 1 and args.cpu_seconds > 0:
             ns = min(total, 16384 if n == 16384 else 2048)
-            host_blocks = data[:ns].cpu().numpy()
-            line["cpu_baseline"] = cpu_baseline(
-                n, h, host_blocks, np.arange(first, first + ns), tpls[0], args.cpu_seconds,
-                rec.view(total, T, 64)[:ns, 0].cpu().numpy().view(F.RECORD_DTYPE).reshape(-1), pnum)
+            host_blocks = leg.data[:ns].cpu().numpy()
+            gpu_rec = leg.host_records(ns)
+        if legs:
+            leg.close()      # the main leg's 32 GiB go before the other configs' data arrive
+            torch.cuda.empty_cache()
+            line["configs"] = {}
+            for key in legs:
+                line["configs"][key] = extra_leg(torch, F, synth, dev, local, key, args.leg_seconds,
+                                                 cpu_ok=args.cpu_seconds > 0)
+                torch.cuda.empty_cache()
+        if host_blocks is not None:
+            line["cpu_baseline"] = cpu_baseline(n, h, host_blocks, np.arange(first, first + len(host_blocks)),
+                                                leg.tpls[0], args.cpu_seconds, gpu_rec, pnum)
             procs, how = physical_cores()
             if args.cpu_procs >= 0:
                 procs, how = args.cpu_procs, "--cpu-procs"
             if procs > 0 and not pnum:
-                ac = cpu_all_cores(n, h, host_blocks, tpls[0], procs, line["cpu_baseline"]["value"])
+                ac = cpu_all_cores(n, h, host_blocks, leg.tpls[0], procs, line["cpu_baseline"]["value"])
                 ac["procs_from"] = how
                 line["cpu_baseline"]["all_cores"] = ac
             if args.card_blocks > 0 and args.config == "c2" and T == 1 and not pnum:
-                for e in engs:      # free the benchmark's engines before the plumbing leg creates its own
-                    e.close()
+                if leg.engs:     # free the benchmark's engines before the plumbing leg creates its own
+                    leg.close()
                 line["cpu_baseline"]["card_to_toad"] = card_to_toad_leg(args.card_blocks)
         print(json.dumps(line))
     if use_dist:

@@ -28,7 +28,9 @@ extern "C" {
 /* (3: THR_N_KERNEL_SLOTS 4 -> 5 (the arrays of thr_profile_read grow; slot 4 = the long-block
  *    combination kernel); everything else unchanged) */
 /* 4: + thr_frame_card (addition only) */
-#define THR_ABI_VERSION 4
+/* 5: + thr_submit / thr_submit_card / thr_submit_stream / thr_collect / thr_inputs_consumed / thr_poll (asynchronous host
+ *    boundary), thr_set_stream_default, thr_format_toad (additions only) */
+#define THR_ABI_VERSION 5
 
 /* status codes */
 #define THR_OK 0
@@ -214,9 +216,60 @@ int thr_detect_device(thr_handle* h, const void* d_samples, int format,
 int thr_sync(thr_handle* h);
 /* Use an externally owned hipStream_t (e.g. a torch side stream); NULL restores the handle's own
  * (non-blocking) stream -- NOTE that torch's DEFAULT stream has the handle value 0, i.e. NULL:
- * passing it selects the engine's own stream, which does not synchronise with the legacy
- * default stream, so work queued there (fills, copies) must be complete before thr_detect_device. */
+ * passing it here selects the engine's own stream, which does not synchronise with the legacy
+ * default stream; to run ON the default stream call thr_set_stream_default() instead
+ * (thrifty_amd._native.Engine.set_stream(0) does). */
 int thr_set_stream(thr_handle* h, void* hip_stream);
+/* Run on the device's legacy default stream (the one torch's default stream and every other
+ * blocking stream are ordered with) -- what a caller holding `torch.cuda.current_stream()` on the
+ * default stream wants: fills and copies queued there are then ordered before the engine's
+ * kernels without any explicit synchronisation. */
+int thr_set_stream_default(thr_handle* h);
+
+/*
+ * Asynchronous host boundary (precedent: the producer/consumer split fastdet
+ * planned and never built, fastdet/fastdet.cpp:179-180).  thr_submit*() is thr_detect*() for ONE
+ * batch (n_blocks <= max_batch) cut in two: it stages the inputs, enqueues the copies and kernels,
+ * and returns a ticket while the device works; thr_collect(ticket) waits for that batch and fills
+ * the `out` array given at submit time (caller-owned; it must stay valid and untouched until the
+ * collect returns -- the records travel through pinned staging owned by the library).  The INPUT
+ * arrays (samples / text / stream, offsets, indices) must stay valid until
+ * thr_inputs_consumed(ticket) -- which waits for the batch's host-to-device copies only, not for
+ * its kernels -- or thr_collect(ticket) has returned.  Up to THR_MAX_IN_FLIGHT tickets may be open per
+ * handle (a further submit fails with THR_ERR_STATE); tickets may be collected in any order, each
+ * exactly once; batches execute in submission order.  Ticket 0 is what an empty batch gets and
+ * needs no collect.  The synchronous host entry points refuse to run while tickets are open.
+ * thr_poll: *done = 1 if thr_collect(ticket) would not block.
+ * Same single-threaded-per-handle rule as everything else.
+ */
+#define THR_MAX_IN_FLIGHT 3
+int thr_submit(thr_handle* h, const void* samples, int format, const int64_t* block_idx,
+               size_t n_blocks, thr_record* out, uint64_t* ticket);
+int thr_submit_card(thr_handle* h, const char* text, size_t text_len, const int64_t* payload_off,
+                    const int64_t* block_idx, size_t n_blocks, thr_record* out, uint64_t* ticket);
+int thr_submit_stream(thr_handle* h, const uint8_t* stream, size_t n_bytes, int64_t first_block_idx,
+                      thr_record* out, size_t out_capacity, size_t* n_blocks_out, uint64_t* ticket);
+int thr_collect(thr_handle* h, uint64_t ticket);
+int thr_inputs_consumed(thr_handle* h, uint64_t ticket);
+int thr_poll(thr_handle* h, uint64_t ticket, int* done);
+
+/*
+ * `.toad` text for a batch of DETECTED records -- replaces `DetectionResult.serialize`
+ * (thrifty/toads_data.py:47-61) called once per detection by detector_cli (detect.py:217-219).
+ * One line per record, each ending in '\n':
+ *   [rxid ][txid ]t block soa sample offset energy noise cbin coffset cenergy cnoise
+ * t as %.6f, soa = new_len * block_idx + corr_sample + corr_offset as %.8f, the integers as
+ * str(int), every other float as Python's repr() of the value widened to a double (what
+ * '{}'.format gives for a float and for an np.float32).  with_rxid / with_txid: prepend the
+ * ids like serialize() does for values that are not None (txid = the record's template_id:
+ * multi-template detection); carrier_offset_f32: round the carrier offset to float32 first
+ * (PreshiftDetector's np.float32 offset).  `out_capacity` must be >= n * THR_TOAD_LINE_MAX.
+ * Host only, no device, handle-free.
+ */
+#define THR_TOAD_LINE_MAX 384
+int thr_format_toad(const thr_record* recs, const double* timestamps, size_t n, int64_t new_len,
+                    int with_rxid, int64_t rxid, int with_txid, int carrier_offset_f32, char* out,
+                    size_t out_capacity, size_t* out_len);
 
 /*
  * K7: keep only records whose THR_FLAG_CORR is set, preserving order -- what

@@ -31,7 +31,8 @@ def _world_sizes():
 
 
 def _torchrun(k, target, extra, timeout=600):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+    # (THRIFTY_SHARDED: what the CLI's own re-launch sets -- marks the ranks as its children)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT, THRIFTY_SHARDED="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(k),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + target + extra
     res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
@@ -148,3 +149,65 @@ def test_thrifty_detect_raw_gpus_cli_equals_single_process(tmp_path):
     one = fields(tmp_path / "one.toad")
     assert fields(tmp_path / "rank.toad") == one
     assert len(one) >= planted - 2 and all(f[0] == "2" for f in one)
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE configs[4]: 4 TX templates per block AND the block shard, together
+# ---------------------------------------------------------------------------------------------
+def _multi_reference(n_blocks, seed, T=4):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dist_detect_worker as w
+    from thrifty_amd import _native as F
+    tpls, blocks = w.make_blocks(n_blocks, seed, T)
+    rec = F.Engine(16384, 4096, tpls, (0, 15, 0), (7, 110), (0, 15, 0), max_batch=n_blocks).detect(
+        blocks, np.arange(n_blocks))
+    flat = rec.reshape(-1)
+    return flat[(flat["flags"] & F.FLAG_CORR) != 0]
+
+
+@pytest.mark.parametrize("k,backend", [(k, "nccl") for k in _world_sizes()] + [(2, "gloo"), (5, "gloo"), (8, "gloo")])
+def test_multi_template_shard_keeps_block_template_order(tmp_path, k, backend):
+    """4 templates x K-way block shard: rank 0's gathered records == the single-process records,
+    byte for byte, ordered [block][template] (nccl at the box's device counts; gloo K = 2 / 5 / 8
+    with every rank on GPU 0 for the world sizes the box cannot give to RCCL)."""
+    from thrifty_amd import _native as F
+    n_blocks, seed = 61, 91
+    out = str(tmp_path / "gathered.npy")
+    _torchrun(k, [os.path.join(ROOT, "tests", "dist_detect_worker.py")],
+              ["--blocks", str(n_blocks), "--seed", str(seed), "--out", out, "--templates", "4",
+               "--backend", backend])
+    got = np.load(out).reshape(-1).view(F.RECORD_DTYPE)
+    want = _multi_reference(n_blocks, seed)
+    assert len(want) > 25 and len(set(want["template_id"].tolist())) == 4
+    assert got.tobytes() == want.tobytes()
+    keys = list(zip(got["block_idx"].tolist(), got["template_id"].tolist()))
+    assert keys == sorted(keys)
+
+
+def test_thrifty_detect_templates_gpus_cli_equals_single_process(golden, tmp_path):
+    """`python -m thrifty_amd.detect --templates a.npy b.npy c.npy d.npy --gpus 1 rx.card -o out`
+    (one rank under torchrun: shard, gather, rank-0 writer) == the single-process CLI's file;
+    every line carries rxid then txid; template 0's lines are the single-template run's."""
+    from thrifty_amd import synth
+    from thrifty_amd.detect import Detector, detector_cli
+    g = golden("c2")
+    _write_case(tmp_path, g)
+    names = []
+    for i in range(4):       # template 0 = the golden's own template
+        t = g["template"] if i == 0 else synth.gold_template(10, 3 + i).astype(np.float64)
+        np.save(tmp_path / ("t%d.npy" % i), t)
+        names.append(str(tmp_path / ("t%d.npy" % i)))
+    common = [str(tmp_path / "rx.card"), "--quiet", "-c", str(tmp_path / "detector.cfg"), "--templates"] + names
+    detector_cli(Detector, argv=common + ["-o", str(tmp_path / "one.toads")])
+    _torchrun(1, ["-m", "thrifty_amd.detect"], ["--gpus", "1"] + common + ["-o", str(tmp_path / "rank.toads")])
+    one = (tmp_path / "one.toads").read_text()
+    assert (tmp_path / "rank.toads").read_text() == one
+    lines = [ln.split() for ln in one.strip().split("\n")]
+    assert all(ln[0] == "0" and ln[1] in "0123" and len(ln) == 13 for ln in lines)
+    detector_cli(Detector, argv=common[:4] + ["-o", str(tmp_path / "single.toad")])
+    single = [ln.split() for ln in (tmp_path / "single.toad").read_text().strip().split("\n")]
+    tx0 = [ln[:1] + ln[2:] for ln in lines if ln[1] == "0"]
+    assert [ln[:5] for ln in tx0] == [ln[:5] for ln in single]       # rxid, time, block, soa, sample
+    # the non-quiet loop prints the same detections
+    detector_cli(Detector, argv=[a for a in common if a != "--quiet"] + ["-o", str(tmp_path / "loud.toads")])
+    assert (tmp_path / "loud.toads").read_text() == one

@@ -121,8 +121,18 @@ class _FakeEngine(object):
         self.recs = self.recs[len(idx):]
         return out.reshape(-1, 1)
 
+    def submit(self, arr, idx):          # the asynchronous pair the iterator drives
+        self.open += 1
+        return self.detect(arr, idx)
 
-def _bare_detector(recs, blocks, batch_size):
+    def collect(self, ticket):
+        self.open -= 1
+        return ticket
+
+    open = 0
+
+
+def _bare_detector(recs, blocks, batch_size, max_wait=float("inf")):
     d = detect.Detector.__new__(detect.Detector)
     d.settings = detect.DetectorSettings(64, 16, 8, (0, 15, 0), (0, -1), np.ones(8), (0, 15, 0))
     d._card = d._raw = None
@@ -131,6 +141,7 @@ def _bare_detector(recs, blocks, batch_size):
     d._engine = _FakeEngine(recs)
     from collections import deque
     d._ready, d._exhausted, d.only_detections = deque(), False, False
+    d._in_flight, d.max_wait = None, max_wait
     return d
 
 
@@ -154,6 +165,21 @@ def test_index_error_surfaces_at_its_block_after_earlier_results():
     assert raised == "index 65 is out of bounds for axis 0 with size 64"
     # and the iterator is finished afterwards, like a crashed loop
     assert list(d) == []
+    assert d._engine.open == 0        # the batch that was in flight behind the error was collected
+
+
+def test_batches_are_submitted_one_ahead_and_all_collected():
+    """File-like sources: batch i + 1 is submitted before batch i is collected (the device works
+    while the host formats), results still come out in input order, no ticket stays open."""
+    recs = np.zeros(10, dtype=_native.RECORD_DTYPE)
+    recs["flags"] = 3
+    recs["corr_sample"] = np.arange(10)
+    blocks = [(float(i), i, np.zeros(64, dtype=np.complex64)) for i in range(10)]
+    d = _bare_detector(recs, blocks, batch_size=3)
+    first = next(d)
+    assert first[1].block == 0 and d._engine.open == 1      # batch 1 is in flight behind batch 0
+    assert [r.block for _, r in d] == list(range(1, 10))
+    assert d._engine.open == 0
 
 
 def test_slow_source_is_not_held_for_a_full_batch():
@@ -164,9 +190,85 @@ def test_slow_source_is_not_held_for_a_full_batch():
             time.sleep(0.05)
             yield float(i), i, np.zeros(64, dtype=np.complex64)
 
-    d = _bare_detector(recs, slow(), batch_size=1024)
+    d = _bare_detector(recs, slow(), batch_size=1024, max_wait=0.002)   # what a `.live` source gets
     t0 = time.perf_counter()
     first = next(d)
     assert time.perf_counter() - t0 < 0.15      # not 4 x 0.05 s (the whole source)
     assert first[1].block == 0
     assert [r.block for _, r in d] == [1, 2, 3]
+
+
+def test_format_toad_is_serialize_byte_for_byte():
+    """thr_format_toad (host routine of the engine library) == DetectionResult.serialize() ==
+    the reference's format string (toads_data.py:47-61): shortest-repr floats, %.6f / %.8f,
+    np.float32 fields printed widened, ids in front."""
+    rng = np.random.default_rng(3)
+    n = 4000
+    recs = np.zeros(n, dtype=_native.RECORD_DTYPE)
+    recs["block_idx"] = rng.integers(0, 1 << 34, n)
+    recs["template_id"] = rng.integers(0, 8, n)
+    recs["carrier_bin"] = rng.integers(0, 16384, n)
+    recs["corr_sample"] = rng.integers(0, 16384, n)
+    recs["corr_offset"] = rng.uniform(-0.6, 0.6, n)
+    recs["carrier_offset"] = rng.standard_normal(n) * 10.0 ** rng.integers(-9, 3, n)
+    for f in ("carrier_energy", "carrier_noise", "corr_energy", "corr_noise"):
+        recs[f] = (rng.standard_normal(n) * 10.0 ** rng.integers(-8, 18, n)).astype(np.float32)
+    special = [0.0, -0.0, 1e16, 1e15, 1e-4, 1e-5, 123456789012345678.0, 1.0, -1.5, 5e-324, 0.1, 2.5e-7]
+    recs["carrier_offset"][:len(special)] = special
+    recs["corr_energy"][:4] = [0.0, 1.0, 16777216.0, 1e-30]
+    stamps = rng.uniform(0, 2e9, n)
+    stamps[:4] = [0.0, 0.0000005, 1234567890.1234565, 0.9999995]      # rounding ties / carries
+    for rxid, multi, f32 in ((None, False, False), (-1, False, False), (7, True, False), (2, False, True)):
+        text = _native.format_toad(recs, stamps, 12288, rxid=rxid, with_txid=multi, carrier_offset_f32=f32)
+        want = []
+        for r, ts in zip(recs, stamps):
+            off = np.float32(r["carrier_offset"]) if f32 else float(r["carrier_offset"])
+            res = toads_data.DetectionResult(
+                float(ts), int(r["block_idx"]),
+                12288 * int(r["block_idx"]) + int(r["corr_sample"]) + float(r["corr_offset"]),
+                toads_data.CarrierSyncInfo(int(r["carrier_bin"]), off, np.float32(r["carrier_energy"]),
+                                           np.float32(r["carrier_noise"])),
+                toads_data.CorrDetectionInfo(int(r["corr_sample"]), float(r["corr_offset"]),
+                                             float(r["corr_energy"]), float(r["corr_noise"])),
+                rxid=rxid, txid=int(r["template_id"]) if multi else None)
+            want.append(res.serialize())
+        assert text.decode().split("\n") == want + [""]
+    assert _native.format_toad(recs[:0], stamps[:0], 1) == b""
+
+
+class _FakeMultiEngine(_FakeEngine):
+    def detect(self, arr, idx):
+        t = 3
+        out = self.recs[:len(idx) * t].copy().reshape(len(idx), t)
+        out["block_idx"] = np.asarray(idx)[:, None]
+        out["template_id"] = np.arange(t)[None, :]
+        self.recs = self.recs[len(idx) * t:]
+        return out
+
+
+def test_multi_template_iteration_groups_per_block_with_txid():
+    recs = np.zeros(12, dtype=_native.RECORD_DTYPE)
+    recs["flags"] = [3, 1, 3, 0, 0, 0, 3, 3, 3, 1, 1, 3]      # block 1: no carrier at all
+    recs["corr_sample"] = np.arange(12)
+    blocks = [(float(i), 10 + i, np.zeros(64, dtype=np.complex64)) for i in range(4)]
+    d = _bare_detector(recs, blocks, batch_size=3)
+    d.__class__ = detect.MultiTemplateDetector
+    d.n_templates = 3
+    d._engine = _FakeMultiEngine(recs)
+    out = list(d)
+    assert [len(per_tx) for per_tx in out] == [3, 3, 3, 3]
+    assert [[(det, res.block, res.txid) for det, res in per_tx] for per_tx in out] == [
+        [(True, 10, 0), (False, 10, 1), (True, 10, 2)], [(False, 11, 0), (False, 11, 1), (False, 11, 2)],
+        [(True, 12, 0), (True, 12, 1), (True, 12, 2)], [(False, 13, 0), (False, 13, 1), (True, 13, 2)]]
+    # the flat record iterator: detections only, [block][template] order, stamps repeated
+    d2 = _bare_detector(recs, blocks, batch_size=3)
+    d2.__class__, d2.n_templates, d2._engine = detect.MultiTemplateDetector, 3, _FakeMultiEngine(recs)
+    flat = [(float(ts), int(r["block_idx"]), int(r["template_id"]))
+            for stamps, rr in d2.iter_detected_records() for ts, r in zip(stamps, rr)]
+    assert flat == [(0.0, 10, 0), (0.0, 10, 2), (2.0, 12, 0), (2.0, 12, 1), (2.0, 12, 2), (3.0, 13, 2)]
+    # only_detections: a block's detected templates, blocks without any are skipped
+    d3 = _bare_detector(recs, blocks, batch_size=4)
+    d3.__class__, d3.n_templates, d3._engine = detect.MultiTemplateDetector, 3, _FakeMultiEngine(recs)
+    d3.only_detections = True
+    assert [[(res.block, res.txid) for _, res in per_tx] for per_tx in d3] == [
+        [(10, 0), (10, 2)], [(12, 0), (12, 1), (12, 2)], [(13, 2)]]

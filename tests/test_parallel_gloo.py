@@ -234,3 +234,95 @@ def test_run_sharded_two_ranks_writes_one_ordered_toad(tmp_path, fail_at):
         assert results == {0: None, 1: None}
     else:       # every rank raises, like the single-process loop
         assert "out of bounds" in results[1] and "IndexError" in results[0], results
+
+
+class _FakeMultiDetections(_FakeDetections):
+    """Multi-template flavour: T records per detected block, ordered [block][template], the
+    template id in `template_id` (what MultiTemplateDetector.iter_detected_records yields)."""
+
+    _multi, T = True, 4
+
+    @classmethod
+    def records(cls, positions):
+        base = _FakeDetections.records(np.repeat(np.asarray(positions, dtype=np.int64), cls.T))
+        base["template_id"] = np.tile(np.arange(cls.T), len(positions))
+        base["corr_energy"] += base["template_id"]
+        keep = (base["block_idx"] + base["template_id"]) % 5 != 0     # some templates undetected
+        return base[keep], keep
+
+    def iter_detected_records(self):
+        for s in range(self.lo, self.hi, 5):
+            pos = [p for p in range(s, min(s + 5, self.hi)) if p % 3 != 1]
+            if pos:
+                recs, keep = self.records(pos)
+                yield np.repeat(0.5 * np.asarray(pos, dtype=np.float64), self.T)[keep], recs
+
+
+def _sharded_multi_worker(rank, world, port, n, out_path, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    lo, hi = parallel.shard_range(n, rank, world)
+    out = open(out_path, "w") if rank == 0 else None
+    try:
+        parallel.run_sharded(_FakeMultiDetections(lo, hi), rank, world, 0, out, backend="gloo")
+        ret.put((rank, None))
+    finally:
+        if out is not None:
+            out.close()
+
+
+def test_run_sharded_multi_template_keeps_block_template_order_and_txid(tmp_path):
+    """BASELINE configs[4] host side: T records per block cross the gather ordered
+    [block][template]; rank 0 writes them with the template id as txid (the reference's
+    serialize() puts txid after rxid, toads_data.py:57-61)."""
+    import torch.multiprocessing as mp
+    from thrifty_amd import toads_data
+    n, world = 23, 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    out_path = str(tmp_path / "rx.toads")
+    procs = [ctx.Process(target=_sharded_multi_worker, args=(r, world, port, n, out_path, ret))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(ret.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert results == {0: None, 1: None}
+    pos = [p for p in range(n) if p % 3 != 1]
+    recs, keep = _FakeMultiDetections.records(pos)
+    stamps = np.repeat(0.5 * np.asarray(pos, dtype=np.float64), _FakeMultiDetections.T)[keep]
+    want = []
+    for r, ts in zip(recs, stamps):      # one DetectionResult per record, serialised the reference's way
+        res = toads_data.DetectionResult(
+            float(ts), int(r["block_idx"]), 48 * int(r["block_idx"]) + int(r["corr_sample"]) + float(r["corr_offset"]),
+            toads_data.CarrierSyncInfo(int(r["carrier_bin"]), float(r["carrier_offset"]),
+                                       np.float32(r["carrier_energy"]), np.float32(r["carrier_noise"])),
+            toads_data.CorrDetectionInfo(int(r["corr_sample"]), float(r["corr_offset"]),
+                                         float(r["corr_energy"]), float(r["corr_noise"])),
+            rxid=3, txid=int(r["template_id"]))
+        want.append(res.serialize())
+    got = open(out_path).read().split("\n")
+    assert got[-1] == "" and got[:-1] == want
+    keys = [(int(g.split()[3]), int(g.split()[1])) for g in got[:-1]]     # (block, txid)
+    assert keys == sorted(keys)
+
+
+def test_sharded_env_needs_the_marker(monkeypatch):
+    """RANK / WORLD_SIZE inherited from an unrelated launcher do not make a plain `thrifty
+    detect` a rank of a sharded run; the re-launched children carry THRIFTY_SHARDED=1."""
+    monkeypatch.setenv("RANK", "1")
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.delenv("THRIFTY_SHARDED", raising=False)
+    assert parallel.sharded_env() == (0, None, 0)
+    monkeypatch.setenv("THRIFTY_SHARDED", "1")
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    assert parallel.sharded_env() == (1, 4, 1)
+
+
+def test_gpus_without_an_output_file_is_refused():
+    from thrifty_amd.detect import Detector, detector_cli
+    with pytest.raises(SystemExit) as exc:
+        detector_cli(Detector, argv=["rx.card", "--gpus", "2", "--quiet"])
+    assert "output file" in str(exc.value)

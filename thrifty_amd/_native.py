@@ -20,14 +20,18 @@ FLAG_CORR = 2
 FLAG_INDEX_ERROR = 4
 N_KERNEL_SLOTS = 5
 
-ABI_VERSION = 4     # THR_ABI_VERSION of include/thrifty_hip.h
+ABI_VERSION = 5     # THR_ABI_VERSION of include/thrifty_hip.h
 
 EXPORTS = [
     "thr_abi_version", "thr_last_error", "thr_create", "thr_destroy", "thr_detect",
     "thr_create_preshift", "thr_create_fastdet", "thr_detect_card", "thr_detect_stream", "thr_detect_stream_device", "thr_detect_device", "thr_sync", "thr_set_stream", "thr_compact_device",
     "thr_profile_enable", "thr_profile_read", "thr_kernel_name", "thr_debug_fft",
     "thr_debug_stage", "thr_identify", "thr_frame_card",
+    "thr_submit", "thr_submit_card", "thr_submit_stream", "thr_collect", "thr_inputs_consumed", "thr_poll",
+    "thr_set_stream_default", "thr_format_toad",
 ]
+MAX_IN_FLIGHT = 3       # THR_MAX_IN_FLIGHT
+TOAD_LINE_MAX = 384     # THR_TOAD_LINE_MAX
 
 
 class ThrSettings(C.Structure):
@@ -118,6 +122,17 @@ def load_library():
     lib.thr_detect_stream.argtypes = [vp, vp, C.c_size_t, C.c_int64, vp, C.c_size_t,
                                       C.POINTER(C.c_size_t)]
     lib.thr_detect_stream_device.argtypes = [vp, vp, vp, C.c_size_t, vp]
+    u64p = C.POINTER(C.c_uint64)
+    lib.thr_submit.argtypes = [vp, vp, C.c_int, vp, C.c_size_t, vp, u64p]
+    lib.thr_submit_card.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_size_t, vp, u64p]
+    lib.thr_submit_stream.argtypes = [vp, vp, C.c_size_t, C.c_int64, vp, C.c_size_t,
+                                      C.POINTER(C.c_size_t), u64p]
+    lib.thr_collect.argtypes = [vp, C.c_uint64]
+    lib.thr_inputs_consumed.argtypes = [vp, C.c_uint64]
+    lib.thr_poll.argtypes = [vp, C.c_uint64, C.POINTER(C.c_int)]
+    lib.thr_set_stream_default.argtypes = [vp]
+    lib.thr_format_toad.argtypes = [vp, vp, C.c_size_t, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int,
+                                    vp, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.thr_sync.argtypes = [vp]
     lib.thr_set_stream.argtypes = [vp, vp]
     lib.thr_compact_device.argtypes = [vp, vp, C.c_size_t, vp, C.POINTER(C.c_size_t)]
@@ -152,6 +167,33 @@ def frame_card(buf, start, stop, block_len, at_eof, max_records):
     del arr
     k = n.value
     return ts[:k], idx[:k], off[:k] + start, start + used.value
+
+
+def format_toad(recs, timestamps, new_len, rxid=None, with_txid=False, carrier_offset_f32=False):
+    """thr_format_toad: `.toad` text (bytes, one '\\n'-terminated line per record) for a batch of
+    DETECTED records -- the text `DetectionResult.serialize()` produces, without per-record
+    objects.  with_txid: prepend each record's template_id as the txid column."""
+    lib = load_library()
+    recs = np.ascontiguousarray(recs, dtype=RECORD_DTYPE).reshape(-1)
+    ts = np.ascontiguousarray(timestamps, dtype=np.float64).reshape(-1)
+    n = len(recs)
+    assert len(ts) == n
+    buf = np.empty(max(1, n * TOAD_LINE_MAX), dtype=np.uint8)
+    used = C.c_size_t(0)
+    _check(lib, lib.thr_format_toad(recs.ctypes.data, ts.ctypes.data, n, int(new_len),
+                                    0 if rxid is None else 1, 0 if rxid is None else int(rxid),
+                                    int(bool(with_txid)), int(bool(carrier_offset_f32)),
+                                    buf.ctypes.data, buf.size, C.byref(used)))
+    return buf[:used.value].tobytes()
+
+
+class Ticket(object):
+    """An open thr_submit*(): the records array the library will fill and the inputs it may
+    still be reading (kept alive here)."""
+    __slots__ = ("id", "out", "keep")
+
+    def __init__(self, tid, out, keep):
+        self.id, self.out, self.keep = tid, out, keep
 
 
 FREQ_RANGE_DTYPE = np.dtype([("rxid", "<i4"), ("txid", "<i4"), ("lo", "<f8"), ("hi", "<f8")])
@@ -285,6 +327,69 @@ class Engine(object):
         assert got.value == nb
         return out
 
+    # ---- asynchronous host path: submit a batch, collect its records later --
+    def _idx_ptr(self, block_idx, nb):
+        if block_idx is None:
+            return None, None
+        idx = np.ascontiguousarray(np.asarray(block_idx, dtype=np.int64))
+        assert idx.shape == (nb,)
+        return idx, idx.ctypes.data
+
+    def submit(self, blocks, block_idx=None):
+        """thr_submit: like detect() for ONE batch (<= max_batch blocks), but returns a Ticket at
+        once; `collect(ticket)` -> records [B, n_templates].  Up to MAX_IN_FLIGHT may be open."""
+        a, fmt = self._as_input(blocks)
+        nb = a.shape[0]
+        out = np.zeros((nb, self.n_templates), dtype=RECORD_DTYPE)
+        idx, idx_p = self._idx_ptr(block_idx, nb)
+        t = C.c_uint64(0)
+        _check(self._lib, self._lib.thr_submit(self._h, a.ctypes.data, fmt, idx_p, nb, out.ctypes.data,
+                                               C.byref(t)))
+        return Ticket(t.value, out, (a, idx))
+
+    def submit_card(self, text, payload_off, block_idx=None):
+        """thr_submit_card (see detect_card)."""
+        buf = np.frombuffer(text, dtype=np.uint8)
+        off = np.ascontiguousarray(np.asarray(payload_off, dtype=np.int64))
+        nb = off.shape[0]
+        out = np.zeros((nb, self.n_templates), dtype=RECORD_DTYPE)
+        idx, idx_p = self._idx_ptr(block_idx, nb)
+        t = C.c_uint64(0)
+        _check(self._lib, self._lib.thr_submit_card(self._h, buf.ctypes.data, buf.size, off.ctypes.data,
+                                                    idx_p, nb, out.ctypes.data, C.byref(t)))
+        # (`text` itself is NOT kept: a reader's bytearray must stay resizable -- the caller keeps
+        # it valid until inputs_consumed() / collect())
+        return Ticket(t.value, out, (off, idx))
+
+    def submit_stream(self, stream, first_block_idx=0):
+        """thr_submit_stream (see detect_stream)."""
+        buf = np.frombuffer(stream, dtype=np.uint8)
+        stride = 2 * (self.block_len - self.history_len)
+        nb = 0 if buf.size < 2 * self.block_len else (buf.size - 2 * self.block_len) // stride + 1
+        out = np.zeros((nb, self.n_templates), dtype=RECORD_DTYPE)
+        got, t = C.c_size_t(0), C.c_uint64(0)
+        _check(self._lib, self._lib.thr_submit_stream(self._h, buf.ctypes.data, buf.size,
+                                                      int(first_block_idx), out.ctypes.data, nb,
+                                                      C.byref(got), C.byref(t)))
+        assert got.value == nb
+        return Ticket(t.value, out, None)
+
+    def collect(self, ticket):
+        """thr_collect: wait for the ticket's batch -> its records [B, n_templates]."""
+        _check(self._lib, self._lib.thr_collect(self._h, ticket.id))
+        ticket.keep = None
+        return ticket.out
+
+    def inputs_consumed(self, ticket):
+        """thr_inputs_consumed: wait until the ticket's input arrays may be overwritten."""
+        _check(self._lib, self._lib.thr_inputs_consumed(self._h, ticket.id))
+        ticket.keep = None
+
+    def poll(self, ticket):
+        done = C.c_int(0)
+        _check(self._lib, self._lib.thr_poll(self._h, ticket.id, C.byref(done)))
+        return bool(done.value)
+
     # ---- device-resident path (pointers are plain integers) ---------------
     def detect_stream_device(self, d_stream, n_blocks, d_out, d_block_idx=None):
         _check(self._lib, self._lib.thr_detect_stream_device(self._h, d_stream, d_block_idx,
@@ -304,7 +409,16 @@ class Engine(object):
         _check(self._lib, self._lib.thr_sync(self._h))
 
     def set_stream(self, stream_ptr):
-        _check(self._lib, self._lib.thr_set_stream(self._h, stream_ptr))
+        """Run on the caller's HIP stream.  0 / None -- the handle value of torch's DEFAULT stream
+        -- selects the device's legacy default stream (ordered with torch's fills and copies
+        there); `use_own_stream()` goes back to the engine's private non-blocking stream."""
+        if not stream_ptr:
+            _check(self._lib, self._lib.thr_set_stream_default(self._h))
+        else:
+            _check(self._lib, self._lib.thr_set_stream(self._h, stream_ptr))
+
+    def use_own_stream(self):
+        _check(self._lib, self._lib.thr_set_stream(self._h, None))
 
     def profile_enable(self, every=1):
         """every = n > 0: time the kernels of every n-th batch; 0/False: off."""

@@ -62,6 +62,32 @@ def _fixed_chunks(stream, nbytes):
         pending = b""
 
 
+def is_live(stream):
+    """True if `stream` reads from a pipe, socket or terminal -- a source that delivers blocks as
+    they are captured (a regular file or an in-memory stream is not)."""
+    try:
+        mode = os.fstat(stream.fileno()).st_mode
+    except (AttributeError, OSError, ValueError):
+        return False
+    return stat.S_ISFIFO(mode) or stat.S_ISSOCK(mode) or stat.S_ISCHR(mode)
+
+
+class _BlockIterator(object):
+    """The classic readers' generator plus `.live` (is_live of the stream): a batching consumer
+    stops filling a batch when a live source makes it wait (thrifty_amd.detect.Detector)."""
+
+    def __init__(self, gen, live):
+        self._gen, self.live = gen, live
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        return next(self._gen)
+
+    next = __next__
+
+
 def block_reader(stream, size, history):
     """Overlapping blocks from a raw u8 I/Q stream (reference block_data.py:70-98).
 
@@ -69,6 +95,10 @@ def block_reader(stream, size, history):
     `size - history` new ones; the very first history is 0.0 (not quantiser
     zero), exactly like the reference, so block 0 has no u8 twin.
     """
+    return _BlockIterator(_block_reader(stream, size, history), is_live(stream))
+
+
+def _block_reader(stream, size, history):
     new = size - history
     data = np.zeros(size)
     raw_hist = None
@@ -92,6 +122,10 @@ def card_reader(stream):
     """Blocks from a .card stream: `<timestamp> <block_idx> <base64 u8 I/Q>` per line;
     `#` comments, blank lines and fastcard's banner lines are skipped
     (reference block_data.py:101-131)."""
+    return _BlockIterator(_card_reader(stream), is_live(stream))
+
+
+def _card_reader(stream):
     while True:
         line = stream.readline()
         if len(line) == 0:
@@ -204,6 +238,13 @@ class CardStream(object):
     def mapped(self):
         """True if the input is a regular file read through mmap (no read buffer of our own)."""
         return isinstance(self._buf, mmap.mmap)
+
+    def ready(self):
+        """True if next_batch() would not have to WAIT for the source: a mapped file, unconsumed
+        text in the buffer, or a descriptor that is readable right now (data or EOF).  A Detector
+        only reads ahead of the batch it is about to hand out when this holds -- on a live pipe the
+        results of what HAS arrived must not wait for the next line."""
+        return self.mapped or self._eof or self._end > self._pos or _readable_within(self.stream, 0)
 
     def shard(self, rank, world):
         """Restrict a mapped .card file to the rank-th of `world` contiguous byte ranges, cut at
@@ -328,6 +369,10 @@ class CardStream(object):
             return None
         return stamps, np.asarray(idxs, dtype=np.int64), buf, np.asarray(offs, dtype=np.int64)
 
+    @property
+    def live(self):
+        return is_live(self.stream)
+
     def __iter__(self):
         while True:
             batch = self.next_batch(64)
@@ -378,6 +423,13 @@ class RawStream(object):
     def mapped(self):
         """True if the input is a regular file read through mmap."""
         return self._map is not None
+
+    def ready(self):
+        """True if next_batch() would not have to WAIT for the source (see CardStream.ready)."""
+        if self._map is not None or self._eof:
+            return True
+        pending = self._have - self._consumed - 2 * self.history
+        return pending >= 2 * self.new or _readable_within(self.stream, 0)
 
     def shard(self, rank, world):
         """Restrict a mapped raw file to this rank's contiguous block range.  The lead-in blocks
@@ -500,6 +552,10 @@ class RawStream(object):
         self._next_idx += n
         self._off += n * step
         return "u8", [time.time()] * n, idxs, view
+
+    @property
+    def live(self):
+        return is_live(self.stream)
 
     def __iter__(self):
         return block_reader(self.stream, self.size, self.history)

@@ -41,19 +41,26 @@ def build_native(force=False, verbose=False):
     # the SLP vectorizer only adds v_mov shuffles (see csrc/fft_regs.hpp)
     extra = os.environ.get("THR_EXTRA_CFLAGS", "").split()
     jobs = []
+    objs = []
+    # an object is rebuilt when its source, any shared header or this file is newer than it (every
+    # translation unit includes the shared headers); THR_EXTRA_CFLAGS builds are never reused
+    common = [os.path.join(CSRC, hname) for hname in HEADERS] + [os.path.abspath(__file__)]
+    newest_common = max(os.path.getmtime(d) for d in common)
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(obj)
+        if (not force and not extra and os.path.exists(obj) and
+                os.path.getmtime(obj) > max(newest_common, os.path.getmtime(os.path.join(CSRC, src)))):
+            continue
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
                "-fno-slp-vectorize"] + PER_FILE_FLAGS.get(src, []) + extra + [
                    "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         jobs.append((subprocess.Popen(cmd), cmd, obj))   # the translation units build in parallel
-    objs = []
     for proc, cmd, obj in jobs:
         if proc.wait() != 0:
             raise subprocess.CalledProcessError(proc.returncode, cmd)
-        objs.append(obj)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))

@@ -132,27 +132,34 @@ struct thr_handle {
     float2* d_bank = nullptr;   // [num][N]; 16384: [k3][k1][k2] gather layout, else natural order
     // host-buffer entry points (thr_detect / _stream / _card): two sets of staging buffers so
     // that the H2D copy of chunk i + 1 (copy stream) runs under the kernels of chunk i (lazy)
+    static constexpr int kPipeDepth = THR_MAX_IN_FLIGHT;
     struct HostPipe {
         bool ready = false;
         hipStream_t copy = nullptr;
-        hipEvent_t ev_h2d[2] = {nullptr, nullptr};    // chunk's inputs have landed (copy stream)
-        hipEvent_t ev_done[2] = {nullptr, nullptr};   // chunk's records are in h_rec (main stream)
-        void* d_in[2] = {nullptr, nullptr};
-        size_t in_bytes[2] = {0, 0};
-        long long* d_idx[2] = {nullptr, nullptr};
-        thr_record* d_rec[2] = {nullptr, nullptr};
-        thr_record* h_rec[2] = {nullptr, nullptr};    // pinned: D2H never blocks the host
-        unsigned char* d_text[2] = {nullptr, nullptr};
-        size_t text_bytes[2] = {0, 0};
-        long long* d_off[2] = {nullptr, nullptr};
-        int* d_bad[2] = {nullptr, nullptr};
-        int* h_bad = nullptr;                         // pinned int[2]
-        std::vector<long long> idx_host[2], off_host[2];
+        hipEvent_t ev_h2d[kPipeDepth] = {};    // chunk's inputs have landed (copy stream)
+        hipEvent_t ev_done[kPipeDepth] = {};   // chunk's records are in h_rec (main stream)
+        void* d_in[kPipeDepth] = {};
+        size_t in_bytes[kPipeDepth] = {};
+        long long* d_idx[kPipeDepth] = {};
+        thr_record* d_rec[kPipeDepth] = {};
+        thr_record* h_rec[kPipeDepth] = {};    // pinned: D2H never blocks the host
+        unsigned char* d_text[kPipeDepth] = {};
+        size_t text_bytes[kPipeDepth] = {};
+        long long* d_off[kPipeDepth] = {};
+        int* d_bad[kPipeDepth] = {};
+        int* h_bad = nullptr;                  // pinned int[kPipeDepth]
+        std::vector<long long> idx_host[kPipeDepth], off_host[kPipeDepth];
         // records of the chunk in buffer b still to be handed to the caller
-        thr_record* pend_dst[2] = {nullptr, nullptr};
-        size_t pend_n[2] = {0, 0};
-        size_t pend_first[2] = {0, 0};                // (first block of the chunk: error messages)
-        bool pend_card[2] = {false, false};
+        thr_record* pend_dst[kPipeDepth] = {};
+        size_t pend_n[kPipeDepth] = {};
+        size_t pend_first[kPipeDepth] = {};    // (first block of the chunk: error messages)
+        bool pend_card[kPipeDepth] = {};
+        // thr_submit*() / thr_collect(): the ticket a buffer's pending chunk belongs to (0: none /
+        // a chunk of the synchronous entry points), tickets handed out so far, tickets not yet
+        // collected
+        uint64_t slot_ticket[kPipeDepth] = {};
+        uint64_t next_ticket = 1;
+        int async_open = 0;
     } hp;
     // single-chunk staging of the test hooks (lazy)
     void* d_in = nullptr;
@@ -348,8 +355,9 @@ int ensure_pipe(thr_handle* h) {
     if (p.ready) return THR_OK;
     const size_t mb = size_t(h->cfg.max_batch), nt = size_t(h->cfg.n_templates);
     HIP_TRY(hipStreamCreateWithFlags(&p.copy, hipStreamNonBlocking));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p.h_bad), 2 * sizeof(int), hipHostMallocDefault));
-    for (int b = 0; b < 2; ++b) {
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p.h_bad), thr_handle::kPipeDepth * sizeof(int),
+                          hipHostMallocDefault));
+    for (int b = 0; b < thr_handle::kPipeDepth; ++b) {
         HIP_TRY(hipEventCreateWithFlags(&p.ev_h2d[b], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&p.ev_done[b], hipEventDisableTiming));
         HIP_TRY(hipMalloc(&p.d_idx[b], mb * sizeof(long long)));
@@ -424,15 +432,15 @@ int pipe_records_enqueued(thr_handle* h, int b, thr_record* dst, size_t n_rec, s
     return THR_OK;
 }
 
-int pipe_finish(thr_handle* h, int rc) {   // drain both buffers; keeps the first error
-    for (int b = 0; b < 2; ++b) {
+int pipe_finish(thr_handle* h, int rc) {   // drain every buffer; keeps the first error
+    for (int b = 0; b < thr_handle::kPipeDepth; ++b) {
         const int r = pipe_drain(h, b);
         if (rc == THR_OK) rc = r;
     }
     if (rc != THR_OK) {
         (void)hipStreamSynchronize(h->hp.copy);
         (void)hipStreamSynchronize(h->stream);
-        h->hp.pend_n[0] = h->hp.pend_n[1] = 0;
+        for (int b = 0; b < thr_handle::kPipeDepth; ++b) h->hp.pend_n[b] = 0;
     }
     return rc;
 }
@@ -902,7 +910,7 @@ void thr_destroy(thr_handle* h) {
             (void)hipStreamDestroy(p.copy);
         }
         if (p.h_bad) (void)hipHostFree(p.h_bad);
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < thr_handle::kPipeDepth; ++b) {
             if (p.ev_h2d[b]) (void)hipEventDestroy(p.ev_h2d[b]);
             if (p.ev_done[b]) (void)hipEventDestroy(p.ev_done[b]);
             if (p.h_rec[b]) (void)hipHostFree(p.h_rec[b]);
@@ -929,6 +937,12 @@ void thr_destroy(thr_handle* h) {
 int thr_set_stream(thr_handle* h, void* hip_stream) {
     if (!h) return fail(THR_ERR_ARG, "null handle");
     h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+    return THR_OK;
+}
+
+int thr_set_stream_default(thr_handle* h) {
+    if (!h) return fail(THR_ERR_ARG, "null handle");
+    h->stream = nullptr;   // the legacy default stream (handle value 0): ordered with every blocking stream
     return THR_OK;
 }
 
@@ -979,6 +993,85 @@ int thr_detect_stream_device(thr_handle* h, const uint8_t* d_stream, const int64
                      int(n_blocks), d_out, nullptr, nullptr, nullptr, 0, false, stride);
 }
 
+// ---- one chunk of each host entry point: stage the inputs into pipe buffer b (copy stream), run
+// the batch (main stream), start the records' way back.  Shared by the synchronous loops and by
+// thr_submit*().  Every HIP failure comes back as a status: the callers all leave through
+// pipe_finish() / pipe_abort(), which synchronise both streams and clear what is pending (a
+// chunk must never stay pending with `pend_dst` pointing into a caller array that is gone).
+static int chunk_samples(thr_handle* h, int b, const void* src, int format, size_t blk_bytes, size_t stride,
+                         const int64_t* block_idx, int64_t first_idx, size_t nb, thr_record* dst,
+                         size_t first) {
+    auto& p = h->hp;
+    // dense blocks: nb * blk_bytes; raw stream: (nb - 1) strides + one whole block
+    const size_t bytes = stride ? (nb - 1) * stride + blk_bytes : nb * blk_bytes;
+    int rc;
+    if ((rc = pipe_grow(&p.d_in[b], &p.in_bytes[b], bytes)) != THR_OK) return rc;
+    if ((rc = pipe_h2d(h, p.d_in[b], src, bytes)) != THR_OK) return rc;
+    p.idx_host[b].resize(nb);
+    for (size_t i = 0; i < nb; ++i)
+        p.idx_host[b][i] = block_idx ? (long long)block_idx[i] : (long long)(first_idx + int64_t(i));
+    HIP_TRY(hipMemcpyAsync(p.d_idx[b], p.idx_host[b].data(), nb * sizeof(long long),
+                           hipMemcpyHostToDevice, p.copy));
+    if ((rc = pipe_inputs_enqueued(h, b)) != THR_OK) return rc;
+    rc = run_batch(h, p.d_in[b], format, p.d_idx[b], int(nb), p.d_rec[b], nullptr, nullptr, nullptr, 0,
+                   false, stride);
+    if (rc != THR_OK) return rc;
+    return pipe_records_enqueued(h, b, dst, nb * size_t(h->cfg.n_templates), first, false);
+}
+
+static int chunk_card(thr_handle* h, int b, const char* text, size_t text_len, const int64_t* payload_off,
+                      const int64_t* block_idx, size_t first, size_t nb, thr_record* dst) {
+    auto& p = h->hp;
+    const size_t out_bytes = size_t(h->cfg.block_len) * 2;
+    const size_t chars = ((out_bytes + 2) / 3) * 4;  // base64 payload length of one block
+    // contiguous span of text covering the chunk's payloads: [lo, hi + chars)
+    long long lo = payload_off[first], hi = payload_off[first];
+    for (size_t i = 0; i < nb; ++i) {
+        const long long o = payload_off[first + i];
+        if (o < 0 || size_t(o) + chars > text_len)
+            return fail(THR_ERR_ARG, "payload %zu (offset %lld, %zu chars) lies outside the text",
+                        first + i, o, chars);
+        lo = std::min(lo, o);
+        hi = std::max(hi, o);
+    }
+    const size_t span = size_t(hi - lo) + chars;
+    int rc;
+    if ((rc = pipe_grow(reinterpret_cast<void**>(&p.d_text[b]), &p.text_bytes[b], span)) != THR_OK) return rc;
+    if ((rc = pipe_grow(&p.d_in[b], &p.in_bytes[b], nb * out_bytes)) != THR_OK) return rc;
+    if (!p.d_off[b]) HIP_TRY(hipMalloc(&p.d_off[b], size_t(h->cfg.max_batch) * sizeof(long long)));
+    if (!p.d_bad[b]) HIP_TRY(hipMalloc(&p.d_bad[b], sizeof(int)));
+    p.off_host[b].resize(nb);
+    p.idx_host[b].resize(nb);
+    for (size_t i = 0; i < nb; ++i) {
+        p.off_host[b][i] = payload_off[first + i] - lo;
+        p.idx_host[b][i] = block_idx ? (long long)block_idx[first + i] : (long long)(first + i);
+    }
+    if ((rc = pipe_h2d(h, p.d_text[b], text + lo, span)) != THR_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(p.d_off[b], p.off_host[b].data(), nb * sizeof(long long),
+                           hipMemcpyHostToDevice, p.copy));
+    HIP_TRY(hipMemcpyAsync(p.d_idx[b], p.idx_host[b].data(), nb * sizeof(long long),
+                           hipMemcpyHostToDevice, p.copy));
+    HIP_TRY(hipMemsetAsync(p.d_bad[b], 0, sizeof(int), p.copy));
+    if ((rc = pipe_inputs_enqueued(h, b)) != THR_OK) return rc;
+    HIP_TRY(thr::launch_b64_decode(p.d_text[b], p.d_off[b], int(nb), int(out_bytes),
+                                   static_cast<unsigned char*>(p.d_in[b]), p.d_bad[b], h->stream));
+    rc = run_batch(h, p.d_in[b], THR_IN_U8, p.d_idx[b], int(nb), p.d_rec[b], nullptr, nullptr, nullptr,
+                   0, false);
+    if (rc != THR_OK) return rc;
+    return pipe_records_enqueued(h, b, dst, nb * size_t(h->cfg.n_templates), first, true);
+}
+
+// entry checks shared by the synchronous host entry points: device, staging, no open tickets
+static int pipe_enter_sync(thr_handle* h, const char* who) {
+    HIP_TRY(hipSetDevice(h->device));
+    const int rc = ensure_pipe(h);
+    if (rc != THR_OK) return rc;
+    if (h->hp.async_open != 0)
+        return fail(THR_ERR_STATE, "%s: %d submitted batch(es) not collected yet (thr_collect first)",
+                    who, h->hp.async_open);
+    return THR_OK;
+}
+
 int thr_detect_stream(thr_handle* h, const uint8_t* stream, size_t n_bytes, int64_t first_block_idx,
                       thr_record* out, size_t out_capacity, size_t* n_blocks_out) {
     if (!h || !stream || !out || !n_blocks_out)
@@ -993,28 +1086,16 @@ int thr_detect_stream(thr_handle* h, const uint8_t* stream, size_t n_bytes, int6
     if (n_blocks > out_capacity)
         return fail(THR_ERR_ARG, "stream holds %zu blocks, records array only %zu", n_blocks,
                     out_capacity);
-    HIP_TRY(hipSetDevice(h->device));
-    rc = ensure_pipe(h);
-    if (rc != THR_OK) return rc;
-    auto& p = h->hp;
+    if ((rc = pipe_enter_sync(h, "thr_detect_stream")) != THR_OK) return rc;
     const size_t nt = size_t(h->cfg.n_templates);
     int chunk = 0;
-    for (size_t done = 0; done < n_blocks && rc == THR_OK; ++chunk) {
-        const int b = chunk & 1;
+    for (size_t done = 0; done < n_blocks; ++chunk) {
+        const int b = chunk % thr_handle::kPipeDepth;
         const size_t nb = std::min(n_blocks - done, pipe_chunk_blocks(h, stride));
-        const size_t bytes = (nb - 1) * stride + blk;
         if ((rc = pipe_drain(h, b)) != THR_OK) break;        // buffer b's previous chunk is handed out
-        if ((rc = pipe_grow(&p.d_in[b], &p.in_bytes[b], bytes)) != THR_OK) break;
-        if ((rc = pipe_h2d(h, p.d_in[b], stream + done * stride, bytes)) != THR_OK) break;
-        p.idx_host[b].resize(nb);
-        for (size_t i = 0; i < nb; ++i) p.idx_host[b][i] = (long long)(first_block_idx + int64_t(done + i));
-        HIP_TRY(hipMemcpyAsync(p.d_idx[b], p.idx_host[b].data(), nb * sizeof(long long),
-                               hipMemcpyHostToDevice, p.copy));
-        if ((rc = pipe_inputs_enqueued(h, b)) != THR_OK) break;
-        rc = run_batch(h, p.d_in[b], THR_IN_U8, p.d_idx[b], int(nb), p.d_rec[b], nullptr, nullptr,
-                       nullptr, 0, false, stride);
+        rc = chunk_samples(h, b, stream + done * stride, THR_IN_U8, blk, stride, nullptr,
+                           first_block_idx + int64_t(done), nb, out + done * nt, done);
         if (rc != THR_OK) break;
-        rc = pipe_records_enqueued(h, b, out + done * nt, nb * nt, done, false);
         done += nb;
     }
     rc = pipe_finish(h, rc);
@@ -1027,33 +1108,21 @@ int thr_detect(thr_handle* h, const void* samples, int format, const int64_t* bl
                size_t n_blocks, thr_record* out) {
     if (!h || !samples || !out) return fail(THR_ERR_ARG, "thr_detect: null argument");
     if (format != THR_IN_U8 && format != THR_IN_C64) return fail(THR_ERR_ARG, "bad format %d", format);
-    HIP_TRY(hipSetDevice(h->device));
-    int rc = ensure_pipe(h);
+    int rc = pipe_enter_sync(h, "thr_detect");
     if (rc != THR_OK) return rc;
-    auto& p = h->hp;
     const size_t blk_bytes = size_t(h->cfg.block_len) * (format == THR_IN_U8 ? 2 : 8);
     const size_t nt = size_t(h->cfg.n_templates);
     // chunk i + 1 is copied (copy stream; the call blocks while the pageable source is staged)
     // while the kernels of chunk i run; records return through pinned staging
     int chunk = 0;
-    for (size_t done = 0; done < n_blocks && rc == THR_OK; ++chunk) {
-        const int b = chunk & 1;
+    for (size_t done = 0; done < n_blocks; ++chunk) {
+        const int b = chunk % thr_handle::kPipeDepth;
         const size_t nb = std::min(n_blocks - done, pipe_chunk_blocks(h, blk_bytes));
         if ((rc = pipe_drain(h, b)) != THR_OK) break;
-        if ((rc = pipe_grow(&p.d_in[b], &p.in_bytes[b], nb * blk_bytes)) != THR_OK) break;
-        if ((rc = pipe_h2d(h, p.d_in[b], static_cast<const unsigned char*>(samples) + done * blk_bytes,
-                           nb * blk_bytes)) != THR_OK)
-            break;
-        p.idx_host[b].resize(nb);
-        for (size_t i = 0; i < nb; ++i)
-            p.idx_host[b][i] = block_idx ? (long long)block_idx[done + i] : (long long)(done + i);
-        HIP_TRY(hipMemcpyAsync(p.d_idx[b], p.idx_host[b].data(), nb * sizeof(long long),
-                               hipMemcpyHostToDevice, p.copy));
-        if ((rc = pipe_inputs_enqueued(h, b)) != THR_OK) break;
-        rc = run_batch(h, p.d_in[b], format, p.d_idx[b], int(nb), p.d_rec[b], nullptr, nullptr, nullptr,
-                       0, false);
+        rc = chunk_samples(h, b, static_cast<const unsigned char*>(samples) + done * blk_bytes, format,
+                           blk_bytes, 0, block_idx ? block_idx + done : nullptr, int64_t(done), nb,
+                           out + done * nt, done);
         if (rc != THR_OK) break;
-        rc = pipe_records_enqueued(h, b, out + done * nt, nb * nt, done, false);
         done += nb;
     }
     return pipe_finish(h, rc);
@@ -1131,65 +1200,321 @@ int thr_frame_card(const char* text, size_t text_len, int block_len, int at_eof,
     return THR_OK;
 }
 
+
 int thr_detect_card(thr_handle* h, const char* text, size_t text_len, const int64_t* payload_off,
                     const int64_t* block_idx, size_t n_blocks, thr_record* out) {
     if (!h || !text || !payload_off || !out) return fail(THR_ERR_ARG, "thr_detect_card: null argument");
-    HIP_TRY(hipSetDevice(h->device));
-    int rc = ensure_pipe(h);
+    int rc = pipe_enter_sync(h, "thr_detect_card");
     if (rc != THR_OK) return rc;
-    auto& p = h->hp;
-    const size_t out_bytes = size_t(h->cfg.block_len) * 2;
-    const size_t chars = ((out_bytes + 2) / 3) * 4;  // base64 payload length of one block
+    const size_t chars = ((size_t(h->cfg.block_len) * 2 + 2) / 3) * 4;
     const size_t nt = size_t(h->cfg.n_templates);
     int chunk = 0;
-    for (size_t done = 0; done < n_blocks && rc == THR_OK; ++chunk) {
-        const int b = chunk & 1;
+    for (size_t done = 0; done < n_blocks; ++chunk) {
+        const int b = chunk % thr_handle::kPipeDepth;
         const size_t nb = std::min(n_blocks - done, pipe_chunk_blocks(h, chars + 32));
-        // contiguous span of text covering a chunk's payloads: [lo, hi + chars)
-        auto span_of = [&](size_t first, size_t count, long long* plo, long long* phi) {
-            long long lo_ = payload_off[first], hi_ = payload_off[first];
-            for (size_t i = 0; i < count; ++i) {
-                const long long o = payload_off[first + i];
-                if (o < 0 || size_t(o) + chars > text_len)
-                    return fail(THR_ERR_ARG, "payload %zu (offset %lld, %zu chars) lies outside the text",
-                                first + i, o, chars);
-                lo_ = std::min(lo_, o);
-                hi_ = std::max(hi_, o);
-            }
-            *plo = lo_;
-            *phi = hi_;
-            return THR_OK;
-        };
-        long long lo = 0, hi = 0;
-        if ((rc = span_of(done, nb, &lo, &hi)) != THR_OK) break;
-        const size_t span = size_t(hi - lo) + chars;
         if ((rc = pipe_drain(h, b)) != THR_OK) break;
-        if ((rc = pipe_grow(reinterpret_cast<void**>(&p.d_text[b]), &p.text_bytes[b], span)) != THR_OK) break;
-        if ((rc = pipe_grow(&p.d_in[b], &p.in_bytes[b], nb * out_bytes)) != THR_OK) break;
-        if (!p.d_off[b]) HIP_TRY(hipMalloc(&p.d_off[b], size_t(h->cfg.max_batch) * sizeof(long long)));
-        if (!p.d_bad[b]) HIP_TRY(hipMalloc(&p.d_bad[b], sizeof(int)));
-        p.off_host[b].resize(nb);
-        p.idx_host[b].resize(nb);
-        for (size_t i = 0; i < nb; ++i) {
-            p.off_host[b][i] = payload_off[done + i] - lo;
-            p.idx_host[b][i] = block_idx ? (long long)block_idx[done + i] : (long long)(done + i);
-        }
-        if ((rc = pipe_h2d(h, p.d_text[b], text + lo, span)) != THR_OK) break;
-        HIP_TRY(hipMemcpyAsync(p.d_off[b], p.off_host[b].data(), nb * sizeof(long long),
-                               hipMemcpyHostToDevice, p.copy));
-        HIP_TRY(hipMemcpyAsync(p.d_idx[b], p.idx_host[b].data(), nb * sizeof(long long),
-                               hipMemcpyHostToDevice, p.copy));
-        HIP_TRY(hipMemsetAsync(p.d_bad[b], 0, sizeof(int), p.copy));
-        if ((rc = pipe_inputs_enqueued(h, b)) != THR_OK) break;
-        HIP_TRY(thr::launch_b64_decode(p.d_text[b], p.d_off[b], int(nb), int(out_bytes),
-                                       static_cast<unsigned char*>(p.d_in[b]), p.d_bad[b], h->stream));
-        rc = run_batch(h, p.d_in[b], THR_IN_U8, p.d_idx[b], int(nb), p.d_rec[b], nullptr, nullptr,
-                       nullptr, 0, false);
+        rc = chunk_card(h, b, text, text_len, payload_off, block_idx, done, nb, out + done * nt);
         if (rc != THR_OK) break;
-        rc = pipe_records_enqueued(h, b, out + done * nt, nb * nt, done, true);
         done += nb;
     }
     return pipe_finish(h, rc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Asynchronous host boundary: thr_submit*() stages one batch and returns a ticket while the GPU
+// works; thr_collect() hands that batch's records out.  kPipeDepth batches may be open.
+// ---------------------------------------------------------------------------------------------
+static int submit_enter(thr_handle* h, const char* who, size_t n_blocks, uint64_t* ticket, int* slot) {
+    if (!ticket) return fail(THR_ERR_ARG, "%s: null ticket pointer", who);
+    *ticket = 0;
+    if (n_blocks > size_t(h->cfg.max_batch))
+        return fail(THR_ERR_ARG, "%s: n_blocks %zu exceeds max_batch %d (one submit = one batch)", who,
+                    n_blocks, h->cfg.max_batch);
+    HIP_TRY(hipSetDevice(h->device));
+    const int rc = ensure_pipe(h);
+    if (rc != THR_OK) return rc;
+    auto& p = h->hp;
+    for (int k = 0; k < thr_handle::kPipeDepth; ++k) {
+        const int b = int((p.next_ticket + uint64_t(k)) % thr_handle::kPipeDepth);
+        if (p.pend_n[b] == 0 && p.slot_ticket[b] == 0) {
+            *slot = b;
+            return THR_OK;
+        }
+    }
+    return fail(THR_ERR_STATE, "%s: %d batches are already in flight; thr_collect() one first", who,
+                thr_handle::kPipeDepth);
+}
+
+// a failed submit must not leave a half-enqueued chunk behind: wait for the streams, clear the slot
+static int submit_leave(thr_handle* h, int b, int rc, uint64_t* ticket) {
+    auto& p = h->hp;
+    if (rc != THR_OK) {
+        (void)hipStreamSynchronize(p.copy);
+        (void)hipStreamSynchronize(h->stream);
+        p.pend_n[b] = 0;
+        p.slot_ticket[b] = 0;
+        return rc;
+    }
+    p.slot_ticket[b] = p.next_ticket++;
+    p.async_open += 1;
+    *ticket = p.slot_ticket[b];
+    return THR_OK;
+}
+
+int thr_submit(thr_handle* h, const void* samples, int format, const int64_t* block_idx,
+               size_t n_blocks, thr_record* out, uint64_t* ticket) {
+    if (!h || !samples || !out) return fail(THR_ERR_ARG, "thr_submit: null argument");
+    if (format != THR_IN_U8 && format != THR_IN_C64) return fail(THR_ERR_ARG, "bad format %d", format);
+    int b = 0;
+    int rc = submit_enter(h, "thr_submit", n_blocks, ticket, &b);
+    if (rc != THR_OK || n_blocks == 0) return rc;   // (an empty batch: ticket 0, nothing to collect)
+    const size_t blk_bytes = size_t(h->cfg.block_len) * (format == THR_IN_U8 ? 2 : 8);
+    rc = chunk_samples(h, b, samples, format, blk_bytes, 0, block_idx, 0, n_blocks, out, 0);
+    return submit_leave(h, b, rc, ticket);
+}
+
+int thr_submit_card(thr_handle* h, const char* text, size_t text_len, const int64_t* payload_off,
+                    const int64_t* block_idx, size_t n_blocks, thr_record* out, uint64_t* ticket) {
+    if (!h || !text || !payload_off || !out) return fail(THR_ERR_ARG, "thr_submit_card: null argument");
+    int b = 0;
+    int rc = submit_enter(h, "thr_submit_card", n_blocks, ticket, &b);
+    if (rc != THR_OK || n_blocks == 0) return rc;
+    rc = chunk_card(h, b, text, text_len, payload_off, block_idx, 0, n_blocks, out);
+    return submit_leave(h, b, rc, ticket);
+}
+
+int thr_submit_stream(thr_handle* h, const uint8_t* stream, size_t n_bytes, int64_t first_block_idx,
+                      thr_record* out, size_t out_capacity, size_t* n_blocks_out, uint64_t* ticket) {
+    if (!h || !stream || !out || !n_blocks_out)
+        return fail(THR_ERR_ARG, "thr_submit_stream: null argument");
+    *n_blocks_out = 0;
+    size_t stride = 0;
+    int rc = stream_stride(h, &stride);
+    if (rc != THR_OK) return rc;
+    const size_t blk = size_t(h->cfg.block_len) * 2;
+    const size_t n_blocks = n_bytes < blk ? 0 : (n_bytes - blk) / stride + 1;
+    if (n_blocks > out_capacity)
+        return fail(THR_ERR_ARG, "stream holds %zu blocks, records array only %zu", n_blocks,
+                    out_capacity);
+    int b = 0;
+    rc = submit_enter(h, "thr_submit_stream", n_blocks, ticket, &b);
+    if (rc != THR_OK || n_blocks == 0) return rc;
+    rc = chunk_samples(h, b, stream, THR_IN_U8, blk, stride, nullptr, first_block_idx, n_blocks, out, 0);
+    rc = submit_leave(h, b, rc, ticket);
+    if (rc == THR_OK) *n_blocks_out = n_blocks;
+    return rc;
+}
+
+int thr_collect(thr_handle* h, uint64_t ticket) {
+    if (!h) return fail(THR_ERR_ARG, "thr_collect: null handle");
+    if (ticket == 0) return THR_OK;   // the ticket of an empty batch
+    auto& p = h->hp;
+    for (int b = 0; b < thr_handle::kPipeDepth; ++b) {
+        if (p.slot_ticket[b] != ticket) continue;
+        HIP_TRY(hipSetDevice(h->device));
+        int rc = pipe_drain(h, b);
+        if (rc != THR_OK && p.pend_n[b] != 0) {   // the wait itself failed: nothing may stay pending
+            (void)hipStreamSynchronize(h->stream);
+            p.pend_n[b] = 0;
+        }
+        p.slot_ticket[b] = 0;
+        p.async_open -= 1;
+        return rc;
+    }
+    return fail(THR_ERR_STATE, "thr_collect: ticket %llu is not open (never issued, or collected already)",
+                (unsigned long long)ticket);
+}
+
+int thr_inputs_consumed(thr_handle* h, uint64_t ticket) {
+    if (!h) return fail(THR_ERR_ARG, "thr_inputs_consumed: null handle");
+    if (ticket == 0) return THR_OK;
+    auto& p = h->hp;
+    for (int b = 0; b < thr_handle::kPipeDepth; ++b) {
+        if (p.slot_ticket[b] != ticket) continue;
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipEventSynchronize(p.ev_h2d[b]));   // recorded behind the chunk's last H2D copy
+        return THR_OK;
+    }
+    return fail(THR_ERR_STATE, "thr_inputs_consumed: ticket %llu is not open", (unsigned long long)ticket);
+}
+
+int thr_poll(thr_handle* h, uint64_t ticket, int* done) {
+    if (!h || !done) return fail(THR_ERR_ARG, "thr_poll: null argument");
+    *done = 1;
+    if (ticket == 0) return THR_OK;
+    auto& p = h->hp;
+    for (int b = 0; b < thr_handle::kPipeDepth; ++b) {
+        if (p.slot_ticket[b] != ticket) continue;
+        const hipError_t e = hipEventQuery(p.ev_done[b]);
+        if (e == hipErrorNotReady) {
+            *done = 0;
+            return THR_OK;
+        }
+        if (e != hipSuccess) return fail(THR_ERR_DEVICE, "hipEventQuery failed: %s", hipGetErrorString(e));
+        return THR_OK;
+    }
+    return fail(THR_ERR_STATE, "thr_poll: ticket %llu is not open", (unsigned long long)ticket);
+}
+
+// ---------------------------------------------------------------------------------------------
+// .toad text (DetectionResult.serialize, toads_data.py:47-61) for a batch of detected records.
+// ---------------------------------------------------------------------------------------------
+extern "C++" {
+namespace {
+// Python's repr(float): the shortest digit string that round-trips (float_repr_style 'short'),
+// fixed notation while -4 <= exponent10 < 16, else d.ddde+XX with at least two exponent digits
+// (PyOS_double_to_string(x, 'r', 0, Py_DTSF_ADD_DOT_0)).
+char* py_repr_double(char* out, double v) {
+    if (std::isnan(v)) return static_cast<char*>(memcpy(out, "nan", 3)) + 3;
+    if (std::isinf(v)) {
+        const char* s = v < 0 ? "-inf" : "inf";
+        const size_t n = strlen(s);
+        return static_cast<char*>(memcpy(out, s, n)) + n;
+    }
+    char sci[40];
+    const auto r = std::to_chars(sci, sci + sizeof sci - 1, v, std::chars_format::scientific);
+    *r.ptr = 0;
+    // sci = [-]d[.ddd]e[+-]XX
+    char* s = sci;
+    if (*s == '-') *out++ = *s++;
+    char digits[24];
+    int nd = 0;
+    char* e = s;
+    for (; e < r.ptr && *e != 'e'; ++e)
+        if (*e != '.') digits[nd++] = *e;
+    const int exp10 = atoi(e + 1);           // value = d.ddd x 10^exp10
+    const int decpt = exp10 + 1;              // value = 0.dddd x 10^decpt
+    if (decpt <= -4 || decpt > 16) {
+        *out++ = digits[0];
+        if (nd > 1) {
+            *out++ = '.';
+            memcpy(out, digits + 1, size_t(nd - 1));
+            out += nd - 1;
+        }
+        *out++ = 'e';
+        *out++ = exp10 < 0 ? '-' : '+';
+        const int a = exp10 < 0 ? -exp10 : exp10;
+        if (a >= 100) *out++ = char('0' + a / 100);
+        *out++ = char('0' + (a / 10) % 10);
+        *out++ = char('0' + a % 10);
+        return out;
+    }
+    if (decpt <= 0) {
+        *out++ = '0';
+        *out++ = '.';
+        for (int i = 0; i < -decpt; ++i) *out++ = '0';
+        memcpy(out, digits, size_t(nd));
+        return out + nd;
+    }
+    if (decpt >= nd) {
+        memcpy(out, digits, size_t(nd));
+        out += nd;
+        for (int i = nd; i < decpt; ++i) *out++ = '0';
+        *out++ = '.';
+        *out++ = '0';
+        return out;
+    }
+    memcpy(out, digits, size_t(decpt));
+    out += decpt;
+    *out++ = '.';
+    memcpy(out, digits + decpt, size_t(nd - decpt));
+    return out + (nd - decpt);
+}
+char* put_int(char* out, long long v) {
+    const auto r = std::to_chars(out, out + 24, v);
+    return r.ptr;
+}
+// "%.<DEC>f" of a finite double, correctly rounded (ties to even on the exact binary value, as
+// glibc's printf and Python's '%.6f' do): v = m 2^-k exactly, so v 10^DEC = m 10^DEC / 2^k in
+// 128-bit integer arithmetic.  Magnitudes the integers cannot hold take snprintf.
+template <int DEC>
+char* put_fixed(char* out, double v) {
+    static_assert(DEC >= 1 && DEC <= 9, "10^DEC must fit 32 bits");
+    int e = 0;
+    const double fr = std::frexp(std::fabs(v), &e);            // |v| = fr 2^e, fr in [0.5, 1)
+    const unsigned long long m = (unsigned long long)std::ldexp(fr, 53);   // 53-bit integer mantissa
+    const int k = 53 - e;                                      // |v| = m 2^-k
+    if (!std::isfinite(v) || k < 0 || k > 120 || e > 62) {
+        if (std::isfinite(v) && k > 120) {                     // |v| < 2^-67: prints as zero
+            if (std::signbit(v)) *out++ = '-';
+            *out++ = '0';
+            *out++ = '.';
+            for (int i = 0; i < DEC; ++i) *out++ = '0';
+            return out;
+        }
+        return out + snprintf(out, 64, "%.*f", DEC, v);
+    }
+    unsigned long long p10 = 1;
+    for (int i = 0; i < DEC; ++i) p10 *= 10;
+    const unsigned __int128 num = (unsigned __int128)m * p10;  // < 2^53 * 2^30
+    unsigned __int128 q = k >= 128 ? 0 : num >> k;
+    const unsigned __int128 rem = num - (q << k), half = (unsigned __int128)1 << (k - 1);
+    if (k > 0 && (rem > half || (rem == half && (q & 1)))) ++q;
+    const unsigned long long ip = (unsigned long long)(q / p10), fp = (unsigned long long)(q % p10);
+    if (std::signbit(v)) *out++ = '-';
+    out = std::to_chars(out, out + 24, ip).ptr;
+    *out++ = '.';
+    char d[DEC];
+    unsigned long long f = fp;
+    for (int i = DEC - 1; i >= 0; --i) {
+        d[i] = char('0' + f % 10);
+        f /= 10;
+    }
+    memcpy(out, d, DEC);
+    return out + DEC;
+}
+}  // namespace
+}  // extern "C++"
+
+int thr_format_toad(const thr_record* recs, const double* timestamps, size_t n, int64_t new_len,
+                    int with_rxid, int64_t rxid, int with_txid, int carrier_offset_f32, char* out,
+                    size_t out_capacity, size_t* out_len) {
+    if ((!recs || !timestamps) && n) return fail(THR_ERR_ARG, "thr_format_toad: null argument");
+    if (!out || !out_len) return fail(THR_ERR_ARG, "thr_format_toad: null output");
+    *out_len = 0;
+    if (out_capacity < n * size_t(THR_TOAD_LINE_MAX))
+        return fail(THR_ERR_ARG, "thr_format_toad: %zu bytes for %zu lines, need %zu", out_capacity, n,
+                    n * size_t(THR_TOAD_LINE_MAX));
+    char* p = out;
+    for (size_t i = 0; i < n; ++i) {
+        const thr_record& r = recs[i];
+        if (with_rxid) {
+            p = put_int(p, rxid);
+            *p++ = ' ';
+        }
+        if (with_txid) {
+            p = put_int(p, r.template_id);
+            *p++ = ' ';
+        }
+        if (!(std::fabs(timestamps[i]) < 1e15))
+            return fail(THR_ERR_ARG, "thr_format_toad: timestamp %g of record %zu out of range", timestamps[i], i);
+        p = put_fixed<6>(p, timestamps[i]);
+        *p++ = ' ';
+        p = put_int(p, r.block_idx);
+        *p++ = ' ';
+        // soa = new_len * block_idx + sample + offset: the integer part exactly, one float64 add (detect.py:69)
+        const double soa = double(new_len * r.block_idx + int64_t(r.corr_sample)) + r.corr_offset;
+        p = put_fixed<8>(p, soa);
+        *p++ = ' ';
+        p = put_int(p, r.corr_sample);
+        *p++ = ' ';
+        p = py_repr_double(p, r.corr_offset);
+        *p++ = ' ';
+        p = py_repr_double(p, double(r.corr_energy));
+        *p++ = ' ';
+        p = py_repr_double(p, double(r.corr_noise));
+        *p++ = ' ';
+        p = put_int(p, r.carrier_bin);
+        *p++ = ' ';
+        p = py_repr_double(p, carrier_offset_f32 ? double(float(r.carrier_offset)) : r.carrier_offset);
+        *p++ = ' ';
+        p = py_repr_double(p, double(r.carrier_energy));
+        *p++ = ' ';
+        p = py_repr_double(p, double(r.carrier_noise));
+        *p++ = '\n';
+    }
+    *out_len = size_t(p - out);
+    return THR_OK;
 }
 
 int thr_compact_device(thr_handle* h, const thr_record* d_in, size_t n_records, thr_record* d_out,

@@ -28,8 +28,8 @@ DetectorSettings = namedtuple("DetectorSettings", [
     "template", "corr_thresh"])
 
 
-_SLOW_SOURCE_S = 0.002   # inter-arrival time above which Detector stops filling a batch
-_CHUNKS_PER_CALL = 8      # engine batches a batch reader hands to one thr_detect_card / _stream call
+_SLOW_SOURCE_S = 0.002   # inter-arrival time above which a LIVE source ends the batch being filled
+_YIELD_DATA_BATCH = 64    # blocks per batch with yield_data (each drags two N-point dumps along)
 
 
 def unique_window(block_len, history_len, template_len):
@@ -59,11 +59,22 @@ class Detector(object):
 
     _fit_reach = 3            # the carrier interpolator reads fft_mag[peak + 3] (carrier_sync.py:187)
     _offset_type = float      # CarrierSyncInfo.offset as the reference types it
+    _multi = False            # MultiTemplateDetector: settings.template is [n_templates, len]
 
     def __init__(self, settings, blocks=None, rxid=-1, yield_data=False, batch_size=None,
-                 device_id=0, _preshift_num=0, _fastdet=False):
+                 device_id=0, _preshift_num=0, _fastdet=False, max_wait=None):
+        """`max_wait` (seconds): a classic `(timestamp, idx, block)` iterator whose next() takes
+        longer than this ends the batch being filled (what has arrived is processed instead of
+        waiting for a full batch).  Default: 2 ms if the source says it is live (`.live` true: a
+        reader over a pipe / tty), else no limit -- a CPU-bound iterator (host decode, gzip, a GC
+        pause) is slow without being live, and one-block batches would only make it slower."""
         if batch_size is None:      # ~64 MiB of u8 samples per engine batch (the staging chunk size)
             batch_size = max(64, min(65536, (64 << 20) // (2 * int(settings.block_len))))
+            if yield_data:          # every block of a batch holds two N-point stage dumps in _ready
+                batch_size = min(batch_size, _YIELD_DATA_BATCH)
+        if max_wait is None:
+            max_wait = _SLOW_SOURCE_S if getattr(blocks, "live", False) else float("inf")
+        self.max_wait = float(max_wait)
         self.settings = settings
         # a CardStream is consumed in whole batches with the base64 payloads decoded on the GPU
         self._card = blocks if isinstance(blocks, CardStream) and not yield_data else None
@@ -76,8 +87,9 @@ class Detector(object):
         self.batch_size = max(1, int(batch_size))
         self.new_len = settings.block_len - settings.history_len
         template = np.asarray(settings.template)
-        if template.ndim != 1:
-            raise ValueError("Detector takes one 1-D template (see MultiTemplateDetector)")
+        if template.ndim != (2 if self._multi else 1):
+            raise ValueError("Detector takes one 1-D template, MultiTemplateDetector a "
+                             "[n_templates, template_len] array")
         self._engine = _native.Engine(
             settings.block_len, settings.history_len, template, settings.carrier_thresh,
             settings.carrier_window, settings.corr_thresh, carrier_len=settings.carrier_len,
@@ -85,17 +97,18 @@ class Detector(object):
             fastdet=_fastdet)
         self._ready = deque()
         self._exhausted = False
+        self._in_flight = None      # the submitted batch whose records have not been collected yet
         # batch readers only (CardStream / RawStream): hand out detections only, skipping the
         # per-block Python objects of everything else (set by detector_cli under --quiet)
         self.only_detections = False
-        corr_len = settings.block_len - len(template) + 1
+        corr_len = settings.block_len - template.shape[-1] + 1
         # descriptive twins of the reference's sub-objects (read-only facts)
         self.sync = SimpleNamespace(thresh_coeffs=settings.carrier_thresh,
                                     window=settings.carrier_window, weights=None)
         self.soa_estimate = SimpleNamespace(
             template=template, template_energy=float(np.sum(np.abs(template) ** 2)),
             corr_len=corr_len, thresh_coeffs=settings.corr_thresh,
-            window=unique_window(settings.block_len, settings.history_len, len(template)))
+            window=unique_window(settings.block_len, settings.history_len, template.shape[-1]))
 
     # ------------------------------------------------------------------ core
     def _stack(self, blocks):
@@ -194,30 +207,35 @@ class Detector(object):
         return detected, result, shifted_fft, corr
 
     # -------------------------------------------------------------- iterator
-    def _next_records(self):
-        """Pull one batch from the block source and run it: -> (stamps, idxs, recs) or None
-        when the source is exhausted."""
-        # a batch reader over a regular (mmap-ed) file hands over up to 8 engine batches per call:
-        # the C entry points then stage, copy and process them as a pipeline (chunk i + 1 is
-        # copied while chunk i is detected); pipes are read one engine batch at a time
+    def _flat(self, stamps, idxs, recs):
+        """Engine records [B, n_templates] -> one record per result slot (this class: template 0)."""
+        return stamps, idxs, recs[:, 0]
+
+    def _submit_next(self, prev=None):
+        """Pull one batch from the block source and hand it to the engine WITHOUT waiting for it
+        (thr_submit*): -> an opaque pending batch, or None when the source is exhausted.  `prev`:
+        the ticket still in flight -- a reader that refills ONE buffer (a pipe) must not touch it
+        before that batch's host-to-device copies are done (a mapped file is never overwritten)."""
+        reader = self._card if self._card is not None else self._raw
+        if prev is not None and reader is not None and not reader.mapped:
+            self._engine.inputs_consumed(prev)
         if self._card is not None:
-            batch = self._card.next_batch(self.batch_size * (_CHUNKS_PER_CALL if self._card.mapped else 1))
+            batch = self._card.next_batch(self.batch_size)
             if batch is None:
                 self._exhausted = True
                 return None
             stamps, idxs, text, offs = batch
-            return stamps, idxs, self._engine.detect_card(text, offs, idxs)[:, 0]
+            return stamps, idxs, self._engine.submit_card(text, offs, idxs)
         if self._raw is not None:
-            batch = self._raw.next_batch(self.batch_size * (_CHUNKS_PER_CALL if self._raw.mapped else 1))
+            batch = self._raw.next_batch(self.batch_size)
             if batch is None:
                 self._exhausted = True
                 return None
             kind, stamps, idxs, data = batch
             if kind == "u8":
-                recs = self._engine.detect_stream(data, int(idxs[0]))[:, 0]
-            else:   # lead-in blocks that still contain the all-zero initial history
-                recs = self._engine.detect(data, idxs)[:, 0]
-            return stamps, idxs, recs
+                return stamps, idxs, self._engine.submit_stream(data, int(idxs[0]))
+            # lead-in blocks that still contain the all-zero initial history
+            return stamps, idxs, self._engine.submit(data, idxs)
         items = []
         while len(items) < self.batch_size and not self._exhausted:
             t0 = time.perf_counter()
@@ -225,9 +243,9 @@ class Detector(object):
                 items.append(next(self.blocks))
             except StopIteration:
                 self._exhausted = True
-            # a source slower than ~500 blocks/s (a live receiver delivers ~200) gains nothing
+            # a live source slower than ~500 blocks/s (a receiver delivers ~200) gains nothing
             # from batching: process what has arrived instead of waiting for a full batch
-            if time.perf_counter() - t0 > _SLOW_SOURCE_S:
+            if time.perf_counter() - t0 > self.max_wait:
                 break
         if not items:
             return None
@@ -235,21 +253,58 @@ class Detector(object):
             return items
         arr = self._stack([it[2] for it in items])
         idx = np.array([int(it[1]) for it in items], dtype=np.int64)
-        return [it[0] for it in items], idx, self._engine.detect(arr, idx)[:, 0]
+        return [it[0] for it in items], idx, self._engine.submit(arr, idx)
+
+    def _next_records(self):
+        """-> (stamps, idxs, recs) of the next batch in input order, or None at the end.  The
+        batch after it is submitted BEFORE this one is waited for, so the device (and the H2D
+        staging of the next inputs) works while the caller formats what it was handed."""
+        cur = self._in_flight if self._in_flight is not None else self._submit_next()
+        self._in_flight = None
+        if cur is None:
+            return None
+        if self.yield_data:
+            return cur
+        if not self._exhausted and self._may_read_ahead():
+            try:
+                self._in_flight = self._submit_next(cur[2])
+            except Exception:
+                self._engine.collect(cur[2])     # never leave a ticket open behind an error
+                raise
+        stamps, idxs, ticket = cur
+        return self._flat(stamps, idxs, self._engine.collect(ticket))
+
+    def _may_read_ahead(self):
+        """Reading the NEXT batch before handing out this one must not delay it: fine on files and
+        on sources with data pending, not on a live source that would have to be waited for."""
+        reader = self._card if self._card is not None else self._raw
+        if reader is not None:
+            return reader.ready()
+        return self.max_wait == float("inf")
+
+    def _package(self, results, groups):
+        """Flat per-record results -> the items next() hands out (this class: as they are)."""
+        return results
 
     def _refill(self):
         got = self._next_records()
         if got is None:
+            if self._in_flight is None:
+                self._exhausted = True
             return
         if self.yield_data:
             self._ready.extend(self.detect(*it) for it in got)
             return
         stamps, idxs, recs = got
+        groups = None
         if self.only_detections:
             keep = np.flatnonzero(recs["flags"] & (_native.FLAG_CORR | _native.FLAG_INDEX_ERROR))
             if len(keep) != len(recs):
-                stamps, idxs, recs = [stamps[i] for i in keep], idxs[keep], recs[keep]
-        self._ready.extend(self._results(stamps, idxs, recs))
+                stamps, idxs, recs, groups = [stamps[i] for i in keep], idxs[keep], recs[keep], keep
+        self._ready.extend(self._package(self._results(stamps, idxs, recs), groups))
+
+    def _more(self):
+        return not self._exhausted or self._in_flight is not None
 
     def iter_detected_records(self):
         """Batches of (timestamps float64[k], records[k]) of the DETECTED blocks only, in input
@@ -260,7 +315,7 @@ class Detector(object):
             raise TypeError("Detector was constructed without a block source")
         if self.yield_data:
             raise TypeError("record iteration is not available with yield_data")
-        while not self._exhausted:
+        while self._more():
             got = self._next_records()
             if got is None:
                 continue
@@ -272,20 +327,29 @@ class Detector(object):
                 yield np.asarray(stamps, dtype=np.float64)[keep], recs[keep]
             if len(bad):
                 self._exhausted = True
+                if self._in_flight is not None and not self.yield_data:
+                    self._engine.collect(self._in_flight[2])
+                self._in_flight = None
                 self._result(stamps[stop], int(idxs[stop]), recs[stop])   # raises
 
-    def iter_toad_lines(self):
-        """Batches of `.toad` lines (lists of str) for the detected blocks, formatted a column
-        at a time (toads_data.toad_lines) -- what `detector_cli --quiet -o` writes."""
+    def iter_toad_text(self):
+        """Batches of `.toad` text (bytes: '\\n'-terminated lines) for the detected blocks,
+        formatted by the engine library (`thr_format_toad`: the text of
+        `DetectionResult.serialize()`, byte for byte) -- what `detector_cli --quiet -o` writes."""
         for stamps, recs in self.iter_detected_records():
-            yield toads_data.toad_lines(recs, stamps, self.new_len, rxid=self.rxid,
-                                        carrier_offset_type=self._offset_type)
+            yield _native.format_toad(recs, stamps, self.new_len, rxid=self.rxid, with_txid=self._multi,
+                                      carrier_offset_f32=self._offset_type is not float)
+
+    def iter_toad_lines(self):
+        """The same as lists of lines (str, no line ends)."""
+        for text in self.iter_toad_text():
+            yield text.decode("ascii").split("\n")[:-1]
 
     def next(self):
         """Result for the next block of the `blocks` iterator."""
         if self.blocks is None and not self._ready:
             raise TypeError("Detector was constructed without a block source")
-        while not self._ready and not self._exhausted:
+        while not self._ready and self._more():
             self._refill()      # (a batch may contribute nothing under only_detections)
         if not self._ready:
             raise StopIteration
@@ -293,6 +357,9 @@ class Detector(object):
         if isinstance(item, _Deferred):
             self._ready.clear()
             self._exhausted = True      # the reference's loop died here
+            if self._in_flight is not None and not self.yield_data:
+                self._engine.collect(self._in_flight[2])
+            self._in_flight = None
             raise item.exc
         return item
 
@@ -306,58 +373,72 @@ class Detector(object):
         return self.next()
 
 
-class MultiTemplateDetector(object):
-    """Several TX templates correlated per block with ONE carrier stage / FFT#2
-    (BASELINE config "multi-template detect").  Yields, per input block, a list of
-    (detected, DetectionResult) -- one per template, `txid` set to the template index."""
+class MultiTemplateDetector(Detector):
+    """Several TX templates correlated per block with ONE carrier stage / FFT#2 (BASELINE
+    configs[4]): `settings.template` is [n_templates, template_len].  The reference correlates
+    one template (detect.py:40-58); its data model already carries the transmitter as
+    `DetectionResult.txid` (toads_data.py:22-61), which is what identifies a template here.
 
-    def __init__(self, settings, blocks=None, rxid=-1, batch_size=256, device_id=0):
-        templates = np.asarray(settings.template)
-        if templates.ndim != 2:
-            raise ValueError("settings.template must be [n_templates, template_len]")
-        self.settings = settings
-        self.blocks = iter(blocks) if blocks is not None else None
-        self.rxid = rxid
-        self.batch_size = max(1, int(batch_size))
-        self.new_len = settings.block_len - settings.history_len
-        self._engine = _native.Engine(
-            settings.block_len, settings.history_len, templates, settings.carrier_thresh,
-            settings.carrier_window, settings.corr_thresh, carrier_len=settings.carrier_len,
-            device_id=device_id, max_batch=self.batch_size)
-        self._single = Detector.__new__(Detector)  # reuse record re-hydration
-        self._single.settings, self._single.rxid, self._single.new_len = settings, rxid, self.new_len
-        self._ready = deque()
+    Iterating yields, per input block, a list of (detected, DetectionResult) -- one per
+    template in template order, `txid` = template index (under `only_detections`: the detected
+    ones of a block, blocks without any skipped).  `iter_detected_records()` /
+    `iter_toad_text()` / `iter_toad_lines()` hand out the detections flat, ordered
+    [block][template], with the txid column after the rxid (the `.toads` line layout)."""
 
-    def detect_batch(self, items):
-        if not items:
-            return []
-        arr = Detector._stack(self._single, [it[2] for it in items])
-        idx = np.array([int(it[1]) for it in items], dtype=np.int64)
-        recs = self._engine.detect(arr, idx)
-        out = []
-        for i, it in enumerate(items):
-            per_tx = []
-            for t in range(recs.shape[1]):
-                det, res = Detector._result(self._single, it[0], int(it[1]), recs[i, t])
-                res.txid = t
-                per_tx.append((det, res))
-            out.append(per_tx)
+    _multi = True
+
+    def __init__(self, settings, blocks=None, rxid=-1, yield_data=False, batch_size=None,
+                 device_id=0, max_wait=None):
+        if yield_data:
+            raise TypeError("stage dumps (yield_data) are a single-template facility")
+        super(MultiTemplateDetector, self).__init__(settings, blocks, rxid=rxid, batch_size=batch_size,
+                                                    device_id=device_id, max_wait=max_wait)
+        self.n_templates = int(np.asarray(settings.template).shape[0])
+
+    def _flat(self, stamps, idxs, recs):
+        t = recs.shape[1]
+        return (np.repeat(np.asarray(stamps, dtype=np.float64), t).tolist(), np.repeat(idxs, t),
+                recs.reshape(-1))
+
+    def _results(self, stamps, idxs, recs):
+        out = super(MultiTemplateDetector, self)._results(stamps, idxs, recs)
+        for item, txid in zip(out, recs["template_id"].tolist()):
+            if not isinstance(item, _Deferred):
+                item[1].txid = txid
         return out
 
-    def __iter__(self):
-        return self
+    def _package(self, results, groups):
+        """Flat [block][template] results -> one list per block (`groups`: the flat positions
+        that survived an only_detections filter; position // n_templates is the block)."""
+        t = self.n_templates
+        pos = np.arange(len(results)) if groups is None else np.asarray(groups)
+        out, last = [], None
+        for item, k in zip(results, (pos // t).tolist()):
+            if isinstance(item, _Deferred):
+                out.append(item)
+                last = None
+            elif k == last:
+                out[-1].append(item)
+            else:
+                out.append([item])
+                last = k
+        return out
 
-    def __next__(self):
-        if not self._ready:
-            items = []
-            for it in self.blocks:
-                items.append(it)
-                if len(items) >= self.batch_size:
-                    break
-            self._ready.extend(self.detect_batch(items))
-        if not self._ready:
-            raise StopIteration
-        return self._ready.popleft()
+    def detect_batch(self, items):
+        """[(timestamp, block_idx, block), ...] -> per block a list of (detected, result) per template."""
+        if not items:
+            return []
+        arr = self._stack([it[2] for it in items])
+        idx = np.array([int(it[1]) for it in items], dtype=np.int64)
+        stamps, idxs, recs = self._flat([it[0] for it in items], idx, self._engine.detect(arr, idx))
+        flat = self._results(stamps, idxs, recs)
+        if flat and isinstance(flat[-1], _Deferred):
+            raise flat[-1].exc
+        return self._package(flat, None)
+
+    def detect(self, timestamp, block_idx, block):
+        """One block -> [(detected, DetectionResult), ...], one per template."""
+        return self.detect_batch([(timestamp, block_idx, block)])[0]
 
 
 def _carrier_freq(carrier_info, block_len, sample_rate):
@@ -420,9 +501,16 @@ def detector_cli(detector_class, parser=None, extra_args=None, argv=None):
     single-process loop and are not printed in that mode."""
     from thrifty_amd import parallel
     argv = list(sys.argv[1:] if argv is None else argv)
-    rank, world, local = parallel.torchrun_env()
     gpus = parallel.peek_gpus(argv)
+    # a rank of a sharded run is a process that THIS CLI re-launched (or that was started with
+    # THRIFTY_SHARDED=1 on purpose): RANK / WORLD_SIZE inherited from an unrelated torchrun, MPI
+    # wrapper or container job do not turn a plain `thrifty detect` into one
+    rank, world, local = parallel.sharded_env()
     if gpus > 1 and world is None:
+        if not any(a in ("-o", "--output", "-a", "--append") or a.startswith(("--output=", "--append="))
+                   or (a[:2] in ("-o", "-a") and len(a) > 2 and a[1] != "-") for a in argv):
+            raise SystemExit("--gpus %d needs an output file (-o / -a): the ranks' detections are "
+                             "gathered and written by rank 0, nothing is printed per block" % gpus)
         sys.exit(parallel.relaunch_under_torchrun(gpus, argv))
     if world is not None and rank != 0:
         argv = _strip_output_args(argv)
@@ -436,6 +524,10 @@ def detector_cli(detector_class, parser=None, extra_args=None, argv=None):
                         help="do not write anything to standard output")
     parser.add_argument("--gpus", dest="gpus", type=int, default=1,
                         help="shard a regular input file over this many GPUs of the node")
+    parser.add_argument("--templates", dest="templates", nargs="+", metavar="NPY", default=None,
+                        help="correlate every block against several TX templates (.npy files of "
+                             "equal length, instead of the `template` setting); detections carry "
+                             "the template's position as txid, written after the rxid")
     group = parser.add_mutually_exclusive_group()
     group.add_argument("-o", "--output", dest="output", type=argparse.FileType("w"),
                        help="Output file (.toad) ('-' for stdout)")
@@ -457,9 +549,17 @@ def detector_cli(detector_class, parser=None, extra_args=None, argv=None):
         # binary stream -> batches with on-device base64 decode (card_reader-compatible tuples
         # if the detector class iterates it the classic way)
         blocks = CardStream(args.input, config.block_size)
-    template = np.load(config.template)
+    if args.templates:
+        tpls = [np.load(f) for f in args.templates]
+        if len({t.shape for t in tpls}) != 1 or tpls[0].ndim != 1:
+            raise SystemExit("--templates: the templates must be 1-D arrays of one length")
+        template = np.stack(tpls)
+        if detector_class is Detector:
+            detector_class = MultiTemplateDetector
+    else:
+        template = np.load(config.template)
     settings = DetectorSettings(block_len=config.block_size, history_len=config.block_history,
-                                carrier_len=len(template), carrier_thresh=config.carrier_threshold,
+                                carrier_len=template.shape[-1], carrier_thresh=config.carrier_threshold,
                                 carrier_window=window, template=template,
                                 corr_thresh=config.corr_threshold)
     if world is not None:
@@ -468,23 +568,29 @@ def detector_cli(detector_class, parser=None, extra_args=None, argv=None):
             raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
         blocks.shard(rank, world)
         detections = detector_class(settings, blocks, rxid=config.rxid, device_id=local, **kwargs)
+        if not hasattr(detections, "iter_detected_records"):
+            raise SystemExit("--gpus: %s does not expose iter_detected_records() (the records that "
+                             "travel between the ranks)" % type(detections).__name__)
         parallel.run_sharded(detections, rank, world, local, output_file)
         return
     detections = detector_class(settings, blocks, rxid=config.rxid, **kwargs)
     if args.quiet and hasattr(detections, "only_detections"):
         detections.only_detections = True   # nothing is printed for the other blocks anyway
-    if args.quiet and output_file is not None and hasattr(detections, "iter_toad_lines"):
-        # nothing per block is needed: format the detections a column at a time
-        for lines in detections.iter_toad_lines():
-            output_file.write("\n".join(lines) + "\n")
+    if args.quiet and output_file is not None and hasattr(detections, "iter_toad_text"):
+        # nothing per block is needed: the library formats the detections of a batch at once
+        for text in detections.iter_toad_text():
+            output_file.write(text.decode("ascii"))
         output_file.flush()
         return
     summary = SummaryLineFormatter(config.sample_rate, config.block_size, add_dt=True)
-    for detected, result in detections:
-        if detected and output_file is not None:
-            print(result.serialize(), file=output_file)
-        if not args.quiet:
-            print(summary(detected, result), file=info_out)
+    for item in detections:
+        # (one (detected, result) pair per block; a multi-template detector: a list of them)
+        for detected, result in (item if isinstance(item, list) else [item]):
+            if detected and output_file is not None:
+                print(result.serialize(), file=output_file)
+            if not args.quiet:
+                line = summary(detected, result)
+                print(line if result.txid is None else "tx=%d; %s" % (result.txid, line), file=info_out)
     if output_file is not None:
         output_file.flush()
 

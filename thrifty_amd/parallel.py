@@ -66,6 +66,14 @@ def torchrun_env():
     return 0, None, 0
 
 
+def sharded_env():
+    """(rank, world, local_rank) of a rank that `relaunch_under_torchrun` started (it sets
+    THRIFTY_SHARDED=1), else (0, None, 0) -- whatever RANK / WORLD_SIZE the environment holds."""
+    if os.environ.get("THRIFTY_SHARDED") == "1":
+        return torchrun_env()
+    return 0, None, 0
+
+
 def peek_gpus(argv):
     """Value of --gpus in argv (1 if absent) without parsing anything else."""
     for i, a in enumerate(argv):
@@ -90,6 +98,7 @@ def relaunch_under_torchrun(gpus, argv):
     target = ["-m", spec.name] if spec is not None and spec.name else [os.path.abspath(sys.argv[0])]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes)
+    env["THRIFTY_SHARDED"] = "1"                        # marks the children as ranks of THIS CLI
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + target + list(argv)
     return subprocess.call(cmd, env=env)
@@ -105,7 +114,7 @@ def run_sharded(detections, rank, world, local, output_file, backend="nccl"):
     that block and every rank raises, like the single-process loop."""
     import torch
     import torch.distributed as dist
-    from thrifty_amd import _native, toads_data
+    from thrifty_amd import _native
 
     if backend == "nccl":       # RCCL; "gloo" (CPU tensors) is for the tests of this function
         dev = torch.device("cuda", local)
@@ -139,10 +148,13 @@ def run_sharded(detections, rank, world, local, output_file, backend="nccl"):
         stamps = recs["reserved"].view(np.float64)
         step = 1 << 16
         for s in range(0, len(recs), step):
-            lines = toads_data.toad_lines(recs[s:s + step], stamps[s:s + step], detections.new_len,
-                                          rxid=detections.rxid,
-                                          carrier_offset_type=getattr(detections, "_offset_type", float))
-            output_file.write("\n".join(lines) + "\n")
+            # (multi-template detection: records arrive ordered [block][template]; the txid column
+            # is the template id, as the single-process writer prints it)
+            text = _native.format_toad(
+                recs[s:s + step], stamps[s:s + step], detections.new_len, rxid=detections.rxid,
+                with_txid=getattr(detections, "_multi", False),
+                carrier_offset_f32=getattr(detections, "_offset_type", float) is not float)
+            output_file.write(text.decode("ascii"))
         output_file.flush()
     dist.barrier()
     dist.destroy_process_group()
