@@ -497,9 +497,12 @@ def oracle_parity(n, h, blocks_u8, template, gpu_rec, procs):
             ok = (r["corr_sample"] == samp and bool(r["flags"] & F.FLAG_CORR) == det and
                   abs(r["corr_energy"] - en) <= 1e-4 * abs(en) and abs(r["corr_offset"] - off) <= 1e-4 + 1e-4 * abs(off))
         mism += 0 if ok else 1
-    return {"parity_checked": len(rows), "parity_mismatches": mism, "oracle_procs": procs,
-            "oracle_seconds": dt, "oracle_blocks_per_s_all_procs": len(rows) / dt,
-            "fields": "carrier bin, both verdicts, SoA sample index exact; corr energy and sub-sample offset 1e-4"}
+    return {"value": len(rows) / dt, "unit": "blocks/s", "cores": procs, "kind": "port",
+            "sample": "%d blocks of one launch batch of this leg through oracle/thrifty_np.py, %d spawned "
+                      "workers (pool start-up included), %.1f s" % (len(rows), procs, dt),
+            "parity_checked": len(rows), "parity_mismatches": mism,
+            "parity_fields": "carrier bin, both verdicts, SoA sample index exact; corr energy and sub-sample "
+                             "offset 1e-4"}
 
 
 def extra_leg(torch, F, synth, dev, local, key, seconds, cpu_ok):
@@ -528,7 +531,7 @@ def extra_leg(torch, F, synth, dev, local, key, seconds, cpu_ok):
         # the oracle check at benchmark shape: 2048 blocks of ONE 16384-block launch batch
         ns = 2048
         procs, _ = physical_cores()
-        out["oracle_parity"] = oracle_parity(leg.n, leg.h, leg.data[:ns].cpu().numpy(), leg.tpls[0],
+        out["cpu_baseline"] = oracle_parity(leg.n, leg.h, leg.data[:ns].cpu().numpy(), leg.tpls[0],
                                              leg.host_records(ns), procs)
     leg.close()
     out["leg_wall_s"] = time.perf_counter() - t_leg

@@ -40,10 +40,13 @@ def test_two_tickets_interleave_and_equal_the_synchronous_call(case):
     rb = eng.collect(b)                                         # any order
     ra = eng.collect(a)
     assert eng.poll(c) in (True, False)
+    eng.sync()
+    assert eng.poll(c) is True                                  # finished: collect would not block
     rc = eng.collect(c)
-    assert eng.poll(c) is True or True
     with pytest.raises(F.NativeError, match="not open"):
         eng.collect(c)                                          # exactly once
+    with pytest.raises(F.NativeError, match="not open"):
+        eng.poll(c)
     got = np.concatenate([ra, rb, rc])
     assert got.tobytes() == want.tobytes()
     # the handle is back to normal

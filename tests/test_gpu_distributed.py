@@ -207,7 +207,9 @@ def test_thrifty_detect_templates_gpus_cli_equals_single_process(golden, tmp_pat
     detector_cli(Detector, argv=common[:4] + ["-o", str(tmp_path / "single.toad")])
     single = [ln.split() for ln in (tmp_path / "single.toad").read_text().strip().split("\n")]
     tx0 = [ln[:1] + ln[2:] for ln in lines if ln[1] == "0"]
-    assert [ln[:5] for ln in tx0] == [ln[:5] for ln in single]       # rxid, time, block, soa, sample
+    # (the 4-template kernel is another specialisation: same indices, floats to rounding)
+    assert [ln[:3] + ln[4:5] for ln in tx0] == [ln[:3] + ln[4:5] for ln in single]   # rxid, time, block, sample
+    assert max(abs(float(a[3]) - float(b[3])) for a, b in zip(tx0, single)) < 1e-5     # soa
     # the non-quiet loop prints the same detections
     detector_cli(Detector, argv=[a for a in common if a != "--quiet"] + ["-o", str(tmp_path / "loud.toads")])
     assert (tmp_path / "loud.toads").read_text() == one

@@ -134,3 +134,50 @@ def test_large_batches_equal_small_batches(n, n_tpl, fmt_c64, total):
         if res.carrier.detected:
             assert r["corr_sample"] == res.corr.sample
             np.testing.assert_allclose(r["corr_energy"], res.corr.energy, rtol=1e-4)
+
+
+def test_c3_benchmark_shape_one_full_sub_batch_against_the_oracle():
+    """BASELINE configs[2] at the shape bench.py runs it: ONE launch batch of 16384 blocks (the
+    long path's whole sub-batch: every workgroup of the fused kernel walks 64 blocks, the carrier
+    stage its 16384 x 4 decimated sequences) holding 2048 FRESH blocks of bench.py's generator,
+    each at eight scattered slots.  Every copy must give the same record (slot / workgroup
+    independence), and the 2048 distinct blocks are checked against the CPU oracle: carrier bin,
+    both verdicts and the SoA sample index exact, energies 2e-5, sub-sample offset 5e-6."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import bench
+    import soak_util
+    n, h, fresh, slots = 65536, 4096, 2048, 16384
+    dev = torch.device("cuda", 0)
+    tpl = synth.gold_template(11, 2, 2.0).astype(np.float64)
+    win = onp.unique_window(n, h, len(tpl))
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(bench.SEED + 33)
+    base = bench.synth_on_device(torch, dev, gen, fresh, n, tpl, win, 0.9)
+    order = torch.cat([torch.randperm(fresh, generator=gen, device=dev) for _ in range(slots // fresh)])
+    data = base[order]                                    # 2 GiB: one full sub-batch
+    idx = torch.arange(1000, 1000 + slots, dtype=torch.int64, device=dev)
+    rec_d = torch.zeros((slots, 64), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    eng = F.Engine(n, h, tpl, (0, 15, 0), (7, 110), (0, 15, 0), max_batch=slots)
+    eng.detect_device(data.data_ptr(), F.THR_IN_U8, slots, rec_d.data_ptr(), idx.data_ptr())
+    eng.sync()
+    rec = rec_d.cpu().numpy().view(F.RECORD_DTYPE).reshape(-1)
+    assert np.array_equal(rec["block_idx"], np.arange(1000, 1000 + slots))
+    order_h = order.cpu().numpy()
+    firsts = np.full(fresh, -1)
+    firsts[order_h[::-1]] = np.arange(slots)[::-1]        # first slot of every distinct block
+    cols = [c for c in F.RECORD_DTYPE.names if c != "block_idx"]
+    ref = rec[firsts][order_h]                            # the first copy's record, per slot
+    for c in cols:
+        assert np.array_equal(rec[c], ref[c]), c          # all eight copies identical, bit for bit
+    blocks = base.cpu().numpy()
+    rows = soak_util.run_oracle(blocks, n, h, tpl, (0, 15, 0), (7, 110), (0, 15, 0), chunk=16)
+    mism, worst, ties = soak_util.compare(rec[firsts], rows, blocks, F.FLAG_CARRIER, F.FLAG_CORR)
+    assert sum(1 for r in rows if r is not None and r[5]) > 0.8 * fresh
+    assert mism == dict(bin=0, carrier=0, sample=0, det=0, index_error=0), (mism, worst, ties)
+    assert len(ties) <= 1, ties
+    assert worst["offset"] <= 5e-6 and worst["energy"] <= 2e-5 and worst["noise"] <= 2e-5, worst
+    assert worst["car_off"] <= 2e-4 and worst["car_energy"] <= 2e-5, worst

@@ -278,7 +278,8 @@ def test_product_package_does_not_import_the_oracle():
     for fn in ("make_oracle", "card_to_toad_leg"):     # ... and only those legs call them
         users = {re.findall(r"^def (\w+)\(", bench_src[:m.start()], re.M)[-1]
                  for m in re.finditer(r"\b%s\(" % fn, bench_src) if not bench_src[:m.start()].endswith("def ")}
-        assert users <= {"cpu_baseline", "_oracle_worker", "main"}, (fn, users)
+        # (_parity_worker: the c3 leg's cpu_baseline -- the oracle over 2048 blocks of that leg)
+        assert users <= {"cpu_baseline", "_oracle_worker", "_parity_worker", "main"}, (fn, users)
     header = open(os.path.join(ROOT, "oracle", "thrifty_np.py")).read()
     assert "TEST INFRASTRUCTURE ONLY" in header and "PINNED" in header
 
