@@ -49,3 +49,11 @@ cnt = sum(1 for d, r in det if d)
 dt = time.perf_counter() - t0
 print("%-30s %8.0f blocks/s (%d detections, %.1f MB stream, %.1f MS/s)" % (
     "sparse file, detections only", nb2 / dt, cnt, len(raw2) / 1e6, nb2 * new / dt / 1e6))
+
+# the CLI's quiet path (`thrifty detect --raw --quiet -o`): no per-block Python objects, text from thr_format_toad
+for label, path, nblk in (("dense file -> .toad text", tmp.name, nb), ("sparse file -> .toad text", tmp2.name, nb2)):
+    det = Detector(st, block_data.RawStream(open(path, "rb"), n, h), rxid=0)
+    t0 = time.perf_counter()
+    nbytes = sum(len(tx) for tx in det.iter_toad_text())
+    dt = time.perf_counter() - t0
+    print("%-30s %8.0f blocks/s (%.1f MB of .toad text, %.1f MS/s)" % (label, nblk / dt, nbytes / 1e6, nblk * new / dt / 1e6))

@@ -690,6 +690,10 @@ int run_batch(thr_handle* h, const void* d_samples, int format, const long long*
               float2* dump_corr, int dump_template, bool carrier_only, size_t stride = 0) {
     // stride 0: blocks packed back to back; otherwise raw-stream framing (overlapping blocks)
     h->dev.blk_stride = stride ? stride : size_t(h->cfg.block_len) * (format == THR_IN_U8 ? 2 : 8);
+    // dev knob (A/B only, results are those of block 0): every block reads the SAME samples, which
+    // then come from L2 -- what is left of a kernel's time is what it costs WITHOUT its HBM fetch
+    static const bool stride0 = getenv("THR_DEV_STRIDE0") != nullptr;
+    if (stride0) h->dev.blk_stride = 0;
     if (h->small) {
         if (!dump_fft && !dump_xhat && !dump_corr && !carrier_only)
             return run_batch_small(h, d_samples, format, d_block_idx, n_blocks, d_out);

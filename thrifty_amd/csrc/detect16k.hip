@@ -17,6 +17,8 @@
 //                 (carrier_sync.py:222-238, soa_estimator.py:78-170)
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "detect_common.hpp"
 #include "fft_regs.hpp"
 #include "kernel_util.hpp"
@@ -433,7 +435,7 @@ correlate_fn correlate_variant(int fmt, bool want_std, bool multi, bool dump) {
 }
 #endif
 
-// window geometries with a specialised peak search (one template, no stddev term, no dumps)
+// window geometries with a specialised peak search (no stddev term, no dumps)
 struct RowGeom {
     int lo, hi;
 };
@@ -449,17 +451,20 @@ bool geom_applies(const RowGeom& g, const DevCfg& cfg) {
     return low_out && high_out && inside;
 }
 
-correlate_fn geom_variant(int fmt, int g) {
+template <int FMT, bool MULTI>
+correlate_fn geom_pick(int g) {
+    return g == 0 ? &k_correlate<FMT, false, MULTI, false, kRowGeoms[0].lo, kRowGeoms[0].hi>
+                  : &k_correlate<FMT, false, MULTI, false, kRowGeoms[1].lo, kRowGeoms[1].hi>;
+}
+correlate_fn geom_variant(int fmt, int g, bool multi) {
 #ifdef THR_DEV_MINIMAL
     (void)fmt;
     (void)g;
+    (void)multi;
     return nullptr;
 #else
-    if (fmt == THR_IN_U8)
-        return g == 0 ? &k_correlate<THR_IN_U8, false, false, false, kRowGeoms[0].lo, kRowGeoms[0].hi>
-                      : &k_correlate<THR_IN_U8, false, false, false, kRowGeoms[1].lo, kRowGeoms[1].hi>;
-    return g == 0 ? &k_correlate<THR_IN_C64, false, false, false, kRowGeoms[0].lo, kRowGeoms[0].hi>
-                  : &k_correlate<THR_IN_C64, false, false, false, kRowGeoms[1].lo, kRowGeoms[1].hi>;
+    if (fmt == THR_IN_U8) return multi ? geom_pick<THR_IN_U8, true>(g) : geom_pick<THR_IN_U8, false>(g);
+    return multi ? geom_pick<THR_IN_C64, true>(g) : geom_pick<THR_IN_C64, false>(g);
 #endif
 }
 static_assert(kNumRowGeoms == 2, "geom_variant() enumerates the geometries by hand");
@@ -481,13 +486,14 @@ hipError_t prepare_16k() {
                     if (e != hipSuccess) return e;
                 }
     for (int fmt = 0; fmt < 2; ++fmt)
-        for (int g = 0; g < kNumRowGeoms; ++g) {
-            correlate_fn fn = geom_variant(fmt, g);
-            if (fn == nullptr) continue;
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-            if (e != hipSuccess) return e;
-        }
+        for (int g = 0; g < kNumRowGeoms; ++g)
+            for (int m = 0; m < 2; ++m) {
+                correlate_fn fn = geom_variant(fmt, g, m != 0);
+                if (fn == nullptr) continue;
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+                if (e != hipSuccess) return e;
+            }
     return hipSuccess;
 }
 
@@ -500,10 +506,11 @@ hipError_t launch_correlate_16k(int fmt, const void* samples, const DevCfg& cfg,
                                 hipStream_t stream) {
     const bool dump = dump_xhat != nullptr || dump_corr != nullptr;
     correlate_fn fn = correlate_variant(fmt, cfg.cor_want_std != 0, cfg.n_templates > 1, dump);
-    if (!dump && cfg.cor_want_std == 0 && cfg.n_templates == 1 && cfg.ablate == 0)
+    static const bool no_geom = getenv("THR_NO_GEOM") != nullptr;   // dev A/B
+    if (!dump && cfg.cor_want_std == 0 && cfg.ablate == 0 && !no_geom)
         for (int g = 0; g < kNumRowGeoms; ++g)
-            if (geom_applies(kRowGeoms[g], cfg) && geom_variant(fmt, g) != nullptr) {
-                fn = geom_variant(fmt, g);
+            if (geom_applies(kRowGeoms[g], cfg) && geom_variant(fmt, g, cfg.n_templates > 1) != nullptr) {
+                fn = geom_variant(fmt, g, cfg.n_templates > 1);
                 break;
             }
     hipLaunchKernelGGL(fn, dim3(grid), dim3(NT), LDS_BYTES, stream, samples, cfg,
