@@ -424,16 +424,21 @@ class Leg(object):
             avg_ms = dom_ms / dom_cnt
             units = self.B * max(solo_batches, 1) / dom_cnt      # blocks one launch of it processes
         achieved = self.bytes_per_block * units / (avg_ms * 1e-3) / 1e9
-        traffic = None
+        traffic = clock = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
                 key = self.name + ("_t%d" % self.T if self.T > 1 else "") + ("_sparse" if self.mix != "dense" else "")
-                traffic = json.load(open(tpath)).get(key, {}).get(dom, {}).get("bytes_per_launch")
+                entry = json.load(open(tpath)).get(key, {}).get(dom, {})
+                traffic = entry.get("bytes_per_launch")
+                clock = entry.get("effective_clock_ghz")
             except Exception:
-                traffic = None
+                traffic = clock = None
         return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                # GRBM_GUI_ACTIVE / duration of this kernel in the committed PMC pass (profiles/): the
+                # clock the part sustained under it (MI355X_MICROARCH.md, "DVFS give-back"); max 2.4
+                "effective_clock_ghz_profiled": clock, "avg_launch_ms": avg_ms,
                 "launches": dom_cnt, "blocks_per_launch": units,
                 "algorithmic_bytes_per_block": self.bytes_per_block,
                 "algorithmic_bytes_per_launch": self.bytes_per_block * units,
@@ -587,7 +592,8 @@ def main():
     # ---- calibration burst = the round-1/2 protocol: 1 Mi blocks (32 launch batches) straight after
     # a two-batch code-load warm-up -- reported as `value_first_1Mi`, and it sizes a step
     leg.timed(0, 2)
-    burst_batches = max(2, min(leg.resident_batches, (1 << 20) // B))
+    # (--min-seconds 0 -- profiler passes, quick A/B runs: no burst, a step is one launch batch)
+    burst_batches = max(2, min(leg.resident_batches, (1 << 20) // B)) if args.min_seconds > 0 else 2
     burst_dt, _ = leg.timed(0, burst_batches)
     burst_rate = burst_batches * B / burst_dt
     R = 1
@@ -662,7 +668,7 @@ def main():
                        "detections_gathered": int(gathered.shape[0])},
             # the sustained-rate protocol (wall clock over >= 1 M blocks after warm-up)
             "timed_region_s": dt, "blocks_timed": blocks_total,
-            "value_first_1Mi": burst_rate,
+            "value_first_1Mi": burst_rate if args.min_seconds > 0 else None,
             "first_1Mi": {"blocks": burst_batches * B, "seconds": burst_dt,
                           "note": "rank 0's first %d launch batches after a two-batch code-load warm-up (the "
                                   "round-1/2 protocol), no gather" % burst_batches},

@@ -12,11 +12,11 @@ K=$R/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O $K
 export TMPDIR=/tmp
 cd $R
-# kernel-trace pass: bench.py's own defaults (32 steps x 32768 blocks), so that clocks settle and the per-kernel averages
+# kernel-trace pass: bench.py's sustained protocol (>= 1 s of steps), so that clocks settle and the per-kernel averages
 # are the ones bench.py's HIP events see; PMC passes: 8 steps (counter collection serialises
 # every dispatch, data generation included -- a full-length run takes tens of minutes)
-BENCH_STATS="python bench.py --streams 1 --cpu-seconds 0 --profile-kernels 0 $*"
-BENCH="python bench.py --streams 1 --steps 8 --warmup 1 --cpu-seconds 0 --profile-kernels 0 $*"
+BENCH_STATS="python bench.py --streams 1 --cpu-seconds 0 --profile-kernels 0 --legs none --min-seconds 1 $*"
+BENCH="python bench.py --streams 1 --steps 8 --warmup 1 --cpu-seconds 0 --profile-kernels 0 --legs none --min-seconds 0 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o stats -- $BENCH_STATS > $O/bench_stats.log 2>&1
 pass() {  # name counters...
   local name=$1; shift

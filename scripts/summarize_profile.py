@@ -62,10 +62,35 @@ if acc:
     print("FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE under-reports wide coalesced")
     print("reads by 2x (MI355X_MICROARCH.md, HBM section) -- see DESIGN.md for the corrected figure.")
     import json
+    # effective clock per kernel: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / duration of the same
+    # dispatches (timestamps of the GRBM pass's own kernel trace)
+    dur = defaultdict(list)
+    for f in find("*kernel_trace.csv"):
+        if "pmc_grbm" not in f:
+            continue
+        for r in csv.DictReader(open(f)):
+            try:
+                dur[short(r["Kernel_Name"])].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+            except (KeyError, ValueError):
+                pass
+    clocks = {}
+    for k in acc:
+        g = acc[k].get("GRBM_GUI_ACTIVE")
+        if g and dur.get(k):
+            clocks[k] = (sum(g) / len(g)) / 8.0 / (sum(dur[k]) / len(dur[k]))     # cycles per ns = GHz
+    if clocks:
+        print()
+        print("## effective clock under PMC collection (GRBM_GUI_ACTIVE / 8 XCDs / kernel duration)\n")
+        print("| kernel | GHz | mean duration us (GRBM pass) |")
+        print("|---|---|---|")
+        for k in sorted(clocks):
+            print("| %s | %.3f | %.1f |" % (k, clocks[k], sum(dur[k]) / len(dur[k]) / 1e3))
     traffic = {}
     for k in acc:
         if k.startswith("k_") and "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
             f = sum(acc[k]["FETCH_SIZE"]) / len(acc[k]["FETCH_SIZE"])
             w = sum(acc[k]["WRITE_SIZE"]) / len(acc[k]["WRITE_SIZE"])
             traffic[k] = {"fetch_kib_raw": f, "write_kib": w, "bytes_per_launch": int((2 * f + w) * 1024)}
+            if k in clocks:
+                traffic[k]["effective_clock_ghz"] = clocks[k]
     json.dump(traffic, open(os.path.join(root, "hbm_traffic.json"), "w"), indent=1)

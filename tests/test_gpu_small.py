@@ -95,7 +95,6 @@ def test_short_blocks_two_templates_and_stage_dumps():
         assert np.array_equal(got["flags"], want["flags"])
         np.testing.assert_allclose(got["corr_energy"], want["corr_energy"], rtol=1e-6)
     assert np.all(rec[:, 1]["template_id"] == 1)
-    # yield_data intermediates come from the multi-pass pipeline (allocated on demand)
     xhat, corr = both.debug_stage(blocks[:3], template_id=0)
     lo, hi = onp.unique_window(n, h, len(tpl))
     for i in range(3):
@@ -103,12 +102,64 @@ def test_short_blocks_two_templates_and_stage_dumps():
             assert int(np.argmax(np.abs(corr[i][lo:hi]))) + lo == rec[i, 0]["corr_sample"]
 
 
-def test_stddev_terms_fall_back_to_the_multi_pass_pipeline(golden):
-    """(the LDS kernels carry no stddev sums: such settings still work, through generic.hip)"""
-    n = 4096
-    h, tpl, cwin, blocks, _ = make_case(n, 24, seed=6)
-    eng = F.Engine(n, h, tpl, (0, 12, 1.0), cwin, (0, 12, 0.5), max_batch=16)
+@pytest.mark.parametrize("n", [1024, 2048, 4096, 8192])
+def test_stage_dumps_of_the_lds_kernels_equal_the_oracle(n):
+    """Detector.detect(yield_data=True)'s intermediates (detect.py:75-78) and the FFT test hook now
+    come from the LDS-resident kernels' dump mode: spectrum vs np.fft, shifted spectrum and
+    correlation vs the oracle, for either template of a two-template engine; the records of the
+    dump call equal the plain call's."""
+    h, tpl, cwin, blocks, _ = make_case(n, 21, seed=40 + n, signal_frac=1.0)
+    bits = GEOMETRY[n][1]
+    tpl2 = synth.gold_template(bits, 5).astype(np.float64)
+    thr = (0, 15, 0)
+    eng = F.Engine(n, h, np.stack([tpl, tpl2]), thr, cwin, thr, max_batch=32)
+    spec = eng.debug_fft(blocks[:19])            # 19: a partly filled last group for every R1
+    for i in range(19):
+        ref = np.fft.fft(onp.iq_u8_to_c64(blocks[i]).astype(np.complex128))
+        assert np.linalg.norm(spec[i] - ref) / np.linalg.norm(ref) < 2e-6
+    plain = eng.detect(blocks[:19])
+    for t, tp in enumerate((tpl, tpl2)):
+        orc = onp.OracleDetector(n, h, tp, thr, cwin, thr)
+        xhat, corr = eng.debug_stage(blocks[:19], template_id=t)
+        for i in range(19):
+            (res,), ((xh, co),) = orc.detect_u8(0, blocks[i], want_data=True)
+            assert res.carrier.detected
+            # (n < 4096: the short template's Dirichlet lobe is wide against the 7 fitted bins, the
+            # fitted carrier offset -- and with it the shift -- is only good to ~1e-3 bins, see
+            # test_fresh_short_blocks_equal_the_oracle; a shift error d bins is a phase ramp of
+            # +-pi d across the block)
+            tol = 5e-6 if n >= 4096 else 3e-3
+            assert np.linalg.norm(xhat[i] - xh) / np.linalg.norm(xh) < tol
+            assert np.linalg.norm(corr[i][:len(co)] - co) / np.linalg.norm(co) < tol
+            assert plain[i, t]["corr_sample"] == res.corr.sample
+    # complex64 input through the same mode
+    spec2 = eng.debug_fft(np.stack([onp.iq_u8_to_c64(b) for b in blocks[:5]]))
+    np.testing.assert_allclose(spec2, spec[:5], rtol=0, atol=1e-4 * np.abs(spec[:5]).max())
+
+
+@pytest.mark.parametrize("n,nb", [(1024, 150), (2048, 120), (4096, 100), (8192, 60)])
+def test_stddev_terms_run_in_the_lds_kernels_and_equal_the_oracle(n, nb, monkeypatch):
+    """Thresholds with a stddev term (carrier_detect.py:110-115, soa_estimator.py:127-134): the
+    short-block kernels carry the sums themselves now (no detour through the multi-pass
+    pipeline); records against the oracle on fresh blocks, and against the multi-pass pipeline."""
+    h, tpl, cwin, blocks, truth = make_case(n, nb, seed=6 + n)
+    cthr, xthr = (0, 12, 1.0), (0, 12, 0.5)
+    eng = F.Engine(n, h, tpl, cthr, (0, -1), xthr, max_batch=64)       # full window: every |X| counts
     rec = eng.detect(blocks)[:, 0]
-    rows = soak_util.run_oracle(blocks, n, h, tpl, (0, 12, 1.0), cwin, (0, 12, 0.5), procs=4, chunk=8)
-    mism, worst, ties = soak_util.compare(rec, rows, blocks, F.FLAG_CARRIER, F.FLAG_CORR)
-    assert mism == dict(bin=0, carrier=0, sample=0, det=0, index_error=0), (mism, worst)
+    rows = soak_util.run_oracle(blocks, n, h, tpl, cthr, (0, -1), xthr, procs=8, chunk=16)
+    mism, worst, ties = soak_util.compare(rec, rows, blocks, F.FLAG_CARRIER, F.FLAG_CORR,
+                                          only=np.asarray(truth["has_signal"], dtype=bool))
+    assert mism == dict(bin=0, carrier=0, sample=0, det=0, index_error=0), (mism, worst, ties)
+    assert len(ties) <= 1
+    assert worst["offset"] <= 5e-6 and worst["energy"] <= 2e-5 and worst["noise"] <= 2e-5, worst
+    monkeypatch.setenv("THR_FORCE_GENERIC", "1")
+    slow_eng = F.Engine(n, h, tpl, cthr, (0, -1), xthr, max_batch=64)
+    monkeypatch.delenv("THR_FORCE_GENERIC")
+    slow = slow_eng.detect(blocks)[:, 0]
+    assert np.array_equal(rec["flags"], slow["flags"]) and np.array_equal(rec["corr_sample"], slow["corr_sample"])
+    # a verdict that flips with the stddev coefficient proves the term is live in these kernels
+    hard = F.Engine(n, h, tpl, (0, 12, 1e6), (0, -1), xthr, max_batch=64).detect(blocks)[:, 0]
+    assert ((rec["flags"] & F.FLAG_CARRIER) != 0).sum() > 0.4 * nb
+    assert ((hard["flags"] & F.FLAG_CARRIER) != 0).sum() == 0
+    hard2 = F.Engine(n, h, tpl, cthr, (0, -1), (0, 12, 1e9), max_batch=64).detect(blocks)[:, 0]
+    assert ((hard2["flags"] & F.FLAG_CORR) != 0).sum() == 0 < ((rec["flags"] & F.FLAG_CORR) != 0).sum()

@@ -100,8 +100,7 @@ struct thr_handle {
     int n_cu = 0;
     bool fast = false;       // LDS-resident 16384 kernels; else the generic multi-pass path
     bool lng = false;        // block_len = 2 or 4 x 16384: R0 LDS sub-transforms per block
-    bool small = false;      // block_len = 1024 ... 8192: 16 / R1 blocks per workgroup in LDS (no
-                             // stddev threshold terms; dumps take the generic path)
+    bool small = false;      // block_len = 1024 ... 8192: 16 / R1 blocks per workgroup in LDS
     int long_batch = 0;      // long path: blocks per internal sub-batch
     int long_chunk = 0;      // long path: work-list slots per correlate-stage chunk (sizes d_dsub)
     float* d_win_pow = nullptr;     // long: [long_batch][win_w] |X|^2 of the window bins (+-3)
@@ -254,7 +253,6 @@ int build_constants(thr_handle* h) {
     //     digit-reversed, lane-coalesced order k_correlate consumes
     const int w = h->cfg.template_len, nt = h->cfg.n_templates;
     std::vector<float2> spec(size_t(nt) * n);
-    std::vector<float2> spec_nat(h->small ? size_t(nt) * n : 0);   // small: natural order too (dump path)
     for (int t = 0; t < nt; ++t) {
         std::vector<std::complex<double>> buf(n, 0.0);
         double energy = 0;
@@ -287,11 +285,6 @@ int build_constants(thr_handle* h) {
                     const std::complex<double> cc = std::conj(buf[k]) / double(n);
                     out[((k3 >> 1) * tb + c) * 2 + (k3 & 1)] = float2{float(cc.real()), float(cc.imag())};
                 }
-            float2* nat = spec_nat.data() + size_t(t) * n;
-            for (int k = 0; k < n; ++k) {
-                const std::complex<double> cc = std::conj(buf[k]) / double(n);
-                nat[k] = float2{float(cc.real()), float(cc.imag())};
-            }
         } else if (h->fast) {
             for (int tid = 0; tid < 512; ++tid)
                 for (int k3 = 0; k3 < 32; ++k3) {
@@ -314,11 +307,6 @@ int build_constants(thr_handle* h) {
         h->d_tspec = reinterpret_cast<float4*>(d_spec);
     else
         h->d_tspec_nat = d_spec;
-    if (h->small) {
-        HIP_TRY(hipMalloc(&h->d_tspec_nat, spec_nat.size() * sizeof(float2)));
-        HIP_TRY(hipMemcpy(h->d_tspec_nat, spec_nat.data(), spec_nat.size() * sizeof(float2),
-                          hipMemcpyHostToDevice));
-    }
     return THR_OK;
 }
 
@@ -659,13 +647,15 @@ int run_batch_long(thr_handle* h, const void* d_samples, int format,
 
 // Short blocks (1024 ... 8192): 16 / R1 blocks per workgroup, LDS-resident (detect_small.hip).
 int run_batch_small(thr_handle* h, const void* d_samples, int format,
-                    const long long* d_block_idx, int n_blocks, thr_record* d_out) {
+                    const long long* d_block_idx, int n_blocks, thr_record* d_out, float2* dump_fft,
+                    float2* dump_xhat, float2* dump_corr, int dump_template, bool carrier_only) {
     h->prof = h->prof_every > 0 && (h->batch_no++ % h->prof_every) == 0;
     {
         ProfScope p(h, 0);
         HIP_TRY(thr::launch_carrier_small(format, d_samples, n_blocks, h->dev, h->d_tables, h->d_gtw,
-                                          h->d_stats, h->n_cu, h->stream));
+                                          h->d_stats, dump_fft, h->n_cu, h->stream));
     }
+    if (carrier_only) return THR_OK;
     {
         ProfScope p(h, 1);
         HIP_TRY(thr::launch_fit(n_blocks, h->dev, h->d_stats, d_block_idx, h->d_shifts,
@@ -675,7 +665,8 @@ int run_batch_small(thr_handle* h, const void* d_samples, int format,
         ProfScope p(h, 2);
         HIP_TRY(thr::launch_correlate_small(format, d_samples, n_blocks, h->dev, h->d_tables, h->d_gtw,
                                             h->d_twn, h->d_tspec, h->d_shifts, h->d_work_list,
-                                            h->d_work_count, h->d_corr_stats, h->n_cu, h->stream));
+                                            h->d_work_count, h->d_corr_stats, dump_xhat, dump_corr,
+                                            dump_template, h->n_cu, h->stream));
     }
     {
         ProfScope p(h, 3);
@@ -694,14 +685,7 @@ int run_batch(thr_handle* h, const void* d_samples, int format, const long long*
     // then come from L2 -- what is left of a kernel's time is what it costs WITHOUT its HBM fetch
     static const bool stride0 = getenv("THR_DEV_STRIDE0") != nullptr;
     if (stride0) h->dev.blk_stride = 0;
-    if (h->small) {
-        if (!dump_fft && !dump_xhat && !dump_corr && !carrier_only)
-            return run_batch_small(h, d_samples, format, d_block_idx, n_blocks, d_out);
-        if (!h->d_gen_scratch)   // stage dumps (test hooks, yield_data): the multi-pass pipeline, on demand
-            HIP_TRY(hipMalloc(&h->d_gen_scratch,
-                              thr::generic_scratch_bytes(h->cfg.block_len, h->gen_batch)));
-    }
-    return (h->fast ? run_batch_fast : h->lng ? run_batch_long : run_batch_generic)(
+    return (h->small ? run_batch_small : h->fast ? run_batch_fast : h->lng ? run_batch_long : run_batch_generic)(
         h, d_samples, format, d_block_idx, n_blocks, d_out, dump_fft, dump_xhat, dump_corr,
         dump_template, carrier_only);
 }
@@ -834,8 +818,7 @@ static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out
                 d.car_prune = 2;  // any narrow window: pre-shift by win_lo - 3
         }
         d.cor_want_std = s->corr_thresh[2] != 0.0;
-        h->small = thr::small_supported(n) && getenv("THR_FORCE_GENERIC") == nullptr && !preshift_num &&
-                   !d.car_want_std && !d.cor_want_std;
+        h->small = thr::small_supported(n) && getenv("THR_FORCE_GENERIC") == nullptr && !preshift_num;
 
         h->cfg.templates = s->templates;
         rc = build_constants(h);
@@ -878,7 +861,7 @@ static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out
             const size_t per_block = size_t(3) * n * sizeof(float2);
             h->gen_batch = int(std::max<size_t>(1, std::min<size_t>(size_t(s->max_batch),
                                                                     (size_t(256) << 20) / per_block)));
-            if (!h->small)   // (short blocks run LDS-resident; their dump path allocates this on demand)
+            if (!h->small)   // (short blocks run LDS-resident)
                 CREATE_TRY(hipMalloc(&h->d_gen_scratch, thr::generic_scratch_bytes(n, h->gen_batch)));
         }
         CREATE_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));

@@ -134,14 +134,16 @@ int long_chunk_blocks(int block_len, int n_templates);
 // detect_small.hip (block_len = 1024, 2048, 4096, 8192: 16 / R1 blocks per workgroup in LDS)
 bool small_supported(int block_len);
 hipError_t prepare_small(int block_len);
+// (dump_* non-null: the stage-dump mode, natural order, [block][block_len]; the stddev sums follow
+// cfg.car_want_std / cfg.cor_want_std)
 hipError_t launch_carrier_small(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,
-                                const float2* tables, const float2* gtw, CarStats* stats, int n_cu,
-                                hipStream_t stream);
+                                const float2* tables, const float2* gtw, CarStats* stats, float2* dump_fft,
+                                int n_cu, hipStream_t stream);
 hipError_t launch_correlate_small(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,
                                   const float2* tables, const float2* gtw, const float2* twn,
                                   const float4* tspec, const ShiftParams* shifts, const int* work_list,
-                                  const int* work_count, CorrStats* corr_stats, int n_cu,
-                                  hipStream_t stream);
+                                  const int* work_count, CorrStats* corr_stats, float2* dump_xhat,
+                                  float2* dump_corr, int dump_template, int n_cu, hipStream_t stream);
 
 // card_ingest.hip (.card base64 payloads -> u8 IQ on the device)
 hipError_t launch_b64_decode(const unsigned char* d_text, const long long* d_payload_off, int n_lines,

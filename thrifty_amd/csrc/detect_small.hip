@@ -15,8 +15,9 @@
 //                       7-bin neighbourhood              (carrier_detect.py:99-154)
 //   k_correlate_small : shift -> FFT#2 -> x conj(T) -> IFFT -> |.|^2 windowed first-max
 //                       (carrier_sync.py:222-238, soa_estimator.py:97-143)
-// k_fit / k_finish (detect16k_carrier.hip) are shared.  Thresholds with a stddev term and the
-// stage dumps take the multi-pass pipeline (generic.hip) instead.
+// k_fit / k_finish (detect16k_carrier.hip) are shared.  MODE 1 adds the sums the stddev threshold
+// terms need (carrier_detect.py:110-115, soa_estimator.py:127-134), MODE 2 also the stage dumps of
+// Detector.detect(yield_data=True) (detect.py:75-78) and of the test hooks.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -222,39 +223,48 @@ __device__ __forceinline__ float halfwave_sum(float v) {
     return v;   // valid in lanes 31 and 63
 }
 
-template <int R1, bool SUM>
-__device__ __forceinline__ void group_reduce(float& s, unsigned long long& m, unsigned char* scratch,
+// NS (0, 1, 2): float sums reduced along with the key (slot: u64 key, float, float)
+template <int R1, int NS>
+__device__ __forceinline__ void group_reduce(float (&s)[2], unsigned long long& m, unsigned char* scratch,
                                              int parity, int g) {
     unsigned char* base = scratch + parity * 16 * RED_SLOT;
     const int hw = threadIdx.x >> 5;   // half-wave index 0..15
     m = halfwave_max(m);
-    if constexpr (SUM) s = halfwave_sum(s);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) s[i] = halfwave_sum(s[i]);
     if ((threadIdx.x & 31) == 31) {
         *reinterpret_cast<unsigned long long*>(base + hw * RED_SLOT) = m;
-        if constexpr (SUM) *reinterpret_cast<float*>(base + hw * RED_SLOT + 8) = s;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) *reinterpret_cast<float*>(base + hw * RED_SLOT + 8 + 4 * i) = s[i];
     }
     __syncthreads();
     unsigned long long mm = 0;
-    float ss = 0.f;
+    float ss[2] = {0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < R1; ++i) {
         const unsigned char* slot = base + (g * R1 + i) * RED_SLOT;
         const unsigned long long v = *reinterpret_cast<const unsigned long long*>(slot);
         mm = v > mm ? v : mm;
-        if constexpr (SUM) ss += *reinterpret_cast<const float*>(slot + 8);
+#pragma unroll
+        for (int j = 0; j < NS; ++j) ss[j] += *reinterpret_cast<const float*>(slot + 8 + 4 * j);
     }
     m = mm;
-    s = ss;
+    s[0] = ss[0];
+    s[1] = ss[1];
 }
+
+// kernel modes: 0 plain, 1 + the sums of the stddev threshold terms, 2 + stage dumps (and the sums)
+constexpr int MODE_PLAIN = 0, MODE_STD = 1, MODE_DUMP = 2;
 
 // =========================================================================
 // carrier stage
 // =========================================================================
-template <int FMT, int R1>
+template <int FMT, int R1, int MODE>
 __global__ __launch_bounds__(NT) void k_carrier_small(const void* __restrict__ samples, int n_blocks,
                                                       DevCfg cfg, const cpx* __restrict__ tables,
                                                       const cpx* __restrict__ gtw,
-                                                      CarStats* __restrict__ stats) {
+                                                      CarStats* __restrict__ stats,
+                                                      cpx* __restrict__ dump_fft) {
     using GE = Geo<R1>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cpx* lds = reinterpret_cast<cpx*>(smem_raw);
@@ -296,7 +306,7 @@ __global__ __launch_bounds__(NT) void k_carrier_small(const void* __restrict__ s
         // thread (row = t >> 5 = g*R1 + k1, k2 = t & 31) holds bins k1 + R1 k2 + 32 R1 k3
         const int k1 = (t >> 5) % R1;
         const int kbase = k1 + R1 * (t & 31);
-        float sum = 0.f;
+        float sums[2] = {0.f, 0.f};   // sum |X|^2, sum |X| (stddev term: MODE >= 1)
         float mg[R3];
         float bestm = -1.0f;
         unsigned bestwi = 0;
@@ -305,7 +315,12 @@ __global__ __launch_bounds__(NT) void k_carrier_small(const void* __restrict__ s
             const float p = cnorm(v[brev(k3, R3)]);
             const float m = sqrtf(p);   // the reference's argmax runs over float32 |X| (carrier_detect.py:146)
             mg[k3] = m;
-            sum += p;
+            sums[0] += p;
+            if constexpr (MODE >= MODE_STD) sums[1] += m;
+            if constexpr (MODE == MODE_DUMP) {
+                if (valid && dump_fft != nullptr)
+                    dump_fft[size_t(b) * GE::NB + kbase + GE::TB * k3] = v[brev(k3, R3)];
+            }
             const unsigned wi = unsigned(kbase + GE::TB * k3 - cfg.win_lo) & unsigned(GE::NB - 1);
             const bool take = wi < unsigned(cfg.win_count) && (m > bestm || (m == bestm && wi < bestwi));
             bestm = take ? m : bestm;
@@ -313,7 +328,7 @@ __global__ __launch_bounds__(NT) void k_carrier_small(const void* __restrict__ s
         });
         unsigned long long best =
             bestm < 0.f ? 0ull : ((unsigned long long)__float_as_uint(bestm) << 32) | (0xFFFFFFFFu - bestwi);
-        group_reduce<R1, true>(sum, best, sc_red, parity, g);
+        group_reduce<R1, MODE >= MODE_STD ? 2 : 1>(sums, best, sc_red, parity, g);
         parity ^= 1;
         const unsigned wi = 0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu);
         int peak_idx = int(wi) + cfg.win_lo;
@@ -332,8 +347,8 @@ __global__ __launch_bounds__(NT) void k_carrier_small(const void* __restrict__ s
                 st->nb[r] = val;
             }
             if (tb == 0) {
-                st->sum_mag2 = sum;
-                st->sum_mag = 0.f;
+                st->sum_mag2 = sums[0];
+                st->sum_mag = MODE >= MODE_STD ? sums[1] : 0.f;
                 st->peak_mag = __uint_as_float(unsigned(best >> 32));
                 st->peak_idx = peak_idx;
                 st->pad = 0;
@@ -346,12 +361,13 @@ __global__ __launch_bounds__(NT) void k_carrier_small(const void* __restrict__ s
 // shift + FFT#2 + matched filter + peak
 // =========================================================================
 // MULTI: more than one template -- the shifted spectrum stays live (64 VGPRs) across the loop
-template <int FMT, int R1, bool MULTI>
+template <int FMT, int R1, bool MULTI, int MODE>
 __global__ __launch_bounds__(NT) void k_correlate_small(
     const void* __restrict__ samples, DevCfg cfg, const cpx* __restrict__ tables,
     const cpx* __restrict__ gtw, const cpx* __restrict__ twn, const f4* __restrict__ tspec,
     const ShiftParams* __restrict__ shifts, const int* __restrict__ work_list,
-    const int* __restrict__ work_count, CorrStats* __restrict__ corr_stats) {
+    const int* __restrict__ work_count, CorrStats* __restrict__ corr_stats,
+    cpx* __restrict__ dump_xhat, cpx* __restrict__ dump_corr, int dump_template) {
     using GE = Geo<R1>;
     constexpr int A = GE::A;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -398,6 +414,13 @@ __global__ __launch_bounds__(NT) void k_correlate_small(
 
         const int k1 = (t >> 5) % R1;
         const int tcol = k1 * 32 + (t & 31);   // == position of this thread's bins in the template slice
+        if constexpr (MODE == MODE_DUMP) {
+            if (valid && dump_xhat != nullptr)
+                static_for<R3>([&](auto K) {
+                    constexpr int k3 = decltype(K)::value;
+                    dump_xhat[size_t(b) * GE::NB + k1 + R1 * (t & 31) + GE::TB * k3] = xh[brev(k3, R3)];
+                });
+        }
         const int n_tpl = MULTI ? cfg.n_templates : 1;
         for (int tpl = 0; tpl < n_tpl; ++tpl) {
             const int t2 = opaque_tid();  // re-derive per template: keeps LICM off the loop body
@@ -422,6 +445,7 @@ __global__ __launch_bounds__(NT) void k_correlate_small(
             float pw[32];
             float bestp = -1.0f;
             int bestn = 0;
+            float sums[2] = {0.f, 0.f};   // sum |corr|, sum |corr|^2 over [0, corr_len): MODE >= 1
             const int m0 = tb2 * A;
             static_for<32>([&](auto Q) {
                 constexpr int q = decltype(Q)::value;
@@ -431,12 +455,21 @@ __global__ __launch_bounds__(NT) void k_correlate_small(
                 const bool take = unsigned(n - cfg.corr_lo) < win_w && pw[q] > bestp;
                 bestp = take ? pw[q] : bestp;
                 bestn = take ? n : bestn;
+                if constexpr (MODE >= MODE_STD) {
+                    if (n < cfg.corr_len) {
+                        sums[1] += pw[q];
+                        sums[0] += __builtin_amdgcn_sqrtf(pw[q]);
+                    }
+                }
+                if constexpr (MODE == MODE_DUMP) {
+                    if (valid && dump_corr != nullptr && tpl == dump_template)
+                        dump_corr[size_t(b) * GE::NB + n] = c[q];
+                }
             });
             unsigned long long best =
                 bestp < 0.f ? 0ull
                             : ((unsigned long long)__float_as_uint(bestp) << 32) | (0xFFFFFFFFu - unsigned(bestn));
-            float dummy = 0.f;
-            group_reduce<R1, false>(dummy, best, sc_red, parity, g2);
+            group_reduce<R1, MODE >= MODE_STD ? 2 : 0>(sums, best, sc_red, parity, g2);
             parity ^= 1;
             const int pk = int(0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu));
             if (valid) {
@@ -462,42 +495,56 @@ __global__ __launch_bounds__(NT) void k_correlate_small(
                 if (tb2 == 0) {
                     cs->pm2 = __uint_as_float(unsigned(best >> 32));
                     cs->pk = pk;
-                    cs->sum_mag = 0.f;
-                    cs->sum_mag2 = 0.f;
+                    cs->sum_mag = MODE >= MODE_STD ? sums[0] : 0.f;
+                    cs->sum_mag2 = MODE >= MODE_STD ? sums[1] : 0.f;
                 }
             }
         }
     }
 }
 
-typedef void (*carrier_small_fn)(const void*, int, DevCfg, const cpx*, const cpx*, CarStats*);
+typedef void (*carrier_small_fn)(const void*, int, DevCfg, const cpx*, const cpx*, CarStats*, cpx*);
 typedef void (*correlate_small_fn)(const void*, DevCfg, const cpx*, const cpx*, const cpx*, const f4*,
-                                   const ShiftParams*, const int*, const int*, CorrStats*);
+                                   const ShiftParams*, const int*, const int*, CorrStats*, cpx*, cpx*, int);
 
-template <int R1>
-carrier_small_fn carrier_fn(int fmt) {
-    return fmt == THR_IN_U8 ? &k_carrier_small<THR_IN_U8, R1> : &k_carrier_small<THR_IN_C64, R1>;
+template <int R1, int FMT>
+carrier_small_fn carrier_fn(int mode) {
+    return mode == MODE_DUMP ? &k_carrier_small<FMT, R1, MODE_DUMP>
+           : mode == MODE_STD ? &k_carrier_small<FMT, R1, MODE_STD>
+                              : &k_carrier_small<FMT, R1, MODE_PLAIN>;
 }
-template <int R1>
-correlate_small_fn correlate_fn(int fmt, bool multi) {
+// (the dump mode exists in the several-template form only: it serves any template count)
+template <int R1, int FMT>
+correlate_small_fn correlate_fn(bool multi, int mode) {
+    if (mode == MODE_DUMP) return &k_correlate_small<FMT, R1, true, MODE_DUMP>;
     if (multi)
-        return fmt == THR_IN_U8 ? &k_correlate_small<THR_IN_U8, R1, true> : &k_correlate_small<THR_IN_C64, R1, true>;
-    return fmt == THR_IN_U8 ? &k_correlate_small<THR_IN_U8, R1, false> : &k_correlate_small<THR_IN_C64, R1, false>;
+        return mode == MODE_STD ? &k_correlate_small<FMT, R1, true, MODE_STD>
+                                : &k_correlate_small<FMT, R1, true, MODE_PLAIN>;
+    return mode == MODE_STD ? &k_correlate_small<FMT, R1, false, MODE_STD>
+                            : &k_correlate_small<FMT, R1, false, MODE_PLAIN>;
 }
-carrier_small_fn pick_carrier(int r1, int fmt) {
+template <int R1>
+carrier_small_fn carrier_r1(int fmt, int mode) {
+    return fmt == THR_IN_U8 ? carrier_fn<R1, THR_IN_U8>(mode) : carrier_fn<R1, THR_IN_C64>(mode);
+}
+template <int R1>
+correlate_small_fn correlate_r1(int fmt, bool multi, int mode) {
+    return fmt == THR_IN_U8 ? correlate_fn<R1, THR_IN_U8>(multi, mode) : correlate_fn<R1, THR_IN_C64>(multi, mode);
+}
+carrier_small_fn pick_carrier(int r1, int fmt, int mode) {
     switch (r1) {
-        case 1: return carrier_fn<1>(fmt);
-        case 2: return carrier_fn<2>(fmt);
-        case 4: return carrier_fn<4>(fmt);
-        default: return carrier_fn<8>(fmt);
+        case 1: return carrier_r1<1>(fmt, mode);
+        case 2: return carrier_r1<2>(fmt, mode);
+        case 4: return carrier_r1<4>(fmt, mode);
+        default: return carrier_r1<8>(fmt, mode);
     }
 }
-correlate_small_fn pick_correlate(int r1, int fmt, bool multi) {
+correlate_small_fn pick_correlate(int r1, int fmt, bool multi, int mode) {
     switch (r1) {
-        case 1: return correlate_fn<1>(fmt, multi);
-        case 2: return correlate_fn<2>(fmt, multi);
-        case 4: return correlate_fn<4>(fmt, multi);
-        default: return correlate_fn<8>(fmt, multi);
+        case 1: return correlate_r1<1>(fmt, multi, mode);
+        case 2: return correlate_r1<2>(fmt, multi, mode);
+        case 4: return correlate_r1<4>(fmt, multi, mode);
+        default: return correlate_r1<8>(fmt, multi, mode);
     }
 }
 
@@ -509,39 +556,45 @@ bool small_supported(int block_len) {
 
 hipError_t prepare_small(int block_len) {
     const int r1 = block_len / 1024;
-    for (int fmt = 0; fmt < 2; ++fmt) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pick_carrier(r1, fmt)),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-        if (e != hipSuccess) return e;
-        for (int multi = 0; multi < 2; ++multi) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(pick_correlate(r1, fmt, multi != 0)),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+    for (int fmt = 0; fmt < 2; ++fmt)
+        for (int mode = 0; mode < 3; ++mode) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pick_carrier(r1, fmt, mode)),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
             if (e != hipSuccess) return e;
+            for (int multi = 0; multi < 2; ++multi) {
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(pick_correlate(r1, fmt, multi != 0, mode)),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+                if (e != hipSuccess) return e;
+            }
         }
-    }
     return hipSuccess;
 }
 
 hipError_t launch_carrier_small(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,
-                                const float2* tables, const float2* gtw, CarStats* stats, int n_cu,
-                                hipStream_t stream) {
+                                const float2* tables, const float2* gtw, CarStats* stats, float2* dump_fft,
+                                int n_cu, hipStream_t stream) {
     const int r1 = cfg.block_len / 1024, groups = (n_blocks + 16 / r1 - 1) / (16 / r1);
-    hipLaunchKernelGGL(pick_carrier(r1, fmt), dim3(std::min(groups, n_cu)), dim3(NT), LDS_BYTES, stream,
+    const int mode = dump_fft != nullptr ? MODE_DUMP : cfg.car_want_std ? MODE_STD : MODE_PLAIN;
+    hipLaunchKernelGGL(pick_carrier(r1, fmt, mode), dim3(std::min(groups, n_cu)), dim3(NT), LDS_BYTES, stream,
                        samples, n_blocks, cfg, reinterpret_cast<const cpx*>(tables),
-                       reinterpret_cast<const cpx*>(gtw), stats);
+                       reinterpret_cast<const cpx*>(gtw), stats, reinterpret_cast<cpx*>(dump_fft));
     return hipGetLastError();
 }
 
 hipError_t launch_correlate_small(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,
                                   const float2* tables, const float2* gtw, const float2* twn,
                                   const float4* tspec, const ShiftParams* shifts, const int* work_list,
-                                  const int* work_count, CorrStats* corr_stats, int n_cu,
-                                  hipStream_t stream) {
+                                  const int* work_count, CorrStats* corr_stats, float2* dump_xhat,
+                                  float2* dump_corr, int dump_template, int n_cu, hipStream_t stream) {
     const int r1 = cfg.block_len / 1024, groups = (n_blocks + 16 / r1 - 1) / (16 / r1);
-    hipLaunchKernelGGL(pick_correlate(r1, fmt, cfg.n_templates > 1), dim3(std::min(groups, n_cu)), dim3(NT), LDS_BYTES, stream,
-                       samples, cfg, reinterpret_cast<const cpx*>(tables), reinterpret_cast<const cpx*>(gtw),
-                       reinterpret_cast<const cpx*>(twn), reinterpret_cast<const f4*>(tspec), shifts,
-                       work_list, work_count, corr_stats);
+    const int mode = (dump_xhat != nullptr || dump_corr != nullptr) ? MODE_DUMP
+                     : cfg.cor_want_std                              ? MODE_STD
+                                                                     : MODE_PLAIN;
+    hipLaunchKernelGGL(pick_correlate(r1, fmt, cfg.n_templates > 1, mode), dim3(std::min(groups, n_cu)),
+                       dim3(NT), LDS_BYTES, stream, samples, cfg, reinterpret_cast<const cpx*>(tables),
+                       reinterpret_cast<const cpx*>(gtw), reinterpret_cast<const cpx*>(twn),
+                       reinterpret_cast<const f4*>(tspec), shifts, work_list, work_count, corr_stats,
+                       reinterpret_cast<cpx*>(dump_xhat), reinterpret_cast<cpx*>(dump_corr), dump_template);
     return hipGetLastError();
 }
 
