@@ -11,8 +11,6 @@
 //   k_compact_* : order-preserving compaction of detected records (count / scan / scatter)
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
-
 #include "detect_common.hpp"
 #include "fft_regs.hpp"
 #include "kernel_util.hpp"
@@ -242,275 +240,6 @@ __global__ __launch_bounds__(NT) void k_carrier_pruned(const void* __restrict__ 
         }
         double tot[1];
         block_reduce<1, NT / 64, true>(sums, tot, best, sc_red, parity);   // (key: |X| bits, -bin)
-        parity ^= 1;
-        const int wi = int(0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu));
-        int peak_idx = wi + cfg.win_lo;
-        if (peak_idx > N) peak_idx -= N;  // sic: '>' (carrier_detect.py:151)
-        CarStats* st = stats + b;
-        if (t < 7) st->nb[t] = sqrtf(sc_bins[wi + win_off - 3 + t]);
-        if (t == 0) {
-            st->sum_mag2 = (float)(tot[0] * double(N));  // Parseval
-            st->sum_mag = 0.f;
-            st->peak_mag = __uint_as_float(unsigned(best >> 32));
-            st->peak_idx = peak_idx;
-            st->pad = 0;
-        }
-    }
-}
-
-// =========================================================================
-// K_A, pruned, SIXTEEN waves: the same transform on 1024 threads -- 4 waves per SIMD
-// =========================================================================
-// The 8-wave kernels above sit at 2 waves per SIMD: the 128 KiB LDS image of a block admits one
-// workgroup per CU, and with 32 complex values per thread that is 512 threads.  Here every thread
-// carries HALF as much -- one column pair (m = 2c, 2c+1) x 8 of the 16 sub-sequences n1 -- so the
-// same image feeds 16 waves.  The radix-16 butterfly over n1 is then shared by the two lanes l
-// and l + 32 of a wave (A: n1 = 4i + {0, 1}, B: n1 = 4i + {2, 3}): each does the first radix-4
-// stage over i for its two residues j = n1 mod 4, which yields, per class q = k1 mod 4, the
-// elements j it owns; A keeps classes {0, 2} and B classes {1, 3}, and ONE v_permlane32_swap per
-// register hands the other half over (vdst lanes 32..63 <-> src lanes 0..31: A's {1, 3} go up,
-// B's {0, 2} come down, and in BOTH lanes the kept register now holds j = 0, 1 and the received
-// one j = 2, 3 -- no selects, no LDS).  The second radix-4 stage over j runs per class in the lane
-// that owns it: thread (c, hh) ends with k1 = hh + 2s + 4r, s < 2, r < 4.  Pass 2 splits each
-// radix-32 column over n2 into its even and odd half (n2 = 2a + p: two threads, a 16-point
-// transform of which 8 outputs are kept, the factor W_32^(p k2) folded into the twiddle table),
-// whose partial results simply join the 64-term sum that pass 3 is anyway.
-constexpr int NT16 = 1024;
-
-template <int FMT>
-struct RawHalf;
-template <>
-struct RawHalf<THR_IN_U8> {
-    unsigned q[8];   // [2 i + jj] = samples 2c, 2c+1 of sub-sequence n1 = 4 i + 2 hh + jj
-    __device__ __forceinline__ void load(const void* __restrict__ blk, int c, int hh) {
-        const char* p = reinterpret_cast<const char*>(blk);
-        const unsigned off = unsigned(c) * 4u + unsigned(hh) * (2u * S1 * 2u);
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            q[k] = *reinterpret_cast<const unsigned*>(p + (off + unsigned((4 * (k >> 1) + (k & 1)) * (S1 * 2))));
-    }
-    static constexpr bool kBytes = true;
-    __device__ __forceinline__ unsigned word(int k) const { return q[k]; }
-    __device__ __forceinline__ void get(int k, cpx& a, cpx& b) const {   // raw bytes (affine map after the butterfly)
-        const unsigned w = q[k];
-        a = cpx{float(w & 0xffu), float((w >> 8) & 0xffu)};
-        b = cpx{float((w >> 16) & 0xffu), float(w >> 24)};
-    }
-};
-template <>
-struct RawHalf<THR_IN_C64> {
-    const f4* p;
-    __device__ __forceinline__ void load(const void* __restrict__ blk, int c, int hh) {
-        p = reinterpret_cast<const f4*>(blk) + c + hh * (2 * (S1 / 2));
-    }
-    static constexpr bool kBytes = false;
-    __device__ __forceinline__ void get(int k, cpx& a, cpx& b) const {
-        const f4 w = p[(4 * (k >> 1) + (k & 1)) * (S1 / 2)];
-        a = cpx{w.x, w.y};
-        b = cpx{w.z, w.w};
-    }
-};
-
-// vdst lanes 32..63 <-> src lanes 0..31
-__device__ __forceinline__ void swap_halves(cpx& keep, cpx& give) {
-    const auto rx = __builtin_amdgcn_permlane32_swap(__float_as_uint(keep.x), __float_as_uint(give.x), false, false);
-    const auto ry = __builtin_amdgcn_permlane32_swap(__float_as_uint(keep.y), __float_as_uint(give.y), false, false);
-    keep = cpx{__uint_as_float(rx[0]), __uint_as_float(ry[0])};
-    give = cpx{__uint_as_float(rx[1]), __uint_as_float(ry[1])};
-}
-
-// W_16^q = exp(-2 pi i q / 16), exactly rounded (compile-time q)
-template <int Q>
-__device__ __forceinline__ cpx w16() {
-    return cpx{cos32(2 * Q), -sin32(2 * Q)};
-}
-
-template <int FMT>
-__global__ __launch_bounds__(NT16) void k_carrier_pruned16(const void* __restrict__ samples,
-                                                           int n_blocks, DevCfg cfg,
-                                                           const cpx* __restrict__ tables,
-                                                           CarStats* __restrict__ stats) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cpx* lds = reinterpret_cast<cpx*>(smem_raw);
-    unsigned char* sc_red = reinterpret_cast<unsigned char*>(lds + OFF_S);
-    float* sc_bins = reinterpret_cast<float*>(sc_red + 2 * red_slot_bytes<NT16 / 64>());   // [128] |X[k]|^2
-    static_assert(2 * red_slot_bytes<NT16 / 64>() + PRUNE_BINS * 4 <= (LDS_CPX - OFF_S) * 8, "scratch");
-
-    {   // the 16 KiB table image: 1024 threads x one float4
-        const f4* src = reinterpret_cast<const f4*>(tables);
-        reinterpret_cast<f4*>(lds + OFF_C)[threadIdx.x] = src[threadIdx.x];
-    }
-    __syncthreads();
-    const int t0_ = opaque_tid();
-    const int hh0 = (t0_ >> 5) & 1;
-    // block-invariant pass-1 twiddles W_N^(k1 m) of the thread's 8 outputs k1 = hh + 2s + 4r and
-    // two columns (x 1/128 for u8: the butterflies run on the raw bytes), 32 VGPRs
-    cpx tw0[8], tw1[8];
-    {
-        const int c = (t0_ >> 6) * 32 + (t0_ & 31);
-        const int n2 = c >> 4, mp = 2 * (c & 15);
-        constexpr float scale = pass1_scale<RawHalf<FMT>>();
-#pragma unroll
-        for (int sr = 0; sr < 8; ++sr) {
-            const int k1 = hh0 + 2 * (sr >> 2) + 4 * (sr & 3);
-            const cpx a = lds[OFF_A + k1 * 32 + n2] * cpx{scale, scale};
-            const f4 bb = *reinterpret_cast<const f4*>(lds + OFF_B + k1 * 32 + mp);
-            cmul2(a, cpx{bb.x, bb.y}, a, cpx{bb.z, bb.w}, tw0[sr], tw1[sr]);
-        }
-    }
-    // first-stage twiddles of the lane's residues j = 2 hh + jj: W_16^(2j), W_16^j, W_16^(3j)
-    cpx wj2[2], wj1[2], wj3[2];
-    wj2[0] = hh0 ? w16<4>() : w16<0>();
-    wj1[0] = hh0 ? w16<2>() : w16<0>();
-    wj3[0] = hh0 ? w16<6>() : w16<0>();
-    wj2[1] = hh0 ? w16<6>() : w16<2>();
-    wj1[1] = hh0 ? w16<3>() : w16<1>();
-    wj3[1] = hh0 ? w16<9>() : w16<3>();
-    // u8: the quantiser's offset lands in output k1 = 0 alone (lane half A, s = 0, r = 0)
-    constexpr float of16 = RawHalf<FMT>::kBytes ? R1 * (-127.4f / 128.0f) : 0.f;
-    const cpx offv = hh0 ? cpx{0.f, 0.f} : cpx{of16, of16};
-    __syncthreads();
-    // pass-2 twiddles T[p][k2][n3] = W_32^(p k2) W_1024^(k2 n3) over the (now unused) A / Bt tables
-    cpx* tT = lds + OFF_A;
-    if (threadIdx.x < 512) {
-        const int i = threadIdx.x, p = i >> 8, k2 = (i >> 5) & 7, n3 = i & 31;
-        cpx v = lds[OFF_C + k2 * 32 + n3];
-        if (p) v = cmul(v, lds[OFF_C + 16 * 32 + 2 * k2]);   // W_1024^(32 k2)
-        asm volatile("" : "+v"(v));
-        __builtin_amdgcn_s_waitcnt(0);   // (reads of C done before anyone rewrites A / Bt: separate areas anyway)
-        tT[i] = v;
-    }
-    __syncthreads();
-    const size_t blk_bytes = cfg.blk_stride;
-    const int win_off = cfg.win_lo;   // window start in the pruned bin domain
-    int parity = 0;
-
-    RawHalf<FMT> cur;
-    {
-        const int t = opaque_tid();
-        if (int(blockIdx.x) < n_blocks)
-            cur.load(static_cast<const unsigned char*>(samples) + size_t(blockIdx.x) * blk_bytes,
-                     (t >> 6) * 32 + (t & 31), (t >> 5) & 1);
-    }
-    for (int b = blockIdx.x; b < n_blocks; b += gridDim.x) {
-        const int t = opaque_tid();
-        const int hh = (t >> 5) & 1, c = (t >> 6) * 32 + (t & 31);
-        // ---- pass 1, first radix-4 stage over i (n1 = 4i + j), for the lane's two residues j
-        cpx P[2][2][2], Q[2][2][2];   // [class slot s][jj][column]: P classes {0, 2}, Q classes {1, 3}
-        float sums[1] = {0.f};
-        {
-            unsigned s1 = 0, s2 = 0;
-            float e = 0.f;
-            static_for<2>([&](auto JJ) {
-                constexpr int jj = decltype(JJ)::value;
-                cpx x[4][2];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    cur.get(2 * i + jj, x[i][0], x[i][1]);
-                    if constexpr (RawHalf<FMT>::kBytes) {
-                        const unsigned w = cur.word(2 * i + jj);
-                        s2 = __builtin_amdgcn_udot4(w, w, s2, false);
-                        s1 = __builtin_amdgcn_udot4(w, 0x01010101u, s1, false);
-                    } else {
-                        e += cnorm(x[i][0]) + cnorm(x[i][1]);
-                    }
-                }
-#pragma unroll
-                for (int col = 0; col < 2; ++col) {
-                    const cpx a = x[0][col], bq = x[1][col], cq = x[2][col], d = x[3][col];
-                    const cpx u0 = a + cq, u1 = a - cq, u2 = bq + d, u3 = bq - d;
-                    P[0][jj][col] = u0 + u2;                                   // k1 = 0 mod 4
-                    P[1][jj][col] = cmul(u0 - u2, wj2[jj]);                    // k1 = 2 mod 4
-                    Q[0][jj][col] = cmul(add_irot<-1>(u1, u3), wj1[jj]);       // k1 = 1 mod 4
-                    Q[1][jj][col] = cmul(add_irot<+1>(u1, u3), wj3[jj]);       // k1 = 3 mod 4
-                }
-            });
-            if constexpr (RawHalf<FMT>::kBytes) {
-                constexpr double cc = double(127.4f);
-                sums[0] = float((double(s2) - 2.0 * cc * double(s1) + 32.0 * cc * cc) * (1.0 / 16384.0));
-            } else {
-                sums[0] = e;
-            }
-        }
-        // next block's samples, into the registers the first stage has just consumed
-        if (b + int(gridDim.x) < n_blocks)
-            cur.load(static_cast<const unsigned char*>(samples) + size_t(b + gridDim.x) * blk_bytes, c, hh);
-        // ---- hand the other lane half its classes (lanes l <-> l + 32)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                for (int col = 0; col < 2; ++col) swap_halves(P[s][jj][col], Q[s][jj][col]);
-        // ---- second radix-4 stage over j = 0..3 (P: j = 0, 1; Q: j = 2, 3), twiddle, store
-        {
-            f4* out = reinterpret_cast<f4*>(lds + hh * ROW + (c >> 4) * CHUNK + 2 * (c & 15));
-            static_for<2>([&](auto S) {
-                constexpr int s = decltype(S)::value;
-                cpx y[4][2];
-#pragma unroll
-                for (int col = 0; col < 2; ++col) {
-                    const cpx a = P[s][0][col], bq = P[s][1][col], cq = Q[s][0][col], d = Q[s][1][col];
-                    const cpx u0 = a + cq, u1 = a - cq, u2 = bq + d, u3 = bq - d;
-                    y[0][col] = u0 + u2;
-                    y[2][col] = u0 - u2;
-                    y[1][col] = add_irot<-1>(u1, u3);
-                    y[3][col] = add_irot<+1>(u1, u3);
-                }
-                static_for<4>([&](auto R) {
-                    constexpr int r = decltype(R)::value;
-                    cpx y0, y1;
-                    cmul2(y[r][0], tw0[s * 4 + r], y[r][1], tw1[s * 4 + r], y0, y1);
-                    if constexpr (s == 0 && r == 0 && RawHalf<FMT>::kBytes) {
-                        y0 += offv;
-                        y1 += offv;
-                    }
-                    out[(2 * s + 4 * r) * (ROW / 2)] = f4{y0.x, y0.y, y1.x, y1.y};
-                });
-            });
-        }
-        __syncthreads();
-        // ---- pass 2: row k1 = wave, column n3, half p of n2 = 2a + p; 8 of 16 outputs kept
-        {
-            const int k1 = t >> 6, p = (t >> 5) & 1, n3 = t & 31;
-            cpx* base = lds + k1 * ROW + p * CHUNK + n3;
-            cpx v[16];
-#pragma unroll
-            for (int a = 0; a < 16; ++a) v[a] = lds_b64(base + a * (2 * CHUNK));
-            dft_dif<16, -1>(v);
-            const cpx* tw = tT + p * 256 + n3;
-            static_for<PRUNE_K2 / 2>([&](auto K) {
-                constexpr int k2 = 2 * decltype(K)::value;
-                cpx y0, y1;
-                cmul2(v[brev(k2, 16)], lds_b64(tw + k2 * 32), v[brev(k2 + 1, 16)], lds_b64(tw + (k2 + 1) * 32), y0, y1);
-                base[k2 * (2 * CHUNK)] = y0;
-                base[(k2 + 1) * (2 * CHUNK)] = y1;
-            });
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- pass 3, output k3 = 0: chunk (k1 = wave, k2) = 64 terms, eight lanes x 8 terms
-        unsigned long long best = 0;
-        {
-            const int k1 = t >> 6, k2 = (t >> 3) & 7, part = t & 7;
-            const f4* src = reinterpret_cast<const f4*>(lds + k1 * ROW + (2 * k2 + (part >> 2)) * CHUNK + (part & 3) * 8);
-            f4 acc = src[0];
-#pragma unroll
-            for (int j = 1; j < 4; ++j) acc += src[j];
-            cpx x = cpx{quad_sum(acc.x + acc.z), quad_sum(acc.y + acc.w)};
-            // the other quad of the eight: row_half_mirror (lane i <-> 7 - i inside each 8)
-            x.x += __uint_as_float(dpp_u32<0x141, 0xf>(0u, __float_as_uint(x.x)));
-            x.y += __uint_as_float(dpp_u32<0x141, 0xf>(0u, __float_as_uint(x.y)));
-            const int k = k1 + 16 * k2;
-            const float pw = cnorm(x);
-            const unsigned wi = unsigned(k - win_off) & unsigned(N - 1);
-            if (part == 0) {
-                sc_bins[k] = pw;
-                if (wi < unsigned(cfg.win_count))
-                    best = ((unsigned long long)__float_as_uint(sqrtf(pw)) << 32) | (0xFFFFFFFFu - wi);
-            }
-        }
-        double tot[1];
-        block_reduce<1, NT16 / 64, true>(sums, tot, best, sc_red, parity);
         parity ^= 1;
         const int wi = int(0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu));
         int peak_idx = wi + cfg.win_lo;
@@ -852,11 +581,6 @@ hipError_t prepare_16k_carrier() {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return e;
     }
-    for (const void* f : {reinterpret_cast<const void*>(&k_carrier_pruned16<THR_IN_U8>),
-                          reinterpret_cast<const void*>(&k_carrier_pruned16<THR_IN_C64>)}) {
-        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-        if (e != hipSuccess) return e;
-    }
     for (int fmt = 0; fmt < 2; ++fmt)
         for (int st = 0; st < 2; ++st)
             for (int d = 0; d < 2; ++d) {
@@ -871,16 +595,6 @@ hipError_t prepare_16k_carrier() {
 hipError_t launch_carrier_16k(int fmt, const void* samples, int n_blocks, const DevCfg& cfg,
                               const float2* tables, const float2* twn, CarStats* stats,
                               float2* dump_fft, int grid, hipStream_t stream) {
-    // window (+ margin) already inside bins [0, 128): the 16-wave form; THR_CARRIER_WAVES=8 (dev A/B)
-    // keeps the 8-wave one
-    static const bool waves8 = getenv("THR_CARRIER_WAVES") != nullptr && atoi(getenv("THR_CARRIER_WAVES")) == 8;
-    if (cfg.car_prune == 1 && dump_fft == nullptr && !waves8) {
-        typedef void (*p16_fn)(const void*, int, DevCfg, const cpx*, CarStats*);
-        p16_fn fn = fmt == THR_IN_U8 ? &k_carrier_pruned16<THR_IN_U8> : &k_carrier_pruned16<THR_IN_C64>;
-        hipLaunchKernelGGL(fn, dim3(grid), dim3(NT16), LDS_BYTES, stream, samples, n_blocks, cfg,
-                           reinterpret_cast<const cpx*>(tables), stats);
-        return hipGetLastError();
-    }
     if (cfg.car_prune && dump_fft == nullptr) {
         typedef void (*pruned_fn)(const void*, int, DevCfg, const cpx*, const cpx*, CarStats*);
         const bool shifted = cfg.car_prune == 2;
