@@ -272,3 +272,54 @@ def test_multi_template_iteration_groups_per_block_with_txid():
     d3.only_detections = True
     assert [[(res.block, res.txid) for _, res in per_tx] for per_tx in d3] == [
         [(10, 0), (10, 2)], [(12, 0), (12, 1), (12, 2)], [(13, 2)]]
+
+
+def test_is_live_and_reader_readiness(tmp_path):
+    """A pipe is live (blocks arrive as they are captured), a file or an in-memory stream is not;
+    a batch reader says whether its next batch would have to be WAITED for -- the Detector reads
+    ahead of the batch it hands out only when it would not."""
+    import io
+    path = tmp_path / "x.bin"
+    path.write_bytes(bytes(4096))
+    with open(path, "rb") as f:
+        assert not block_data.is_live(f)
+        assert block_data.RawStream(f, 64, 16).ready() and not block_data.RawStream(f, 64, 16).live
+    assert not block_data.is_live(io.BytesIO(b"abc"))
+    rfd, wfd = os.pipe()
+    with os.fdopen(rfd, "rb") as r, os.fdopen(wfd, "wb", buffering=0) as w:
+        assert block_data.is_live(r)
+        assert block_data.card_reader(r).live and block_data.block_reader(r, 64, 16).live
+        cs = block_data.CardStream(r, 64)
+        assert cs.live and not cs.mapped and not cs.ready()       # nothing has arrived
+        raw = np.arange(128, dtype=np.uint8)
+        w.write(block_data.card_line(1.0, 0, raw).encode())
+        assert cs.ready()                                         # readable now
+        assert cs.next_batch(8)[1].tolist() == [0]
+        assert not cs.ready()                                     # consumed, pipe empty again
+
+
+def test_a_live_source_is_not_read_ahead_of():
+    """Reference behaviour on a pipe: block i's result is out before block i + 1 exists
+    (block_data.py:101-131 yields per line).  The batching Detector over a CardStream must neither
+    wait for a full batch nor submit the NEXT batch before handing out this one."""
+    recs = np.zeros(3, dtype=_native.RECORD_DTYPE)
+    recs["flags"] = 3
+    rng = np.random.default_rng(2)
+    lines, _ = _card_text(3, 64, rng)
+    rfd, wfd = os.pipe()
+    reader = os.fdopen(rfd, "rb")
+    w = os.fdopen(wfd, "wb", buffering=0)
+    d = _bare_detector(recs, (), batch_size=1024)    # (the batch reader below is the source)
+    d._card = block_data.CardStream(reader, 64)
+    eng = d._engine
+    eng.submit_card = lambda text, offs, idxs: eng.submit(None, idxs)
+    eng.inputs_consumed = lambda ticket: None
+    w.write(lines[0])
+    t0 = time.perf_counter()
+    first = next(d)                      # must not block on line 1 (nobody has written it yet)
+    assert time.perf_counter() - t0 < 0.5 and first[1].block == 0 and eng.open == 0
+    w.write(lines[1])
+    w.write(lines[2])
+    w.close()
+    assert [r.block for _, r in d] == [1, 2]
+    assert eng.open == 0
