@@ -55,3 +55,39 @@ def test_fresh_blocks_equal_the_oracle(name, nb, cthr, cwin, xthr, what):
     assert worst["offset"] <= 5e-6, worst
     assert worst["energy"] <= 2e-5 and worst["noise"] <= 2e-5 and worst["car_energy"] <= 2e-5, worst
     assert worst["car_off"] <= 2e-4, worst
+
+
+def test_an_eighth_of_the_baseline_workload_equals_the_oracle():
+    """131 072 fresh blocks of bench.py's on-device generator (BASELINE configs[1], 90 % carry a
+    burst) through the default pipeline -- pruned carrier kernel, fit, k_correlate with the
+    compile-time window rows -- against the oracle spread over the host's cores: every index and
+    verdict equal, floats inside the tolerances of this file.  (The whole 1 Mi-block workload,
+    tests/tools/soak_parity.py on the round-3 build: 0 mismatches in every field, worst energy
+    deviation 6.3e-7, sub-sample offset 4.6e-7, carrier offset 9.8e-5 bins, 60 s.)"""
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    total = 131072
+    dev = torch.device("cuda", 0)
+    tpl = synth.gold_template(10, 2).astype(np.float64)
+    win = onp.unique_window(N, H, len(tpl))
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(bench.SEED + 5)
+    truth = {}
+    data = bench.synth_on_device(torch, dev, gen, total, N, tpl, win, 0.9, truth=truth)
+    has = torch.cat(truth["has"]).cpu().numpy()
+    rec_d = torch.zeros((total, 64), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    eng = F.Engine(N, H, tpl, (0, 15, 0), (7, 110), (0, 15, 0), max_batch=32768)
+    for s in range(0, total, 32768):
+        eng.detect_device(data[s:s + 32768].data_ptr(), F.THR_IN_U8, 32768, rec_d[s:].data_ptr(), None)
+    eng.sync()
+    rec = rec_d.cpu().numpy().view(F.RECORD_DTYPE).reshape(-1)
+    blocks = data.cpu().numpy()
+    rows = soak_util.run_oracle(blocks, N, H, tpl, (0, 15, 0), (7, 110), (0, 15, 0), chunk=256)
+    mism, worst, ties = soak_util.compare(rec, rows, blocks, F.FLAG_CARRIER, F.FLAG_CORR, only=has)
+    assert sum(1 for r in rows if r is not None and r[5]) > 0.85 * total
+    assert mism == dict(bin=0, carrier=0, sample=0, det=0, index_error=0), (mism, worst, ties)
+    assert len(ties) <= 1, ties
+    assert worst["offset"] <= 5e-6 and worst["energy"] <= 2e-5 and worst["noise"] <= 2e-5, worst
+    assert worst["car_off"] <= 2e-4 and worst["car_energy"] <= 2e-5, worst
