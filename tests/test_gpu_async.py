@@ -89,6 +89,15 @@ def test_detector_iteration_rides_on_the_tickets(case, tmp_path):
     assert text.decode().split("\n")[:-1] == [r.serialize() for d, r in
                                                Detector(st, rxid=4, batch_size=96).detect_batch(
                                                    [(10.0 + i, i, blocks[i]) for i in range(96)]) if d]
+    # a direct detect() between two next() calls (a batch is in flight then) still works
+    with open(path, "rb") as f:
+        det = Detector(st, block_data.CardStream(f, N), batch_size=16)
+        first = next(det)
+        assert det._in_flight is not None
+        d, r = det.detect(10.0 + 40, 40, blocks[40])
+        assert (d, r.block, r.soa) == (whole[40][0], 40, whole[40][1].soa)
+        rest = list(det)
+        assert [(x[0], x[1].block) for x in [first] + rest] == [(x[0], x[1].block) for x in whole]
     # a pipe-like source (no mmap): same answer through the refilled buffer
     got2 = list(Detector(st, block_data.CardStream(io.BytesIO(path.read_bytes()), N, chunk_bytes=1 << 20),
                          batch_size=16))

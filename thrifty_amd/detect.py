@@ -181,13 +181,24 @@ class Detector(object):
                                  Car(cbin[i], coff[i], cen[i], cno[i]), cor, self.rxid)))
         return out
 
+    def _run(self, arr, idx):
+        """Records [B, n_templates] of the blocks in `arr`, now.  While the iterator has a batch
+        in flight the synchronous entry point would refuse to run (thr_detect waits for open
+        tickets to be collected), so a direct detect() between two next() calls rides the
+        ticket interface too."""
+        if self._in_flight is None or self.yield_data:
+            return self._engine.detect(arr, idx)
+        step = self.batch_size
+        return np.concatenate([self._engine.collect(self._engine.submit(arr[s:s + step], idx[s:s + step]))
+                               for s in range(0, len(arr), step)])
+
     def detect_batch(self, items):
         """[(timestamp, block_idx, block), ...] -> [(detected, DetectionResult), ...]."""
         if not items:
             return []
         arr = self._stack([it[2] for it in items])
         idx = np.array([int(it[1]) for it in items], dtype=np.int64)
-        recs = self._engine.detect(arr, idx)[:, 0]
+        recs = self._run(arr, idx)[:, 0]
         out = self._results([it[0] for it in items], idx, recs)
         if out and isinstance(out[-1], _Deferred):
             raise out[-1].exc
@@ -430,7 +441,7 @@ class MultiTemplateDetector(Detector):
             return []
         arr = self._stack([it[2] for it in items])
         idx = np.array([int(it[1]) for it in items], dtype=np.int64)
-        stamps, idxs, recs = self._flat([it[0] for it in items], idx, self._engine.detect(arr, idx))
+        stamps, idxs, recs = self._flat([it[0] for it in items], idx, self._run(arr, idx))
         flat = self._results(stamps, idxs, recs)
         if flat and isinstance(flat[-1], _Deferred):
             raise flat[-1].exc
