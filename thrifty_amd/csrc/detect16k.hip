@@ -150,9 +150,7 @@ __global__ __launch_bounds__(NT) void k_correlate(
         THR_STAMP(1);
         // (the previous block's pass-C LDS reads all precede its reduction barrier)
         // (multi-template: 64 more live VGPRs for the spectrum -- the L2-table path would spill)
-        // pass 1 always takes its twiddles from the L2 table; pass B only with one template (with
-        // several, the spectrum stays live across the template loop and the table form spills)
-        constexpr bool GTW = !MULTI;
+        // passes 1 and B take their twiddles from the L2 table
         const cpx* gtw = static_cast<const cpx*>(cfg.gtw);
         thread_phasor(sc_ph, t, p);   // (table of THIS block: written one iteration ago, two barriers back)
         fwd_pass1<true, true>(lds, cur, sp->rpow, p[0], p[1], nullptr, gtw);
@@ -266,7 +264,10 @@ __global__ __launch_bounds__(NT) void k_correlate(
             __builtin_amdgcn_sched_barrier(0);
             THR_STAMP(7);
             THR_ABLATE_AT(14, { __syncthreads(); continue; });
-            inv_passB<GTW>(lds, gtw);
+            // (several templates: the table twiddles in two halves after the butterfly -- the spectrum
+            // stays live beside this pass, and all 32 requested ahead of it spill; -3.3 % against the
+            // LDS-product form this kernel used before)
+            inv_passB<true, MULTI>(lds, gtw);
             THR_STAMP(8);
             THR_LOOP_BARRIER();
             THR_STAMP(9);

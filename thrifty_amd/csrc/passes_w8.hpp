@@ -324,7 +324,10 @@ __device__ __forceinline__ void inv_passA(cpx* lds, cpx* z) {
 // tw_row >= 0: row of the gtw table to use instead of k1 (block_len R1 * 1024 < 16384: LDS row
 // r holds sub-sequence k1 = r mod R1 of one of the 16 / R1 blocks, whose twiddle
 // W_N^(k1 q) = W_16384^(k1 (16 / R1) q) is table row k1 * 16 / R1 -- detect_small.hip)
-template <bool GTW = false>
+// GTW_LATE (with GTW): the table twiddles are requested in two halves AFTER the butterfly -- 32
+// instead of 64 more live VGPRs, for kernels that keep the spectrum live beside this pass (several
+// templates); the second half's L2 latency is exposed once per call.
+template <bool GTW = false, bool GTW_LATE = false>
 __device__ __forceinline__ void inv_passB(cpx* lds, const cpx* __restrict__ gtw = nullptr,
                                           int tw_row = -1) {
     const int t = opaque_tid();
@@ -333,6 +336,29 @@ __device__ __forceinline__ void inv_passB(cpx* lds, const cpx* __restrict__ gtw 
     cpx v[R2];
 #pragma unroll
     for (int k2 = 0; k2 < R2; ++k2) v[k2] = lds_b64(base + k2 * CHUNK);
+    if constexpr (GTW && GTW_LATE) {
+        const cpx* tw = gtw + (tw_row >= 0 ? tw_row : k1) * 1024 + n3;
+        cpx w[R2 / 2];
+#pragma unroll
+        for (int n2 = 0; n2 < R2 / 2; ++n2) w[n2] = tw[n2 * 32];
+        dft_dif<R2, +1>(v);
+        static_for<2>([&](auto H) {
+            constexpr int h = decltype(H)::value;
+            static_for<R2 / 4>([&](auto K) {
+                constexpr int n2 = h * (R2 / 2) + 2 * decltype(K)::value;
+                cpx y0, y1;
+                cmulc2(v[brev(n2, R2)], w[n2 - h * (R2 / 2)], v[brev(n2 + 1, R2)], w[n2 + 1 - h * (R2 / 2)], y0, y1);
+                base[n2 * CHUNK] = y0;
+                base[(n2 + 1) * CHUNK] = y1;
+            });
+            if constexpr (h == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int n2 = 0; n2 < R2 / 2; ++n2) w[n2] = tw[(n2 + R2 / 2) * 32];
+            }
+        });
+        return;
+    }
     if constexpr (GTW) {
         // twiddles W_N^(k1 (32 n2 + n3)) straight from the L2-resident table: issued before the
         // butterfly, consumed after it
