@@ -30,7 +30,9 @@ extern "C" {
 /* 4: + thr_frame_card (addition only) */
 /* 5: + thr_submit / thr_submit_card / thr_submit_stream / thr_collect / thr_inputs_consumed / thr_poll (asynchronous host
  *    boundary), thr_set_stream_default, thr_format_toad (additions only) */
-#define THR_ABI_VERSION 5
+/* 6: + thr_create_ex (explicit variant and kernel-path selection), thr_plan_sections (additions only).
+ *    No environment variable changes what a handle computes or how it schedules any more. */
+#define THR_ABI_VERSION 6
 
 /* status codes */
 #define THR_OK 0
@@ -135,6 +137,47 @@ int thr_create_preshift(const thr_settings* settings, int num_shifts, thr_handle
  * reference output.
  */
 int thr_create_fastdet(const thr_settings* settings, thr_handle** out);
+/*
+ * The three constructors above in one call, plus an explicit choice of kernel path.  `variant`:
+ * THR_VARIANT_DEFAULT (thr_create), THR_VARIANT_PRESHIFT (thr_create_preshift; variant_arg =
+ * num_shifts) or THR_VARIANT_FASTDET (thr_create_fastdet).  `path`:
+ *   THR_PATH_AUTO         what the other constructors use: the fastest kernels for the block
+ *                         length (LDS-resident for 1024 ... 65536, multi-pass otherwise);
+ *   THR_PATH_MULTIPASS    the generic multi-pass pipeline (Stockham passes through HBM) whatever
+ *                         the block length -- an independent implementation of the same arithmetic,
+ *                         kept for cross-checking the fused kernels on identical input;
+ *   THR_PATH_UNSECTIONED  block_len 32768 / 65536 only: the correlate stage as ONE block_len-point
+ *                         transform pair (decimated sub-transforms, detect_long.hip) instead of
+ *                         overlap-save sections of 16384 points (detect_seg.hip).  AUTO falls back
+ *                         to it by itself for templates longer than 9361 samples (at 65536) and for
+ *                         thr_debug_stage dumps.
+ * All paths implement the same reference semantics and agree to rounding (tests/test_gpu_*.py).
+ */
+#define THR_VARIANT_DEFAULT 0
+#define THR_VARIANT_PRESHIFT 1
+#define THR_VARIANT_FASTDET 2
+#define THR_PATH_AUTO 0
+#define THR_PATH_MULTIPASS 1
+#define THR_PATH_UNSECTIONED 2
+int thr_create_ex(const thr_settings* settings, int variant, int variant_arg, int path, thr_handle** out);
+/*
+ * The overlap-save plan THR_PATH_AUTO uses for the correlate stage of a long block (host-only, no
+ * device involved; exported so that the plan itself can be checked against the reference's
+ * `despread` / `get_peak`, soa_estimator.py:97-102,137-143, on a CPU).  Section g transforms samples
+ * [start[g], start[g] + 16384) of the frequency-shifted block against the template zero-padded to
+ * 16384; lag j of that circular correlation, 0 <= j <= 16384 - template_len, is lag start[g] + j of
+ * the block's.  In block coordinates section g searches the window lags [win_lo[g], win_hi[g]) and
+ * sums (stddev threshold term) the lags [sum_lo[g], sum_hi[g]): the window ranges tile the unique
+ * window of soa_estimator.calculate_window (soa_estimator.py:20-39) and the sum ranges tile
+ * [0, corr_len), each exactly once, ascending in g, and every searched lag has both neighbours
+ * inside its section.  Arrays hold THR_MAX_SECTIONS ints.  *n_sections = 0 when the block is not
+ * sectioned (block_len <= 16384, or more than THR_MAX_SECTIONS would be needed: templates longer
+ * than 9361 samples at block_len 65536).  Geometry only: whether an engine handle
+ * uses the plan also depends on its block length and path.
+ */
+#define THR_MAX_SECTIONS 8
+int thr_plan_sections(int block_len, int history_len, int template_len, int* n_sections, int* start,
+                      int* win_lo, int* win_hi, int* sum_lo, int* sum_hi);
 /* Replaces fastcard_free() (fastcard.c:119-146). */
 void thr_destroy(thr_handle* h);
 

@@ -1,5 +1,5 @@
 """Dev aid: print the per-wave cycle timeline of one k_correlate block (needs a library
-built with THR_EXTRA_CFLAGS="-DTHR_TIMELINE -DTHR_DEV_MINIMAL")."""
+built with THR_EXTRA_CFLAGS="-DTHR_DEV -DTHR_DEV_MINIMAL")."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

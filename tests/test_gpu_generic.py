@@ -29,12 +29,10 @@ def test_generic_lengths_match_reference_golden(golden, name):
 
 
 @pytest.mark.parametrize("name", ["c2", "c2_stddev", "c2_negwin"])
-def test_generic_path_agrees_with_fast_path(golden, name, monkeypatch):
+def test_generic_path_agrees_with_fast_path(golden, name):
     g = golden(name)
     fast = engine_for(g).detect(g["blocks"], g["block_idx"])[:, 0]
-    monkeypatch.setenv("THR_FORCE_GENERIC", "1")
-    slow_eng = engine_for(g)
-    monkeypatch.delenv("THR_FORCE_GENERIC")
+    slow_eng = engine_for(g, path="multipass")
     slow = slow_eng.detect(g["blocks"], g["block_idx"])[:, 0]
     check_against_golden(slow, g)
     assert np.array_equal(fast["carrier_bin"], slow["carrier_bin"])
@@ -53,12 +51,10 @@ def test_small_card_stream_to_toad(golden):
     assert_toad_close(lines, g["card_toad"])
 
 
-def test_generic_multi_template_and_dumps(golden, monkeypatch):
+def test_generic_multi_template_and_dumps(golden):
     gs = [golden("c5_tx%d" % i) for i in range(4)]
     tpls = np.stack([g["template"] for g in gs]).astype(np.float64)
-    monkeypatch.setenv("THR_FORCE_GENERIC", "1")
-    eng = engine_for(gs[0], templates=tpls)
-    monkeypatch.delenv("THR_FORCE_GENERIC")
+    eng = engine_for(gs[0], templates=tpls, path="multipass")
     rec = eng.detect(gs[0]["blocks"], gs[0]["block_idx"])
     for t, g in enumerate(gs):
         check_against_golden(rec[:, t], g)

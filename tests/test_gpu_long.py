@@ -1,6 +1,9 @@
-"""GPU parity of the long-block path (csrc/detect_long.hip): block_len = 4 x 16384
-(BASELINE config C3) and 2 x 16384, against the reference goldens, the oracle, and
-the generic multi-pass pipeline."""
+"""GPU parity of the long-block paths: block_len = 4 x 16384 (BASELINE config C3) and 2 x 16384,
+against the reference goldens, the oracle, and each other -- "auto" = carrier stage of
+csrc/detect_long.hip + the correlate stage as overlap-save sections of the 16384-point kernel
+(csrc/detect_seg.hip), "unsectioned" = the decimated long transform pair of detect_long.hip (what
+"auto" itself uses for stage dumps and for templates too long to section), "multipass" = the
+generic pipeline."""
 import numpy as np
 import pytest
 
@@ -13,17 +16,23 @@ from test_gpu_parity import check_against_golden, engine_for
 pytestmark = pytest.mark.gpu
 
 
-def test_c3_long_path_and_generic_path_both_match_golden(golden, monkeypatch):
+PATHS = ["auto", "unsectioned"]
+
+
+def test_c3_every_path_matches_the_golden(golden):
     g = golden("c3")
-    rec_long = engine_for(g, max_batch=8).detect(g["blocks"], g["block_idx"])[:, 0]
-    check_against_golden(rec_long, g)
-    monkeypatch.setenv("THR_FORCE_GENERIC", "1")
-    eng_gen = engine_for(g, max_batch=8)
-    monkeypatch.delenv("THR_FORCE_GENERIC")
-    rec_gen = eng_gen.detect(g["blocks"], g["block_idx"])[:, 0]
-    check_against_golden(rec_gen, g)
-    assert np.array_equal(rec_long["corr_sample"], rec_gen["corr_sample"])
-    np.testing.assert_allclose(rec_long["corr_energy"], rec_gen["corr_energy"], rtol=2e-5)
+    recs = {}
+    for path in ("auto", "unsectioned", "multipass"):
+        recs[path] = engine_for(g, max_batch=8, path=path).detect(g["blocks"], g["block_idx"])[:, 0]
+        check_against_golden(recs[path], g)
+    for path in ("unsectioned", "multipass"):
+        assert np.array_equal(recs["auto"]["corr_sample"], recs[path]["corr_sample"])
+        assert np.array_equal(recs["auto"]["flags"], recs[path]["flags"])
+        np.testing.assert_allclose(recs["auto"]["corr_energy"], recs[path]["corr_energy"], rtol=2e-5)
+        np.testing.assert_allclose(recs["auto"]["corr_offset"], recs[path]["corr_offset"], atol=5e-6)
+    # (the carrier stage is shared by "auto" and "unsectioned": identical carrier halves)
+    for c in ("carrier_bin", "carrier_offset", "carrier_energy", "carrier_noise"):
+        assert np.array_equal(recs["auto"][c], recs["unsectioned"][c])
 
 
 def test_c3_stage_dumps(golden):
@@ -41,19 +50,26 @@ def test_c3_stage_dumps(golden):
         assert np.linalg.norm(corr[i][:len(co)] - co) / np.linalg.norm(co) < 5e-6
 
 
-@pytest.mark.parametrize("n,bits,sps,cwin,cthr", [
-    (32768, 11, 1.0, (7, 110), (0, 15, 0)),          # R0 = 2
-    (65536, 11, 2.0, (-300, -20), (0, 15, 0)),       # negative-bin window
-    (65536, 11, 2.0, (0, -1), (100.0, 5.0, 2.0)),    # full window + stddev terms
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("n,bits,sps,cwin,cthr,h", [
+    (32768, 11, 1.0, (7, 110), (0, 15, 0), 4096),          # R0 = 2; three sections
+    (32768, 11, 2.0, (7, 110), (0, 15, 0), 4200),          # ... unequal section windows
+    (65536, 11, 2.0, (-300, -20), (0, 15, 0), 4096),       # negative-bin window
+    (65536, 11, 2.0, (0, -1), (100.0, 5.0, 2.0), 4096),    # full window + stddev terms
+    (65536, 11, 2.0, (0, -1), (100.0, 5.0, 2.0), 6001),    # ... sections with ragged windows
+    (65536, 10, 1.0, (7, 110), (0, 15, 0), 1500),          # short template: sections nearly disjoint
+    (65536, 11, 4.5, (7, 110), (0, 15, 0), 9300),          # 9211-sample template: eight sections
+    (65536, 11, 4.6, (7, 110), (0, 15, 0), 9500),          # 9416 samples: too long to section ("auto" falls back)
 ])
-def test_long_blocks_match_oracle(n, bits, sps, cwin, cthr):
-    h = 4096
+def test_long_blocks_match_oracle(n, bits, sps, cwin, cthr, h, path):
     tpl = synth.gold_template(bits, 3, sps)
+    if path == "auto":
+        assert bool(F.plan_sections(n, h, len(tpl))) == (len(tpl) <= 9361)
     win = onp.unique_window(n, h, len(tpl))
     rng = np.random.default_rng(n + len(tpl))
     lo, hi = (-250.0, -30.0) if cwin[0] < 0 and cwin[1] < 0 else (10.0, 100.0)
     blocks, _ = synth.synth_blocks(rng, 5, n, tpl, win, signal_frac=0.8, carrier_bins=(lo, hi))
-    eng = F.Engine(n, h, tpl, cthr, cwin, (50.0, 8.0, 3.0) if cthr[2] else (0, 15, 0), max_batch=3)
+    eng = F.Engine(n, h, tpl, cthr, cwin, (50.0, 8.0, 3.0) if cthr[2] else (0, 15, 0), max_batch=3, path=path)
     orc = onp.OracleDetector(n, h, tpl, cthr, cwin, (50.0, 8.0, 3.0) if cthr[2] else (0, 15, 0))
     idx = np.arange(5) * 3 + 1
     rec = eng.detect(blocks, idx)[:, 0]
@@ -73,14 +89,15 @@ def test_long_blocks_match_oracle(n, bits, sps, cwin, cthr):
             np.testing.assert_allclose(r["carrier_offset"], res.carrier.offset, atol=1e-3)
 
 
-def test_long_multi_template_and_c64_input():
+@pytest.mark.parametrize("path", PATHS)
+def test_long_multi_template_and_c64_input(path):
     n, h = 65536, 4096
     tpls = np.stack([synth.gold_template(11, i, 2.0) for i in (2, 3, 4)]).astype(np.float64)
     win = onp.unique_window(n, h, tpls.shape[1])
     rng = np.random.default_rng(77)
     parts = [synth.synth_blocks(rng, 2, n, t, win)[0] for t in tpls]
     blocks = np.concatenate(parts)
-    eng = F.Engine(n, h, tpls, (0, 15, 0), (7, 110), (0, 15, 0), max_batch=4)
+    eng = F.Engine(n, h, tpls, (0, 15, 0), (7, 110), (0, 15, 0), max_batch=4, path=path)
     rec = eng.detect(blocks)
     rec_c64 = eng.detect(np.stack([block_data.raw_to_complex(b) for b in blocks]))
     for t in range(3):
@@ -94,14 +111,16 @@ def test_long_multi_template_and_c64_input():
                 np.testing.assert_allclose(r["corr_offset"], res.corr.offset, atol=1e-4)
 
 
+@pytest.mark.parametrize("path", PATHS)
 @pytest.mark.parametrize("n,n_tpl,fmt_c64,total", [
     (65536, 1, False, 900),     # fused kernel, several blocks per workgroup (combine_own, PeakTail carry-over)
     (65536, 1, True, 600),      # ... complex64 input
     (32768, 1, False, 1200),    # R0 = 2
     (65536, 3, False, 600),     # several templates: rows combined from memory after the template loop
 ])
-def test_large_batches_equal_small_batches(n, n_tpl, fmt_c64, total):
-    """One sub-batch with more carrier-positive blocks than workgroups takes the fused kernel with
+def test_large_batches_equal_small_batches(n, n_tpl, fmt_c64, total, path):
+    """("auto": thousands of (block, section) items walked by 256 workgroups through the dynamic
+    cursor against batches of three blocks -- one item per workgroup; "unsectioned":)  One sub-batch with more carrier-positive blocks than workgroups takes the fused kernel with
     several blocks per workgroup (next-block prefetch, the peak written one barrier into the next
     block, the workgroup's last block after the loop); batches of <= 3 blocks take one block per
     workgroup or the two-kernel form.  Same arithmetic, so the records must be byte-identical --
@@ -118,8 +137,8 @@ def test_large_batches_equal_small_batches(n, n_tpl, fmt_c64, total):
     inp = np.stack([block_data.raw_to_complex(b) for b in base])[order] if fmt_c64 else blocks
     idx = np.arange(total) * 2 + 5
     tp = tpls if n_tpl > 1 else tpls[0]
-    big = F.Engine(n, h, tp, (0, 15, 0), (7, 110), (0, 15, 0), max_batch=total).detect(inp, idx)
-    small = F.Engine(n, h, tp, (0, 15, 0), (7, 110), (0, 15, 0), max_batch=3).detect(inp, idx)
+    big = F.Engine(n, h, tp, (0, 15, 0), (7, 110), (0, 15, 0), max_batch=total, path=path).detect(inp, idx)
+    small = F.Engine(n, h, tp, (0, 15, 0), (7, 110), (0, 15, 0), max_batch=3, path=path).detect(inp, idx)
     assert int(((big["flags"][:, 0] & F.FLAG_CARRIER) != 0).sum()) > 300    # (more than 256 workgroups' worth)
     assert big.tobytes() == small.tobytes()
     # and a spot check against the oracle on the distinct blocks

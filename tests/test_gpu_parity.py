@@ -21,11 +21,11 @@ TOL_COFF = 2e-4     # absolute, carrier sub-bin offset (same solver as the refer
                     # lmdif -- fed float32 magnitudes that differ in the last digit)
 
 
-def engine_for(g, templates=None, max_batch=64):
+def engine_for(g, templates=None, max_batch=64, path="auto"):
     tpl = g["template"] if templates is None else templates
     return F.Engine(int(g["block_len"]), int(g["history_len"]), tpl,
                     tuple(g["carrier_thresh"]), tuple(int(v) for v in g["carrier_window"]),
-                    tuple(g["corr_thresh"]), max_batch=max_batch)
+                    tuple(g["corr_thresh"]), max_batch=max_batch, path=path)
 
 
 def check_against_golden(rec, g):

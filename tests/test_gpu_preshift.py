@@ -61,16 +61,14 @@ def test_matches_reference_goldens(golden, name):
             assert int(rec[i]["reserved"] & np.uint64(0xFFFFFFFF)) == int(np.round((frac + 0.5) * (int(g["num"]) - 1)))
 
 
-def test_c64_input_and_generic_pipeline_agree(golden, monkeypatch):
+def test_c64_input_and_generic_pipeline_agree(golden):
     g = golden("preshift_c2")
     eng = engine_for(g, max_batch=8)
     rec_u8 = eng.detect(g["blocks"], g["block_idx"])[:, 0]
     c64 = np.stack([block_data.raw_to_complex(b) for b in g["blocks"]])
     rec_c = eng.detect(c64, g["block_idx"])[:, 0]
     assert rec_u8.tobytes() == rec_c.tobytes()
-    monkeypatch.setenv("THR_FORCE_GENERIC", "1")
-    eng_gen = engine_for(g, max_batch=8)
-    monkeypatch.delenv("THR_FORCE_GENERIC")
+    eng_gen = engine_for(g, max_batch=8, path="multipass")
     rec_gen = eng_gen.detect(g["blocks"], g["block_idx"])[:, 0]
     check_records(rec_gen, g)
     assert np.array_equal(rec_gen["corr_sample"], rec_u8["corr_sample"])

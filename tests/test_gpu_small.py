@@ -65,13 +65,11 @@ def test_fresh_short_blocks_equal_the_oracle(n, nb):
 
 
 @pytest.mark.parametrize("n", [1024, 2048, 4096, 8192])
-def test_lds_path_agrees_with_the_multi_pass_pipeline(n, monkeypatch):
+def test_lds_path_agrees_with_the_multi_pass_pipeline(n):
     h, tpl, cwin, blocks, _ = make_case(n, 90, seed=77 + n)
     thr = (0, 15, 0)
     fast = F.Engine(n, h, tpl, thr, cwin, thr, max_batch=32).detect(blocks)[:, 0]
-    monkeypatch.setenv("THR_FORCE_GENERIC", "1")
-    slow_eng = F.Engine(n, h, tpl, thr, cwin, thr, max_batch=32)
-    monkeypatch.delenv("THR_FORCE_GENERIC")
+    slow_eng = F.Engine(n, h, tpl, thr, cwin, thr, max_batch=32, path="multipass")
     slow = slow_eng.detect(blocks)[:, 0]
     assert np.array_equal(fast["carrier_bin"], slow["carrier_bin"])
     assert np.array_equal(fast["corr_sample"], slow["corr_sample"])
@@ -138,7 +136,7 @@ def test_stage_dumps_of_the_lds_kernels_equal_the_oracle(n):
 
 
 @pytest.mark.parametrize("n,nb", [(1024, 150), (2048, 120), (4096, 100), (8192, 60)])
-def test_stddev_terms_run_in_the_lds_kernels_and_equal_the_oracle(n, nb, monkeypatch):
+def test_stddev_terms_run_in_the_lds_kernels_and_equal_the_oracle(n, nb):
     """Thresholds with a stddev term (carrier_detect.py:110-115, soa_estimator.py:127-134): the
     short-block kernels carry the sums themselves now (no detour through the multi-pass
     pipeline); records against the oracle on fresh blocks, and against the multi-pass pipeline."""
@@ -152,9 +150,7 @@ def test_stddev_terms_run_in_the_lds_kernels_and_equal_the_oracle(n, nb, monkeyp
     assert mism == dict(bin=0, carrier=0, sample=0, det=0, index_error=0), (mism, worst, ties)
     assert len(ties) <= 1
     assert worst["offset"] <= 5e-6 and worst["energy"] <= 2e-5 and worst["noise"] <= 2e-5, worst
-    monkeypatch.setenv("THR_FORCE_GENERIC", "1")
-    slow_eng = F.Engine(n, h, tpl, cthr, (0, -1), xthr, max_batch=64)
-    monkeypatch.delenv("THR_FORCE_GENERIC")
+    slow_eng = F.Engine(n, h, tpl, cthr, (0, -1), xthr, max_batch=64, path="multipass")
     slow = slow_eng.detect(blocks)[:, 0]
     assert np.array_equal(rec["flags"], slow["flags"]) and np.array_equal(rec["corr_sample"], slow["corr_sample"])
     # a verdict that flips with the stddev coefficient proves the term is live in these kernels

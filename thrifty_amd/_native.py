@@ -20,16 +20,18 @@ FLAG_CORR = 2
 FLAG_INDEX_ERROR = 4
 N_KERNEL_SLOTS = 5
 
-ABI_VERSION = 5     # THR_ABI_VERSION of include/thrifty_hip.h
+ABI_VERSION = 6     # THR_ABI_VERSION of include/thrifty_hip.h
 
 EXPORTS = [
     "thr_abi_version", "thr_last_error", "thr_create", "thr_destroy", "thr_detect",
-    "thr_create_preshift", "thr_create_fastdet", "thr_detect_card", "thr_detect_stream", "thr_detect_stream_device", "thr_detect_device", "thr_sync", "thr_set_stream", "thr_compact_device",
+    "thr_create_preshift", "thr_create_fastdet", "thr_create_ex", "thr_plan_sections", "thr_detect_card", "thr_detect_stream", "thr_detect_stream_device", "thr_detect_device", "thr_sync", "thr_set_stream", "thr_compact_device",
     "thr_profile_enable", "thr_profile_read", "thr_kernel_name", "thr_debug_fft",
     "thr_debug_stage", "thr_identify", "thr_frame_card",
     "thr_submit", "thr_submit_card", "thr_submit_stream", "thr_collect", "thr_inputs_consumed", "thr_poll",
     "thr_set_stream_default", "thr_format_toad",
 ]
+VARIANT_DEFAULT, VARIANT_PRESHIFT, VARIANT_FASTDET = 0, 1, 2      # THR_VARIANT_*
+PATHS = {"auto": 0, "multipass": 1, "unsectioned": 2}             # THR_PATH_*
 MAX_IN_FLIGHT = 3       # THR_MAX_IN_FLIGHT
 TOAD_LINE_MAX = 384     # THR_TOAD_LINE_MAX
 
@@ -112,6 +114,9 @@ def load_library():
     lib.thr_create.argtypes = [C.POINTER(ThrSettings), C.POINTER(vp)]
     lib.thr_create_preshift.argtypes = [C.POINTER(ThrSettings), C.c_int, C.POINTER(vp)]
     lib.thr_create_fastdet.argtypes = [C.POINTER(ThrSettings), C.POINTER(vp)]
+    ip = C.POINTER(C.c_int)
+    lib.thr_plan_sections.argtypes = [C.c_int, C.c_int, C.c_int, ip] + [C.c_int * 8] * 5
+    lib.thr_create_ex.argtypes = [C.POINTER(ThrSettings), C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     lib.thr_destroy.argtypes = [vp]
     lib.thr_destroy.restype = None
     lib.thr_detect.argtypes = [vp, vp, C.c_int, vp, C.c_size_t, vp]
@@ -226,14 +231,30 @@ def identify(rxid, block, timestamp, carrier_bin, carrier_offset, energy, freq_r
     return txid, keep.astype(bool), order[:n_kept.value]
 
 
+def plan_sections(block_len, history_len, template_len):
+    """thr_plan_sections: the overlap-save plan of a long block's correlate stage (host-only).
+    Returns a list of dicts (start, win_lo, win_hi, sum_lo, sum_hi), block coordinates; [] when the
+    geometry is not sectioned."""
+    lib = load_library()
+    n = C.c_int()
+    arrs = [(C.c_int * 8)() for _ in range(5)]
+    _check(lib, lib.thr_plan_sections(int(block_len), int(history_len), int(template_len), C.byref(n), *arrs))
+    keys = ("start", "win_lo", "win_hi", "sum_lo", "sum_hi")
+    return [dict((k, int(a[g])) for k, a in zip(keys, arrs)) for g in range(n.value)]
+
+
 class Engine(object):
     """One detector handle == one (device, stream).  Not thread-safe per handle."""
 
     def __init__(self, block_len, history_len, templates, carrier_thresh, carrier_window,
                  corr_thresh, carrier_len=0, device_id=0, max_batch=256, preshift_num=0,
-                 fastdet=False):
+                 fastdet=False, path="auto"):
         """preshift_num > 0 selects the PreshiftDetector variant (thr_create_preshift);
-        fastdet=True the fastdet-compatible one (thr_create_fastdet, power-domain thresholds)."""
+        fastdet=True the fastdet-compatible one (thr_create_fastdet, power-domain thresholds).
+        path: "auto" (the fastest kernels for the block length), "multipass" (the generic
+        multi-pass pipeline whatever the length) or "unsectioned" (block_len 32768 / 65536: one
+        long transform pair instead of overlap-save sections) -- thr_create_ex's THR_PATH_*; the
+        non-default paths are independent implementations kept for cross-checks."""
         lib = load_library()
         tpl = np.ascontiguousarray(np.atleast_2d(np.asarray(templates, dtype=np.float64)))
         if tpl.ndim != 2:
@@ -250,12 +271,9 @@ class Engine(object):
             st.corr_thresh[i] = float(corr_thresh[i])
         st.device_id, st.max_batch = int(device_id), int(max_batch)
         handle = C.c_void_p()
-        if fastdet:
-            _check(lib, lib.thr_create_fastdet(C.byref(st), C.byref(handle)))
-        elif preshift_num:
-            _check(lib, lib.thr_create_preshift(C.byref(st), int(preshift_num), C.byref(handle)))
-        else:
-            _check(lib, lib.thr_create(C.byref(st), C.byref(handle)))
+        variant = VARIANT_FASTDET if fastdet else VARIANT_PRESHIFT if preshift_num else VARIANT_DEFAULT
+        _check(lib, lib.thr_create_ex(C.byref(st), variant, int(preshift_num), PATHS[path], C.byref(handle)))
+        self.path = path
         self.preshift_num = int(preshift_num)
         self._lib, self._h = lib, handle
         self.block_len, self.n_templates = int(block_len), int(tpl.shape[0])

@@ -106,6 +106,10 @@ struct thr_handle {
     float* d_win_pow = nullptr;     // long: [long_batch][win_w] |X|^2 of the window bins (+-3)
     float* d_partial = nullptr;     // long: [long_batch][R0][2] partial sums of FFT#1
     float2* d_dsub = nullptr;       // long: [long_chunk][T][R0][16384] sub-transform outputs
+    bool seg = false;               // long: correlate stage as overlap-save sections (detect_seg.hip)
+    float4* d_tspec16k = nullptr;   // sectioned: templates zero-padded to 16384, k_correlate's layout
+    thr::CorrStats* d_seg_stats = nullptr;   // sectioned: [long_batch][T][n_seg]
+    int path = 0;                   // THR_PATH_* the handle was created with
     int gen_batch = 0;       // generic path: blocks per internal sub-batch
     float2* d_gen_scratch = nullptr;  // generic path: 3 * gen_batch * N complex
     float2* d_tspec_nat = nullptr;    // generic path: conj(FFT(template))/N, natural order
@@ -121,7 +125,7 @@ struct thr_handle {
     thr::CorrStats* d_corr_stats = nullptr;
     int* d_work_list = nullptr;
     int* d_work_count = nullptr;
-    float4* d_xhat_scratch = nullptr;
+    float4* d_xhat_scratch = nullptr;   // long (unsectioned), several templates: one spectrum per workgroup
     int* d_ncompact = nullptr;
     int* d_compact_tiles = nullptr;   // per-tile counts / offsets of thr_compact_device (lazy)
     int compact_tiles_cap = 0;
@@ -220,6 +224,38 @@ int window_indices(int start, int stop, int n, int* lo, int* count) {
     return THR_OK;
 }
 
+// Overlap-save sections of a long block's correlate stage (detect_seg.hip).  A section is 16384
+// samples; against a W-sample template its lags 0 .. V - 1, V = 16384 - W + 1, are exact lags of
+// the block (soa_estimator.py:97-102 keeps only lags that do not wrap).  Sections start every D
+// samples, D = the largest even number <= V - 2 (even: u8 samples are fetched as 4-byte pairs; - 2:
+// a section must also hold the lag below and the lag above every lag it owns, for the peak's
+// neighbours, soa_estimator.py:159-170), the last one at block_len - 16384.  Section g > 0 owns the
+// block's lags from its start + 1 up to the next section's start; section 0 owns lag 0 too, the
+// last one everything up to corr_len.  Returns false (d.n_seg = 0) when the block needs more than
+// kMaxSections -- templates longer than about half a section: the decimated kernels keep those.
+bool plan_sections(thr::DevCfg& d, int template_len) {
+    const int m = 16384, n = d.block_len;
+    d.n_seg = 0;
+    const int v = m - template_len + 1;
+    if (n <= m || v < 4) return false;
+    const int stride = (v - 2) & ~1;
+    const int n_seg = (n - m + stride - 1) / stride + 1;
+    if (n_seg > thr::kMaxSections) return false;
+    int own_lo = 0;   // first lag of the block section g owns
+    for (int g = 0; g < n_seg; ++g) {
+        const int start = std::min(g * stride, n - m);
+        const int own_hi = g + 1 < n_seg ? std::min((g + 1) * stride, n - m) + 1 : d.corr_len;
+        d.seg_start[g] = start;
+        d.seg_sum_lo[g] = own_lo - start;
+        d.seg_sum_hi[g] = own_hi - start;
+        d.seg_lo[g] = std::max(own_lo, d.corr_lo) - start;
+        d.seg_hi[g] = std::max(std::min(own_hi, d.corr_hi), std::max(own_lo, d.corr_lo)) - start;
+        own_lo = own_hi;
+    }
+    d.n_seg = n_seg;
+    return true;
+}
+
 int build_constants(thr_handle* h) {
     const int n = h->cfg.block_len;
     // --- LDS twiddle tables (forward sign): C[32][32], A[16][32], Bt[16][32]  (fast path)
@@ -236,7 +272,7 @@ int build_constants(thr_handle* h) {
     // --- pass-1 / pass-B twiddles W_16384^(k1 q) of k_correlate (one template) and of the
     //     short-block kernels as one L2-resident table in global memory
     h->dev.gtw = nullptr;
-    if (h->small || h->fast) {
+    if (h->small || h->fast || h->seg) {
         std::vector<float2> g(16 * 1024);
         for (int k1 = 0; k1 < 16; ++k1)
             for (int q = 0; q < 1024; ++q) g[k1 * 1024 + q] = unit_root((long long)k1 * q, 16384);
@@ -299,6 +335,26 @@ int build_constants(thr_handle* h) {
                 out[k] = float2{float(c.real()), float(c.imag())};
             }
         }
+    }
+    if (h->seg) {
+        // sectioned correlate stage: conj(FFT(template zero-padded to 16384)) / 16384 in the
+        // digit-reversed, lane-coalesced order k_correlate consumes (same as block_len 16384)
+        const int m = 16384;
+        std::vector<float2> s16(size_t(nt) * m);
+        for (int t = 0; t < nt; ++t) {
+            std::vector<std::complex<double>> buf(m, 0.0);
+            for (int i = 0; i < w; ++i) buf[i] = h->cfg.templates[size_t(t) * w + i];
+            host_fft(buf);
+            float2* out = s16.data() + size_t(t) * m;
+            for (int tid = 0; tid < 512; ++tid)
+                for (int k3 = 0; k3 < 32; ++k3) {
+                    const int k = (tid >> 5) + 16 * (tid & 31) + 512 * k3;
+                    const std::complex<double> c = std::conj(buf[k]) / double(m);
+                    out[((k3 >> 1) * 512 + tid) * 2 + (k3 & 1)] = float2{float(c.real()), float(c.imag())};
+                }
+        }
+        HIP_TRY(hipMalloc(&h->d_tspec16k, s16.size() * sizeof(float2)));
+        HIP_TRY(hipMemcpy(h->d_tspec16k, s16.data(), s16.size() * sizeof(float2), hipMemcpyHostToDevice));
     }
     float2* d_spec = nullptr;
     HIP_TRY(hipMalloc(&d_spec, spec.size() * sizeof(float2)));
@@ -498,8 +554,7 @@ int run_batch_fast(thr_handle* h, const void* d_samples_all, int format,
             ProfScope p(h, 2);
             HIP_TRY(thr::launch_correlate_16k(
                 format, d_samples, h->dev, h->d_tables, h->d_twn, h->d_tspec, h->d_shifts, h->d_work_list,
-                h->d_work_count, h->d_corr_stats, d_out, h->d_xhat_scratch, dump_xhat, dump_corr,
-                dump_template, grid, h->stream));
+                h->d_work_count, h->d_corr_stats, dump_xhat, dump_corr, dump_template, grid, h->stream));
         }
         {
             ProfScope p(h, 3);
@@ -612,6 +667,20 @@ int run_batch_long(thr_handle* h, const void* d_samples, int format,
         // to the two-kernel form, in chunks of work-list slots (one chunk's d_k0 exchange stays
         // in the Infinity Cache between the two kernels).  Each form returns at once when the
         // batch is the other's (the work count lives on the device).
+        if (h->seg && !dump_xhat && !dump_corr) {
+            // overlap-save sections of the 16384-point kernel: one work item per (block, section)
+            {
+                ProfScope p(h, 2);
+                HIP_TRY(thr::launch_correlate_seg(format, in, h->dev, h->d_tables, h->d_twn, h->d_tspec16k,
+                                                  h->d_shifts, h->d_work_list, h->d_work_count,
+                                                  h->d_seg_stats, std::min(nb * h->dev.n_seg, h->n_cu),
+                                                  h->stream));
+            }
+            ProfScope p(h, 3);
+            HIP_TRY(thr::launch_finish(nb * int(T), h->dev, h->d_corr_stats, out, h->d_work_count,
+                                       h->stream, h->d_seg_stats));
+            continue;
+        }
         const int fused_grid = std::min(nb, h->n_cu);
         float2* dcorr = dump_corr ? dump_corr + size_t(off) * n : nullptr;
         float2* dxhat = dump_xhat ? dump_xhat + size_t(off) * n : nullptr;
@@ -681,10 +750,12 @@ int run_batch(thr_handle* h, const void* d_samples, int format, const long long*
               float2* dump_corr, int dump_template, bool carrier_only, size_t stride = 0) {
     // stride 0: blocks packed back to back; otherwise raw-stream framing (overlapping blocks)
     h->dev.blk_stride = stride ? stride : size_t(h->cfg.block_len) * (format == THR_IN_U8 ? 2 : 8);
-    // dev knob (A/B only, results are those of block 0): every block reads the SAME samples, which
+#ifdef THR_DEV
+    // dev A/B only (results are those of block 0): every block reads the SAME samples, which
     // then come from L2 -- what is left of a kernel's time is what it costs WITHOUT its HBM fetch
     static const bool stride0 = getenv("THR_DEV_STRIDE0") != nullptr;
     if (stride0) h->dev.blk_stride = 0;
+#endif
     return (h->small ? run_batch_small : h->fast ? run_batch_fast : h->lng ? run_batch_long : run_batch_generic)(
         h, d_samples, format, d_block_idx, n_blocks, d_out, dump_fft, dump_xhat, dump_corr,
         dump_template, carrier_only);
@@ -704,29 +775,76 @@ const char* thr_kernel_name(int slot) {
     return (slot >= 0 && slot < THR_N_KERNEL_SLOTS) ? names[slot] : "";
 }
 
-static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out, int variant = -1);
+static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out, int variant = -1,
+                       int path = THR_PATH_AUTO);
 
 int thr_create(const thr_settings* s, thr_handle** out) { return create_impl(s, 0, out); }
 
-int thr_create_fastdet(const thr_settings* s, thr_handle** out) {
+static int create_fastdet(const thr_settings* s, thr_handle** out, int path) {
     if (!s || !out) return fail(THR_ERR_ARG, "thr_create_fastdet: null argument");
     if (s->n_templates != 1) return fail(THR_ERR_ARG, "the fastdet variant takes exactly one template");
     if (s->carrier_thresh[2] != 0.0 || s->corr_thresh[2] != 0.0)
         return fail(THR_ERR_ARG, "fastdet thresholds are constant + snr * noise_power (no stddev term)");
     if (s->carrier_window[0] < 0 && s->carrier_window[1] >= 0)   // cardet.c:44-48
         return fail(THR_ERR_ARG, "Carrier frequency window range not supported.");
-    return create_impl(s, 1, out, 2);
+    return create_impl(s, 1, out, 2, path);
 }
 
-int thr_create_preshift(const thr_settings* s, int num_shifts, thr_handle** out) {
+int thr_create_fastdet(const thr_settings* s, thr_handle** out) {
+    return create_fastdet(s, out, THR_PATH_AUTO);
+}
+
+static int create_preshift(const thr_settings* s, int num_shifts, thr_handle** out, int path) {
     if (num_shifts < 1 || num_shifts > 4096)
         return fail(THR_ERR_ARG, "num_shifts %d out of range [1, 4096]", num_shifts);
     if (s && s->n_templates != 1)
         return fail(THR_ERR_ARG, "the preshift variant takes exactly one template");
-    return create_impl(s, num_shifts, out);
+    return create_impl(s, num_shifts, out, -1, path);
 }
 
-static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out, int variant) {
+int thr_create_preshift(const thr_settings* s, int num_shifts, thr_handle** out) {
+    return create_preshift(s, num_shifts, out, THR_PATH_AUTO);
+}
+
+int thr_plan_sections(int block_len, int history_len, int template_len, int* n_sections, int* start,
+                      int* win_lo, int* win_hi, int* sum_lo, int* sum_hi) {
+    if (!n_sections || !start || !win_lo || !win_hi || !sum_lo || !sum_hi)
+        return fail(THR_ERR_ARG, "thr_plan_sections: null argument");
+    if (block_len <= 0 || (block_len & (block_len - 1)) || template_len < 1 || template_len > block_len ||
+        history_len < template_len - 1 || history_len >= block_len)
+        return fail(THR_ERR_ARG, "thr_plan_sections: bad geometry (%d, %d, %d)", block_len, history_len,
+                    template_len);
+    thr::DevCfg d{};
+    d.block_len = block_len;
+    d.corr_len = block_len - template_len + 1;
+    const int pad = history_len - template_len + 1;   // soa_estimator.py:20-39
+    d.corr_lo = pad / 2;
+    d.corr_hi = d.corr_len - (pad - pad / 2);
+    plan_sections(d, template_len);
+    *n_sections = d.n_seg;
+    for (int g = 0; g < d.n_seg; ++g) {
+        start[g] = d.seg_start[g];
+        win_lo[g] = d.seg_lo[g] + d.seg_start[g];
+        win_hi[g] = d.seg_hi[g] + d.seg_start[g];
+        sum_lo[g] = d.seg_sum_lo[g] + d.seg_start[g];
+        sum_hi[g] = d.seg_sum_hi[g] + d.seg_start[g];
+    }
+    return THR_OK;
+}
+
+int thr_create_ex(const thr_settings* s, int variant, int variant_arg, int path, thr_handle** out) {
+    if (path != THR_PATH_AUTO && path != THR_PATH_MULTIPASS && path != THR_PATH_UNSECTIONED)
+        return fail(THR_ERR_ARG, "thr_create_ex: unknown path %d", path);
+    switch (variant) {
+        case THR_VARIANT_DEFAULT: return create_impl(s, 0, out, -1, path);
+        case THR_VARIANT_PRESHIFT: return create_preshift(s, variant_arg, out, path);
+        case THR_VARIANT_FASTDET: return create_fastdet(s, out, path);
+    }
+    return fail(THR_ERR_ARG, "thr_create_ex: unknown variant %d", variant);
+}
+
+
+static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out, int variant, int path) {
     if (!s || !out) return fail(THR_ERR_ARG, "thr_create: null argument");
     *out = nullptr;
     const int n = s->block_len;
@@ -754,9 +872,11 @@ static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out
     h->cfg.templates = nullptr;  // not retained beyond this call (re-pointed below)
     h->device = s->device_id;
     h->preshift_num = preshift_num;
-    h->fast = (n == 16384) && getenv("THR_FORCE_GENERIC") == nullptr;
+    h->path = path;
+    const bool multipass = path == THR_PATH_MULTIPASS;
+    h->fast = (n == 16384) && !multipass;
     // the preshift variant has a fused kernel for 16384 only; other lengths use the multi-pass pipeline
-    h->lng = thr::long_supported(n) && getenv("THR_FORCE_GENERIC") == nullptr && !preshift_num;
+    h->lng = thr::long_supported(n) && !multipass && !preshift_num;
     int rc = THR_OK;
     do {
         if (hipSetDevice(h->device) != hipSuccess) {
@@ -797,19 +917,19 @@ static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out
             d.car_thr[i] = s->carrier_thresh[i];
             d.cor_thr[i] = s->corr_thresh[i];
         }
+#ifdef THR_DEV
         d.timeline = nullptr;
-#ifdef THR_TIMELINE
         if (hipMalloc(&d.timeline, 128 * sizeof(unsigned long long)) == hipSuccess)
             hipMemset(d.timeline, 0, 128 * sizeof(unsigned long long));
 #endif
-        d.stagger = getenv("THR_STAGGER") ? atoi(getenv("THR_STAGGER")) : 1;
-        d.dyn_sched = getenv("THR_DYN") ? atoi(getenv("THR_DYN")) : 1;
         d.variant = variant >= 0 ? variant : (preshift_num ? 1 : 0);
-        d.prio_mode = getenv("THR_PRIO") ? atoi(getenv("THR_PRIO")) : 0;
-        d.ablate = getenv("THR_ABLATE") ? atoi(getenv("THR_ABLATE")) : 0;
         d.car_want_std = s->carrier_thresh[2] != 0.0;
         d.car_prune = 0;
-        if (!d.car_want_std && getenv("THR_NO_PRUNE") == nullptr) {
+        bool prune_ok = !d.car_want_std;
+#ifdef THR_DEV
+        if (getenv("THR_NO_PRUNE")) prune_ok = false;   // dev A/B: the full-spectrum carrier kernel
+#endif
+        if (prune_ok) {
             // long blocks: R0 sub-transforms, each pruned to its 128 lowest bins (mode 1 only)
             const int span = 128 * (h->lng ? n / 16384 : 1);
             if (d.win_lo >= 3 && d.win_lo + d.win_count + 3 <= span)
@@ -818,7 +938,10 @@ static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out
                 d.car_prune = 2;  // any narrow window: pre-shift by win_lo - 3
         }
         d.cor_want_std = s->corr_thresh[2] != 0.0;
-        h->small = thr::small_supported(n) && getenv("THR_FORCE_GENERIC") == nullptr && !preshift_num;
+        h->small = thr::small_supported(n) && !multipass && !preshift_num;
+        // long blocks: the correlate stage in overlap-save sections wherever the template allows
+        h->seg = h->lng && path != THR_PATH_UNSECTIONED && plan_sections(d, s->template_len);
+        if (!h->seg) d.n_seg = 0;
 
         h->cfg.templates = s->templates;
         rc = build_constants(h);
@@ -834,6 +957,9 @@ static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out
         if (h->fast) CREATE_TRY(thr::prepare_16k());
         if (h->fast && preshift_num) CREATE_TRY(thr::prepare_preshift_16k());
         if (h->small) CREATE_TRY(thr::prepare_small(n));
+        if (h->seg) {
+            CREATE_TRY(thr::prepare_seg());
+        }
         if (h->lng) {
             CREATE_TRY(thr::prepare_long(n));
             const int r0 = n / 16384;
@@ -842,19 +968,19 @@ static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out
             // sub-batch is as large as the small per-block buffers allow: fewer kernel ramps and
             // tails, +3.7 % from 4096 to 16384 blocks)
             h->long_batch = std::min(s->max_batch, std::max(64, 16384 / s->n_templates));
-            if (getenv("THR_LONG_BATCH")) h->long_batch = std::max(1, std::min(s->max_batch, atoi(getenv("THR_LONG_BATCH"))));
             const size_t lb = size_t(h->long_batch);
             const size_t win_w = size_t(std::min(h->dev.win_count + 6, n));
             // (the decimation-in-time carrier stage parks R0 complex values per window bin here)
             CREATE_TRY(hipMalloc(&h->d_win_pow, lb * win_w * sizeof(float) * 2 * r0));
             CREATE_TRY(hipMalloc(&h->d_partial, lb * r0 * 2 * sizeof(float)));
             h->long_chunk = std::min(h->long_batch, thr::long_chunk_blocks(n, s->n_templates));
-            if (getenv("THR_LONG_CHUNK")) h->long_chunk = std::max(1, std::min(h->long_batch, atoi(getenv("THR_LONG_CHUNK"))));
             const size_t lc = size_t(h->long_chunk);
             // (one chunk of the two-kernel form, or one row per workgroup of the fused form)
             const size_t rows = std::max(lc, size_t(std::min(h->long_batch, h->n_cu)));
             CREATE_TRY(hipMalloc(&h->d_dsub, rows * s->n_templates * size_t(n) * sizeof(float2)));
             CREATE_TRY(hipMalloc(&h->d_xhat_scratch, size_t(h->n_cu) * 16384 * sizeof(float2)));
+            if (h->seg)
+                CREATE_TRY(hipMalloc(&h->d_seg_stats, lb * s->n_templates * size_t(d.n_seg) * sizeof(thr::CorrStats)));
         }
         if (!h->fast && !h->lng) {
             // sub-batch so that the 3 ping-pong buffers stay near 256 MiB (Infinity-Cache sized)
@@ -874,8 +1000,6 @@ static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out
         CREATE_TRY(hipMalloc(&h->d_work_count, 4 * sizeof(int)));  // [0] work count, [1] dynamic cursor
         CREATE_TRY(hipMemset(h->d_work_count, 0, 4 * sizeof(int)));  // re-armed by k_finish
         CREATE_TRY(hipMalloc(&h->d_ncompact, sizeof(int)));
-        if (h->fast && s->n_templates > 1)
-            CREATE_TRY(hipMalloc(&h->d_xhat_scratch, size_t(h->n_cu) * n * sizeof(float2)));
 #undef CREATE_TRY
     } while (0);
     if (rc != THR_OK) {
@@ -913,7 +1037,7 @@ void thr_destroy(thr_handle* h) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
     }
-    void* bufs[] = {h->d_tables, h->d_twn, h->d_tspec, h->d_stats, h->d_shifts, h->d_corr_stats, h->d_gen_scratch, h->d_tspec_nat, h->d_bank, h->d_gtw, h->d_win_pow, h->d_partial, h->d_dsub, h->d_work_list,
+    void* bufs[] = {h->d_tables, h->d_twn, h->d_tspec, h->d_stats, h->d_shifts, h->d_corr_stats, h->d_gen_scratch, h->d_tspec_nat, h->d_bank, h->d_gtw, h->d_tspec16k, h->d_seg_stats, h->d_win_pow, h->d_partial, h->d_dsub, h->d_work_list,
                     h->d_work_count, h->d_xhat_scratch, h->d_ncompact, h->d_compact_tiles, h->d_in, h->d_idx, h->d_rec};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -1556,7 +1680,7 @@ int thr_profile_read(thr_handle* h, double ms[THR_N_KERNEL_SLOTS],
     return THR_OK;
 }
 
-#ifdef THR_TIMELINE
+#ifdef THR_DEV
 int thr_debug_timeline(thr_handle* h, unsigned long long* out128) {
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);

@@ -35,10 +35,6 @@ __global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples
 
     load_tables(lds, tables);
     __syncthreads();
-    // dev knob (THR_PRIO): waves w and w+4 share a SIMD and the older one finishes every phase
-    // ~35 % earlier; raising either half's priority was measured to change nothing here
-    if (cfg.prio_mode == 1 && threadIdx.x >= NT / 2) __builtin_amdgcn_s_setprio(1);
-    if (cfg.prio_mode == 2 && threadIdx.x < NT / 2) __builtin_amdgcn_s_setprio(1);
     const size_t blk_bytes = cfg.blk_stride;  // dense: N * sample size; raw streams: 2 (N - H)
     int parity = 0;
     cpx tw0[R1], tw1[R1];   // block-invariant pass-1 twiddles of this thread's two columns
@@ -57,23 +53,11 @@ __global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples
             cur.load(static_cast<const unsigned char*>(samples) + size_t(b + gridDim.x) * blk_bytes,
                      opaque_tid());
         __syncthreads();
-        THR_ABLATE_AT(1, continue);
         // passes 2 and 3 of row k1 are done by the same half-wave: no barrier between them
         fwd_pass2(lds);
         __builtin_amdgcn_sched_barrier(0);  // keep the passes' register working sets apart
-        THR_ABLATE_AT(2, { __syncthreads(); continue; });
         cpx v[R3];
         fwd_pass3(lds, v);
-#ifdef THR_DEV_ABLATE
-        if (cfg.ablate == 3) {
-            float acc = 0;
-#pragma unroll
-            for (int i = 0; i < R3; ++i) acc += v[i].x + v[i].y;
-            if (acc == 1.2345f) stats[b].pad = 1;  // keep pass 3 alive
-            __syncthreads();
-            continue;
-        }
-#endif
 
         // ---- statistics over the spectrum held in registers
         const int t = opaque_tid();
@@ -186,9 +170,6 @@ __global__ __launch_bounds__(NT) void k_carrier_pruned(const void* __restrict__ 
         for (int e = 0; e < 2; ++e) ph[e] = twn[((2 * int(threadIdx.x) + e) * base) & (N - 1)];
     }
     __syncthreads();
-    // dev knob (THR_PRIO): see k_carrier
-    if (cfg.prio_mode == 1 && threadIdx.x >= NT / 2) __builtin_amdgcn_s_setprio(1);
-    if (cfg.prio_mode == 2 && threadIdx.x < NT / 2) __builtin_amdgcn_s_setprio(1);
     const size_t blk_bytes = cfg.blk_stride;  // dense: N * sample size; raw streams: 2 (N - H)
     int parity = 0;
     cpx tw0[R1], tw1[R1];   // block-invariant pass-1 twiddles (unshifted variant only)
@@ -333,6 +314,13 @@ __global__ __launch_bounds__(64) void k_fit(int n_blocks, DevCfg cfg,
                 sincospi(2.0 * a, &sn, &cs);
                 sp->r0pow[j] = float2{float(cs), float(sn)};
             }
+            if (j < cfg.n_seg) {  // sectioned correlate stage: phasor of a section's first sample
+                double a = s * (double(cfg.seg_start[j]) / double(n) - 0.5);
+                a -= rint(a);
+                double sn, cs;
+                sincospi(2.0 * a, &sn, &cs);
+                sp->segc0[j] = float2{float(cs), float(sn)};
+            }
             if (j == 0) {
                 double a = -0.5 * s;  // exp(2 pi i * s * (-1/2))
                 a -= rint(a);
@@ -390,7 +378,8 @@ __global__ __launch_bounds__(64) void k_fit(int n_blocks, DevCfg cfg,
 __global__ __launch_bounds__(256) void k_finish(int n_records, DevCfg cfg,
                                                 const CorrStats* __restrict__ corr_stats,
                                                 thr_record* __restrict__ records,
-                                                int* __restrict__ work_count) {
+                                                int* __restrict__ work_count,
+                                                const CorrStats* __restrict__ seg_stats) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {  // k_correlate is done with them: re-arm for the next batch
         work_count[0] = 0;
@@ -400,7 +389,28 @@ __global__ __launch_bounds__(256) void k_finish(int n_records, DevCfg cfg,
     thr_record* r = records + i;
     if (!(r->flags & THR_FLAG_CARRIER)) return;
     const int tpl = i % cfg.n_templates;
-    const CorrStats cs = corr_stats[i];
+    CorrStats cs = corr_stats[i];
+    if (seg_stats != nullptr) {
+        // sectioned correlate stage (detect_seg.hip): the block's windowed first-max is the first
+        // section that holds the largest power (the sections' owned lags ascend with the section
+        // index, np.argmax takes the lowest lag: soa_estimator.py:137-143); the stddev sums add up
+        const CorrStats* sg = seg_stats + size_t(i) * cfg.n_seg;
+        int best = -1;
+        double s1 = 0, s2 = 0;
+        for (int g = 0; g < cfg.n_seg; ++g) {
+            s1 += double(sg[g].sum_mag);
+            s2 += double(sg[g].sum_mag2);
+            if (sg[g].pk >= 0 && (best < 0 || sg[g].pm2 > sg[best].pm2)) best = g;
+        }
+        if (best < 0) best = 0;   // (cannot happen: the owned ranges tile a non-empty window)
+        cs.pm2 = sg[best].pm2;
+        cs.m2[0] = sg[best].m2[0];
+        cs.m2[1] = sg[best].m2[1];
+        cs.m2[2] = sg[best].m2[2];
+        cs.pk = sg[best].pk + cfg.seg_start[best];
+        cs.sum_mag = float(s1);
+        cs.sum_mag2 = float(s2);
+    }
     if (cfg.variant == 2) {
         // fastdet-compatible verdict (fastdet/corr_detector.cpp:103-175): float32, power domain,
         // noise clamped at 0 and -- sic -- computed from the peak power truncated to an integer
@@ -621,9 +631,10 @@ hipError_t launch_fit(int n_blocks, const DevCfg& cfg, const CarStats* stats,
 }
 
 hipError_t launch_finish(int n_records, const DevCfg& cfg, const CorrStats* corr_stats,
-                         thr_record* records, int* work_count, hipStream_t stream) {
+                         thr_record* records, int* work_count, hipStream_t stream,
+                         const CorrStats* seg_stats) {
     hipLaunchKernelGGL(k_finish, dim3((n_records + 255) / 256), dim3(256), 0, stream, n_records,
-                       cfg, corr_stats, records, work_count);
+                       cfg, corr_stats, records, work_count, seg_stats);
     return hipGetLastError();
 }
 

@@ -7,6 +7,7 @@
 namespace thr {
 
 constexpr int kMaxTemplates = 8;
+constexpr int kMaxSections = 8;   // (a work item carries its section in 3 bits)
 
 // Per-launch constants (passed by value as a kernel argument).
 struct DevCfg {
@@ -32,14 +33,20 @@ struct DevCfg {
                                     // size for packed blocks, 2 (N - H) for raw-stream framing
     int car_prune;     // pruned FFT#1 (16384 path): 0 off, 1 window+margin inside bins [0,128),
                        // 2 any window of <= 122 bins (samples pre-shifted by win_lo - 3)
-    unsigned long long* timeline;  // dev only (-DTHR_TIMELINE): [8 waves][16] s_memtime stamps
     const void* gtw;   // [16][1024] W_16384^(k1 q) for k_correlate's passes 1 and B (kernels compiled for the LDS-table form ignore it)
     int variant;       // 0 reference Detector, 1 PreshiftDetector, 2 fastdet-compatible (power-domain verdicts)
-    int dyn_sched;     // THR_DYN (default 1): k_correlate takes blocks from a global counter (see kernel)
-    int stagger;       // THR_STAGGER (default 1): younger half of k_correlate's waves computes the next
-                       // block's phasor after the pass-1 barrier instead of before it
-    int prio_mode;     // dev knob THR_PRIO: 0 none (default), 1: s_setprio(1) for waves 4-7, 2: waves 0-3
-    int ablate;        // dev only (THR_ABLATE): stop each block after phase n; 0 = off
+    // Overlap-save sections of the correlate stage (block_len > 16384, detect_seg.hip; 0 = none):
+    // section g covers samples [seg_start[g], seg_start[g] + 16384) of a block.  In SECTION
+    // coordinates (lag - seg_start[g]): it owns the window lags [seg_lo[g], seg_hi[g]) and, for the
+    // stddev term, sums the lags [seg_sum_lo[g], seg_sum_hi[g]); the owned ranges tile the block's
+    // [corr_lo, corr_hi) resp. [0, corr_len) exactly once (plan_sections, api.hip).
+    int n_seg;
+    int seg_start[kMaxSections];
+    int seg_lo[kMaxSections], seg_hi[kMaxSections];
+    int seg_sum_lo[kMaxSections], seg_sum_hi[kMaxSections];
+#ifdef THR_DEV
+    unsigned long long* timeline;  // -DTHR_DEV: [8 waves][16] s_memtime stamps of one k_correlate item
+#endif
 };
 
 // K_A -> K_fit
@@ -71,6 +78,7 @@ struct ShiftParams {
     float sf_over_n;  // (s - round(s)) / N
     int bank;         // preshift variant (multi-pass pipeline): pre-shifted template index
     int pad_;
+    float2 segc0[kMaxSections];  // sectioned correlate stage: exp(2 pi i s (seg_start[g] / N - 1/2))
 };
 
 // detect16k_preshift.hip -- PreshiftDetector variant (one fused kernel per block at 16384)
@@ -97,14 +105,23 @@ hipError_t launch_correlate_16k(int fmt, const void* samples, const DevCfg& cfg,
                                 const float2* tables, const float2* twn, const float4* tspec,
                                 const ShiftParams* shifts, const int* work_list,
                                 const int* work_count, CorrStats* corr_stats,
-                                thr_record* records, float4* xhat_scratch,
                                 float2* dump_xhat, float2* dump_corr, int dump_template, int grid,
                                 hipStream_t stream);
+// seg_stats (or null): the sectioned correlate stage's [record][section] results, merged here
 hipError_t launch_finish(int n_records, const DevCfg& cfg, const CorrStats* corr_stats,
-                         thr_record* records, int* work_count, hipStream_t stream);
+                         thr_record* records, int* work_count, hipStream_t stream,
+                         const CorrStats* seg_stats = nullptr);
 int compact_tiles(int n_records);   // ints of tile scratch launch_compact needs
 hipError_t launch_compact(const thr_record* in, int n, thr_record* out, int* n_out,
                           int* tile_scratch, hipStream_t stream);
+
+// detect_seg.hip (block_len = 2 or 4 x 16384: the correlate stage as overlap-save sections of the
+// 16384-point kernel; tspec16k = the templates zero-padded to 16384, k_correlate's layout)
+hipError_t prepare_seg();
+hipError_t launch_correlate_seg(int fmt, const void* samples, const DevCfg& cfg, const float2* tables,
+                                const float2* twn, const float4* tspec16k, const ShiftParams* shifts,
+                                const int* work_list, const int* work_count, CorrStats* seg_stats,
+                                int grid, hipStream_t stream);
 
 // detect_long.hip (block_len = 2 or 4 x 16384: R0 LDS-resident sub-transforms per block)
 bool long_supported(int block_len);

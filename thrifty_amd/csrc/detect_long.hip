@@ -997,25 +997,10 @@ __global__ __launch_bounds__(NT) void k_correlate_sub(
             });
             if constexpr (FUSED && !MULTI) {
                 if (k0 == R0 - 1) {
-#ifdef THR_DEV_ABLATE
-                    if (cfg.ablate == 21) continue;   // dev: the sub-transforms alone
-#endif
                     const f4* rows = dsub + (size_t(blockIdx.x) * T + tpl) * (size_t(R0) * (M / 2));
                     float bp[R0];
                     int bn[R0];
-#ifdef THR_DEV_ABLATE
-                    if (cfg.ablate == 23) {   // dev: no lag loop (finish only)
-#pragma unroll
-                        for (int n0 = 0; n0 < R0; ++n0) { bp[n0] = c0[n0].x; bn[n0] = n0; }
-                    } else
-#endif
                     combine_own<R0>(cfg, stab, rows, c0, c1, wb0, wb1, bp, bn);
-#ifdef THR_DEV_ABLATE
-                    if (cfg.ablate == 22) {   // dev: lag loop, no reduction / neighbours
-                        if (bp[0] + bp[1] == 1.2345f) corr_stats[b].pk = bn[0] + bn[1];
-                        continue;
-                    }
-#endif
                     // the workgroup's next block: its raw words are requested here, between the
                     // lags and the reduction -- their latency hides under the reduction, the
                     // neighbour recombination and the next block's preamble (earlier, their 16 R0

@@ -46,27 +46,10 @@ __device__ __forceinline__ void sincos_small(float x, float* s, float* c) {
     *c = fmaf(x2, pc, 1.0f);
 }
 
-// Dev-only phase ablation (-DTHR_DEV_ABLATE, env THR_ABLATE=n): leave each block after phase n
-// so that cumulative phase costs can be read off the kernel time (results are garbage).
-#ifdef THR_DEV_ABLATE
-#define THR_ABLATE_AT(code, stmt) \
-    if (cfg.ablate == (code)) stmt
-#else
-#define THR_ABLATE_AT(code, stmt) do { } while (0)
-#endif
-
-// Dev-only (-DTHR_DEV_NOBAR): the workgroup barriers inside the per-block loops vanish, so the
-// waves free-run and drift apart (results are garbage) -- the kernel time then shows what the
-// barrier lockstep of the LDS and VALU bursts costs.
-#ifdef THR_DEV_NOBAR
-#define THR_LOOP_BARRIER() __builtin_amdgcn_sched_barrier(0)
-#else
-#define THR_LOOP_BARRIER() __syncthreads()
-#endif
-
-// Dev-only cycle timeline (-DTHR_TIMELINE): workgroup 0 records s_memtime at phase
-// boundaries of its 4th block, one row of 16 stamps per wave, into cfg.timeline.
-#ifdef THR_TIMELINE
+// Dev-only cycle timeline (-DTHR_DEV, never set by thrifty_amd/build.py): workgroup 0 records
+// s_memtime at phase boundaries of its 4th work item, one row of 16 stamps per wave, into
+// cfg.timeline (scripts/timeline.py).  The default build compiles the stamps to nothing.
+#ifdef THR_DEV
 #define THR_STAMP(slot)                                                                   \
     do {                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                \
@@ -172,7 +155,7 @@ __device__ __forceinline__ double block_sum(float s, unsigned char* scratch, int
     double* sd = reinterpret_cast<double*>(scratch + parity * red_slot_bytes<NW>());
     s = wave_sum(s);
     if (lane == 0) sd[wv * 3] = (double)s;
-    THR_LOOP_BARRIER();
+    __syncthreads();
     double t = 0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) t += sd[w * 3];
@@ -196,7 +179,7 @@ __device__ __forceinline__ void block_reduce(float (&s)[NS], double (&out)[NS],
         for (int i = 0; i < NS; ++i) sd[wv * 3 + i] = (double)s[i];
         su[wv] = m;
     }
-    THR_LOOP_BARRIER();
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         double t = 0;
@@ -246,7 +229,7 @@ __device__ __forceinline__ void block_reduce_wave_keys(unsigned long long& m, un
     unsigned long long* su =
         reinterpret_cast<unsigned long long*>(scratch + parity * red_slot_bytes<NW>()) + 3 * NW;
     if (lane == 0) su[wv] = m;
-    THR_LOOP_BARRIER();
+    __syncthreads();
     unsigned long long t = su[0];
 #pragma unroll
     for (int w = 1; w < NW; ++w) t = max_power_key(su[w], t);
@@ -263,7 +246,7 @@ __device__ __forceinline__ void block_reduce_max(unsigned long long& m, unsigned
         reinterpret_cast<unsigned long long*>(scratch + parity * red_slot_bytes<NW>()) + 3 * NW;
     m = wave_max_power_key(m);
     if (lane == 0) su[wv] = m;
-    THR_LOOP_BARRIER();
+    __syncthreads();
     unsigned long long t = su[0];
 #pragma unroll
     for (int w = 1; w < NW; ++w) t = max_power_key(su[w], t);
