@@ -19,11 +19,14 @@ sparse), each with its own recomputable roofline.  Workloads (BASELINE.json `con
   --config c3: configs[2] -- block_len 65536, history 4096, 2047-chip Gold code at 2 samples
       per chip (W = 4094), the long-FFT regime (a block does not fit the LDS)
 
-Metric: IQ blocks/s, whole job.  For N > 1 launch with
+Metric: IQ blocks/s, whole job.  For N > 1 the driver launches
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
-Blocks are sharded by contiguous block-index ranges (weak scaling: K*B blocks
-per GPU); the only collective is the gather of detection records to rank 0.
+and a plain `python bench.py --gpus N` starts exactly that by itself.  Blocks are sharded by
+contiguous block-index ranges (weak scaling: K*B blocks per GPU); the only collective is the
+gather of detection records to rank 0.  `--dist-backend gloo` rehearses the whole N-rank body
+(pre-flight, step-size broadcast, MAX all-reduce of the time, record gather) on ONE GPU: every
+rank computes on cuda:0 and the collectives carry CPU tensors.
 """
 from __future__ import annotations
 
@@ -54,6 +57,22 @@ CONFIGS = {
 }
 
 
+# extra legs of the default run: other single-GPU workloads of BASELINE.json's configs (and the
+# reference's DEFAULT carrier window, settings.py:75-80 '0--1' = every bin, which takes the
+# full-spectrum carrier kernel instead of the pruned one)
+LEGS = {"c3": dict(name="c3", T=1, mix="dense", batch=16384, resident=2 * 16384),
+        "t4": dict(name="c2", T=4, mix="dense", batch=16384, resident=4 * 16384),
+        "sparse": dict(name="c2", T=1, mix="sparse", batch=32768, resident=4 * 32768),
+        "fullwin": dict(name="c2", T=1, mix="dense", batch=32768, resident=4 * 32768, window=(0, -1)),
+        "c3t4": dict(name="c3", T=4, mix="dense", batch=4096, resident=2 * 4096)}
+
+
+def csrc_sha16():
+    """Hash of the kernel sources: profiles/hbm_traffic.json records the one its PMC passes ran on."""
+    from thrifty_amd import build
+    return build.csrc_hash()
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,6 +85,9 @@ def parse_args():
     ap.add_argument("--mix", choices=["dense", "sparse"], default="dense",
                     help="dense: every block carries a signal; sparse: 10%% do")
     ap.add_argument("--templates", type=int, default=1)
+    ap.add_argument("--carrier-window", type=int, nargs=2, default=list(WINDOW_BINS), metavar=("START", "STOP"),
+                    help="carrier window bins (default 7 110, SURVEY 8(d)); 0 -1 = every bin, the "
+                         "reference's own default (settings.py:75-80), runs the full-spectrum carrier kernel")
     ap.add_argument("--streams", type=int, default=0,
                     help="engine handles (each with its own HIP stream) the steps alternate over "
                          "(default per config)")
@@ -80,8 +102,8 @@ def parse_args():
                     help="lower bound on the timed region: a step becomes R launch batches of --batch "
                          "blocks, R from a calibration burst, so that K steps last this long (0: R = 1)")
     ap.add_argument("--legs", default="auto",
-                    help="comma list of extra single-GPU legs after the main one (c3,t4,sparse); "
-                         "'auto' = all three on the default c2 / 1 GPU run, none otherwise; 'none'")
+                    help="comma list of extra single-GPU legs after the main one (%s); 'auto' = all of "
+                         "them on the default c2 / 1 GPU run, none otherwise; 'none'" % ",".join(LEGS))
     ap.add_argument("--leg-seconds", type=float, default=0.75, help="timed region of each extra leg")
     ap.add_argument("--cpu-procs", type=int, default=-1,
                     help="worker processes of the all-cores CPU leg (-1: one per physical core, "
@@ -90,6 +112,11 @@ def parse_args():
                     help="wall budget of the single-core CPU baseline leg (0 disables every CPU leg)")
     ap.add_argument("--card-blocks", type=int, default=4096,
                     help="blocks of the config-#1 .card -> .toad plumbing leg (0 skips it)")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl: RCCL, one GPU per rank (the real thing); gloo: every rank on cuda:0, "
+                         "collectives on CPU tensors -- a rehearsal of the N-rank body on a 1-GPU box")
+    ap.add_argument("--resident-blocks", type=int, default=0,
+                    help="distinct blocks resident in HBM per rank (default per config: c2 1 Mi = 32 GiB)")
     return ap.parse_args()
 
 
@@ -126,19 +153,19 @@ def synth_on_device(torch, dev, gen, n_blocks, n, template, window, signal_frac,
     return out
 
 
-def make_oracle(n, h, template, preshift_num=0):
+def make_oracle(n, h, template, preshift_num=0, window=WINDOW_BINS):
     from oracle import thrifty_np as onp
     if preshift_num:
-        return onp.OraclePreshiftDetector(n, h, template, THRESH, WINDOW_BINS, THRESH, num=preshift_num)
-    return onp.OracleDetector(n, h, template, THRESH, WINDOW_BINS, THRESH)
+        return onp.OraclePreshiftDetector(n, h, template, THRESH, tuple(window), THRESH, num=preshift_num)
+    return onp.OracleDetector(n, h, template, THRESH, tuple(window), THRESH)
 
 
-def cpu_baseline(n, h, blocks_u8, idx, template, budget_s, gpu_rec, preshift_num=0):
+def cpu_baseline(n, h, blocks_u8, idx, template, budget_s, gpu_rec, preshift_num=0, window=WINDOW_BINS):
     """Oracle (oracle/thrifty_np.py, a NumPy port of the reference algorithm) timed on ONE
     host core over a bounded sample of the same blocks; also spot-checks parity."""
     from thrifty_amd import _native as F
     os.environ.setdefault("OMP_NUM_THREADS", "1")
-    orc = make_oracle(n, h, template, preshift_num)
+    orc = make_oracle(n, h, template, preshift_num, window)
     done, mism = 0, 0
     t0 = time.perf_counter()
     for i in range(len(blocks_u8)):
@@ -169,7 +196,7 @@ def _compute_view(kernel, n, n_templates, blocks_per_launch, avg_ms):
     """Nominal flop of the dominant kernel per block -> achieved TFLOP/s vs the VALU peak."""
     fft = 5.0 * n * np.log2(n)
     point = 6.0 * n
-    if kernel in ("k_correlate", "k_correlate_sub"):  # shift, FFT#2, then per template: product, IFFT, |.|^2
+    if kernel in ("k_correlate", "k_correlate_sub", "k_correlate_seg"):  # shift, FFT#2, then per template: product, IFFT, |.|^2
         flop = point + fft + n_templates * (point + fft + 3.0 * n)
     elif kernel == "k_preshift":     # FFT#1, |X|^2, product, IFFT, |.|^2
         flop = fft + 3.0 * n + point + fft + 3.0 * n
@@ -183,8 +210,8 @@ def _compute_view(kernel, n, n_templates, blocks_per_launch, avg_ms):
 def _oracle_worker(job):
     """(spawned process) run the oracle over a slab of blocks; returns (n, seconds)."""
     os.environ["OMP_NUM_THREADS"] = "1"
-    n, h, blocks, template = job
-    orc = make_oracle(n, h, template)
+    n, h, blocks, template, window = job
+    orc = make_oracle(n, h, template, 0, window)
     t0 = time.perf_counter()
     for i in range(len(blocks)):
         orc.detect_u8(i, blocks[i])
@@ -218,7 +245,7 @@ def physical_cores():
     return n, how
 
 
-def cpu_all_cores(n, h, blocks_u8, template, procs, single_rate, seconds=4.0):
+def cpu_all_cores(n, h, blocks_u8, template, procs, single_rate, seconds=4.0, window=WINDOW_BINS):
     """Oracle throughput with `procs` spawned workers (one per physical core), each over its own
     slab of the blocks, sized from the single-core rate so the leg takes `seconds` if the cores
     scaled perfectly (they do not: all-core clocks and memory bandwidth; expect ~2x that)."""
@@ -228,11 +255,11 @@ def cpu_all_cores(n, h, blocks_u8, template, procs, single_rate, seconds=4.0):
     for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
         os.environ[var] = "1"
     per_proc = int(max(4, min(len(blocks_u8), single_rate * seconds)))
-    jobs = [(n, h, blocks_u8[(i * per_proc) % max(1, len(blocks_u8) - per_proc + 1):][:per_proc], template)
-            for i in range(procs)]
+    jobs = [(n, h, blocks_u8[(i * per_proc) % max(1, len(blocks_u8) - per_proc + 1):][:per_proc], template,
+             tuple(window)) for i in range(procs)]
     ctx = mp.get_context("spawn")
     with ctx.Pool(procs) as pool:
-        pool.map(_oracle_worker, [(n, h, j[2][:2], template) for j in jobs])   # warm imports
+        pool.map(_oracle_worker, [(n, h, j[2][:2], template, tuple(window)) for j in jobs])   # warm imports
         t0 = time.perf_counter()
         done = pool.map(_oracle_worker, jobs)
         dt = time.perf_counter() - t0
@@ -297,10 +324,11 @@ def card_to_toad_leg(n_card):
             "first_lines_agree_on_rxid_time_block_sample_bin": bool(same)}
 
 
-def preflight(torch, dist, dev, rank, world, local, total, first):
+def preflight(torch, dist, dev, cdev, rank, world, local, total, first, shared_gpu=False):
     """Fail early and legibly if the process group is not what the launch line says: RCCL sees
-    `world` ranks, every rank has its own device, and the block ranges tile [0, world * total)."""
-    one = torch.ones(1, dtype=torch.int64, device=dev)
+    `world` ranks, every rank has its own device, and the block ranges tile [0, world * total).
+    (shared_gpu: the gloo rehearsal, where every rank computes on cuda:0 by design.)"""
+    one = torch.ones(1, dtype=torch.int64, device=cdev)
     dist.all_reduce(one)
     if int(one.item()) != world:
         raise SystemExit("pre-flight: all_reduce over %s counted %d ranks, expected %d"
@@ -313,7 +341,7 @@ def preflight(torch, dist, dev, rank, world, local, total, first):
     if rank == 0:
         spans = sorted(e["blocks"] for e in everyone)
         ok = spans[0][0] == 0 and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
-        if not ok or len({e["local_rank"] for e in everyone}) != world:
+        if not ok or (not shared_gpu and len({e["local_rank"] for e in everyone}) != world):
             raise SystemExit("pre-flight: ranks do not tile the block range / share a device: %r" % (everyone,))
         print("pre-flight ok: backend %s, %d rank(s); per-rank blocks: %s" % (
             dist.get_backend(), world, ", ".join("r%d@cuda:%d [%d, %d)" % (
@@ -326,7 +354,7 @@ class Leg(object):
     record buffers -- and the loops that run launch batches over them."""
 
     def __init__(self, torch, F, synth, dev, local, name, T=1, mix="dense", batch=0, resident=0, streams=0,
-                 pnum=0, seed_off=0, first=0):
+                 pnum=0, seed_off=0, first=0, carrier_window=WINDOW_BINS):
         cfg = CONFIGS[name]
         self.torch, self.F, self.dev, self.name, self.cfg = torch, F, dev, name, cfg
         self.n, self.h, self.T, self.mix, self.pnum = cfg["n"], cfg["h"], T, mix, pnum
@@ -336,7 +364,9 @@ class Leg(object):
         pad = self.h - self.wlen + 1
         self.window = (pad // 2, (self.n - self.wlen + 1) - (pad - pad // 2))
         n_handles = max(1, streams or cfg["streams"])
-        self.engs = [F.Engine(self.n, self.h, self.tpls, THRESH, WINDOW_BINS, THRESH, device_id=local,
+        self.cwin = tuple(carrier_window)
+        self.sectioned = self.n > 16384 and not pnum and bool(F.plan_sections(self.n, self.h, self.wlen))
+        self.engs = [F.Engine(self.n, self.h, self.tpls, THRESH, self.cwin, THRESH, device_id=local,
                               max_batch=self.B, preshift_num=pnum) for _ in range(n_handles)]
         self.resident_batches = max(1, (resident or cfg["resident"]) // self.B)
         self.total = self.resident_batches * self.B
@@ -409,8 +439,11 @@ class Leg(object):
         rename = {}
         if self.pnum:   # the fused kernel is timed in k_correlate's event slot
             rename["k_correlate"] = "k_preshift"
-        if self.n > 16384:   # long blocks: the correlate slot times the fused sub-transform + combination kernel
-            rename.update({"k_correlate": "k_correlate_sub", "k_carrier": "k_carrier_dit+k_select_dit"})
+        if self.n > 16384:
+            # long blocks: the correlate slot times k_correlate<SEG> over the (block, section) items --
+            # or, for templates too long to section, the fused sub-transform + combination kernel
+            rename.update({"k_correlate": "k_correlate_seg" if self.sectioned else "k_correlate_sub",
+                           "k_carrier": "k_carrier_dit+k_select_dit"})
         return {rename.get(k, k): v for k, v in prof.items() if v[1] > 0}
 
     def roofline(self, prof, solo_batches, fallback_ms):
@@ -424,22 +457,42 @@ class Leg(object):
             avg_ms = dom_ms / dom_cnt
             units = self.B * max(solo_batches, 1) / dom_cnt      # blocks one launch of it processes
         achieved = self.bytes_per_block * units / (avg_ms * 1e-3) / 1e9
-        traffic = clock = None
+        # HBM traffic from the committed PMC passes of this workload (profiles/hbm_traffic.json,
+        # scripts/profile_gpu.sh): the dominant kernel's, and the sum over every kernel of a launch
+        # batch (`pipeline_traffic`: each stage fetches the block again).  The file names the hash
+        # of the kernel sources it was measured on; `traffic_stale` says it is not today's.
+        traffic = clock = pipeline = stale = src = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                key = self.name + ("_t%d" % self.T if self.T > 1 else "") + ("_sparse" if self.mix != "dense" else "")
+                key = (self.name + ("_t%d" % self.T if self.T > 1 else "") + ("_sparse" if self.mix != "dense" else "")
+                       + ("_fullwin" if self.cwin != tuple(WINDOW_BINS) else ""))
                 per_kernel = json.load(open(tpath)).get(key, {})
                 # (the engine's carrier slot times whichever carrier kernel the window selects: the
-                # pruned one for the 7..110 window of these workloads)
-                alias = {"k_carrier": "k_carrier_pruned", "k_carrier_dit+k_select_dit": "k_carrier_dit"}
-                entry = per_kernel.get(dom) or per_kernel.get(alias.get(dom, ""), {})
-                traffic = entry.get("bytes_per_launch")
-                clock = entry.get("effective_clock_ghz")
+                # pruned one for the 7..110 window, the full-spectrum one for (0, -1))
+                alias = {"k_carrier": ["k_carrier" if self.cwin != tuple(WINDOW_BINS) else "k_carrier_pruned"],
+                         "k_carrier_dit+k_select_dit": ["k_carrier_dit", "k_select_dit"]}
+                def entries(k):
+                    return [per_kernel[a] for a in alias.get(k, [k]) if a in per_kernel]
+                if per_kernel:
+                    e = entries(dom)
+                    traffic = sum(x["bytes_per_launch"] for x in e) if e else None
+                    clock = e[0].get("effective_clock_ghz") if e else None
+                    every = [x for k in prof for x in entries(k)]
+                    if every and all(entries(k) for k in prof):
+                        pipeline = sum(x["bytes_per_launch"] for x in every)
+                    src = per_kernel.get("_source", {})
+                    stale = src.get("csrc_sha16") != csrc_sha16()
             except Exception:
-                traffic = clock = None
+                traffic = clock = pipeline = stale = None
         return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                # all kernels of one launch batch (carrier stage + fit + correlate + finish) / the
+                # batch's algorithmic bytes would be 1.0 if every block were fetched exactly once
+                "pipeline_traffic": pipeline,
+                "pipeline_traffic_over_algorithmic": (pipeline / (self.bytes_per_block * float(self.B))
+                                                      if pipeline else None),
+                "traffic_source": (src or {}).get("summary"), "traffic_stale": stale,
                 # GRBM_GUI_ACTIVE / duration of this kernel in the committed PMC pass (profiles/): the
                 # clock the part sustained under it (MI355X_MICROARCH.md, "DVFS give-back"); max 2.4
                 "effective_clock_ghz_profiled": clock, "avg_launch_ms": avg_ms,
@@ -454,9 +507,11 @@ class Leg(object):
                 "compute": _compute_view(dom, self.n, self.T, units, avg_ms)}
 
     def workload_text(self):
-        return ("BASELINE configs[%d]: %s, %s mix, %d blocks per GPU resident in HBM as u8 IQ"
+        return ("BASELINE configs[%d]: %s, %s mix, %d blocks per GPU resident in HBM as u8 IQ%s"
                 % (4 if (self.T > 1 and self.n == 16384) else self.cfg["idx"], self.cfg["label"], self.mix,
-                   self.total))
+                   self.total,
+                   "" if self.cwin == tuple(WINDOW_BINS) else
+                   "; carrier window %d..%d (the reference's default '0--1': every bin)" % self.cwin))
 
     def host_records(self, nblocks):
         return self.rec.view(self.total, self.T, 64)[:nblocks, 0].cpu().numpy().view(self.F.RECORD_DTYPE).reshape(-1)
@@ -517,12 +572,10 @@ def oracle_parity(n, h, blocks_u8, template, gpu_rec, procs):
 def extra_leg(torch, F, synth, dev, local, key, seconds, cpu_ok):
     """One bounded leg of the default run: another single-GPU workload of BASELINE.json's configs,
     timed over ~`seconds` after a calibration burst, with its own roofline object."""
-    spec = {"c3": dict(name="c3", T=1, mix="dense", batch=16384, resident=2 * 16384),
-            "t4": dict(name="c2", T=4, mix="dense", batch=16384, resident=4 * 16384),
-            "sparse": dict(name="c2", T=1, mix="sparse", batch=32768, resident=4 * 32768)}[key]
+    spec = LEGS[key]
     t_leg = time.perf_counter()
     leg = Leg(torch, F, synth, dev, local, spec["name"], T=spec["T"], mix=spec["mix"], batch=spec["batch"],
-              resident=spec["resident"], seed_off=17)
+              resident=spec["resident"], seed_off=17, carrier_window=spec.get("window", WINDOW_BINS))
     leg.timed(0, 2)                                           # code load, first-touch
     dt, _ = leg.timed(0, 4)                                   # calibration burst
     nb = int(max(8, min(4096, seconds / (dt / 4))))
@@ -557,6 +610,10 @@ def main():
 
     cfg = CONFIGS[args.config]
     n, h = cfg["n"], cfg["h"]
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N`: start the N ranks ourselves, exactly as the driver would
+        # (torch.distributed.run, one node, 127.0.0.1); rank 0 of the children prints the line
+        raise SystemExit(parallel.relaunch_under_torchrun(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -564,13 +621,24 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
+    gloo = args.dist_backend == "gloo"
+    if gloo:
+        local = 0           # rehearsal: every rank computes on cuda:0
+    elif local >= torch.cuda.device_count():
+        raise SystemExit("rank %d wants cuda:%d but %d device(s) are visible (one GPU per rank; "
+                         "--dist-backend gloo rehearses the N-rank body on one GPU)"
+                         % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = torch.device("cpu") if gloo else dev      # where the collectives' tensors live
     # under torchrun (RANK set) always bring RCCL up, even for one rank: the record gather
     # then runs through the same collectives as the multi-GPU case
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
     if use_dist:
-        dist.init_process_group("nccl", device_id=dev)
+        if gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     K, W, T = args.steps, args.warmup, args.templates
     pnum = args.preshift_num if args.variant == "preshift" else 0
@@ -578,8 +646,10 @@ def main():
     # distinct blocks resident in HBM: up to the config's limit (c2: 1 Mi blocks = 32 GiB of u8 =
     # BASELINE's "1M synthetic blocks"); longer runs cycle through them
     resident = min(cfg["resident"], max(B, K * B)) if args.min_seconds <= 0 else cfg["resident"]
+    if args.resident_blocks > 0:
+        resident = max(B, args.resident_blocks)
     leg = Leg(torch, F, synth, dev, local, args.config, T=T, mix=args.mix, batch=B, resident=resident,
-              streams=args.streams, pnum=pnum, seed_off=rank, first=0)
+              streams=args.streams, pnum=pnum, seed_off=rank, first=0, carrier_window=tuple(args.carrier_window))
     total = leg.total
     # contiguous block-index range per rank
     first = rank * total
@@ -589,7 +659,8 @@ def main():
     if len(engs) == 1:
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
     if use_dist:
-        preflight(torch, dist, dev, rank, world, local, total, first)
+        preflight(torch, dist, dev, cdev, rank, world, int(os.environ.get("LOCAL_RANK", "0")), total, first,
+                  shared_gpu=gloo)
     kept = torch.zeros_like(leg.rec)
     torch.cuda.synchronize()
 
@@ -604,7 +675,7 @@ def main():
     if args.min_seconds > 0:
         R = int(max(1, np.ceil(args.min_seconds * burst_rate / (K * B))))
     if use_dist:    # every rank must run the same step size: take rank 0's
-        r_t = torch.tensor([R], dtype=torch.int64, device=dev)
+        r_t = torch.tensor([R], dtype=torch.int64, device=cdev)
         dist.broadcast(r_t, 0)
         R = int(r_t.item())
     for i in range(W):
@@ -633,7 +704,7 @@ def main():
         profiled = (K * R + args.profile_kernels - 1) // args.profile_kernels
     # K7 + C1: compact detected records, gather them to rank 0 (the only collective)
     n_kept = eng.compact_device(leg.rec.data_ptr(), total * T, kept.data_ptr())
-    gathered = (parallel.gather_records(kept[:n_kept], world, rank, dev, force=use_dist)
+    gathered = (parallel.gather_records(kept[:n_kept].to(cdev), world, rank, cdev, force=use_dist)
                 if use_dist else kept[:n_kept])
     torch.cuda.synchronize()
     if use_dist:
@@ -641,8 +712,11 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof = leg.read_profile()
+    per_rank = [int(n_kept)]
     if use_dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, int(n_kept))      # (after the clock stopped: reporting only)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     # ---- one handle alone (what the roofline's solo kernel times belong to), a short leg
@@ -666,10 +740,13 @@ def main():
                        "variant": args.variant if not pnum else "preshift(num=%d)" % pnum,
                        "blocks_per_step_per_gpu": R * B, "launch_batches_per_step": R,
                        "blocks_per_launch_batch": B, "templates": T,
-                       "carrier_window": list(WINDOW_BINS), "thresholds": "15*snr",
+                       "carrier_window": list(leg.cwin), "thresholds": "15*snr",
                        "parallelism": "block-shard x%d" % world,
+                       "dist_backend": ((("gloo (rehearsal: every rank on cuda:0)" if gloo else "nccl (RCCL)"))
+                                        if use_dist else None),
                        "handles_per_gpu": len(engs),
-                       "detections_gathered": int(gathered.shape[0])},
+                       "detections_gathered": int(gathered.shape[0]),
+                       "detections_per_rank": per_rank},
             # the sustained-rate protocol (wall clock over >= 1 M blocks after warm-up)
             "timed_region_s": dt, "blocks_timed": blocks_total,
             "value_first_1Mi": burst_rate if args.min_seconds > 0 else None,
@@ -684,8 +761,8 @@ def main():
         }
         legs = []
         if args.legs == "auto":
-            legs = (["c3", "t4", "sparse"] if (world == 1 and args.config == "c2" and T == 1 and not pnum
-                                               and args.mix == "dense") else [])
+            legs = (list(LEGS) if (world == 1 and args.config == "c2" and T == 1 and not pnum
+                                   and args.mix == "dense") else [])
         elif args.legs != "none":
             legs = [x for x in args.legs.split(",") if x]
         host_blocks = gpu_rec = None
@@ -703,12 +780,13 @@ def main():
                 torch.cuda.empty_cache()
         if host_blocks is not None:
             line["cpu_baseline"] = cpu_baseline(n, h, host_blocks, np.arange(first, first + len(host_blocks)),
-                                                leg.tpls[0], args.cpu_seconds, gpu_rec, pnum)
+                                                leg.tpls[0], args.cpu_seconds, gpu_rec, pnum, leg.cwin)
             procs, how = physical_cores()
             if args.cpu_procs >= 0:
                 procs, how = args.cpu_procs, "--cpu-procs"
             if procs > 0 and not pnum:
-                ac = cpu_all_cores(n, h, host_blocks, leg.tpls[0], procs, line["cpu_baseline"]["value"])
+                ac = cpu_all_cores(n, h, host_blocks, leg.tpls[0], procs, line["cpu_baseline"]["value"],
+                                   window=leg.cwin)
                 ac["procs_from"] = how
                 line["cpu_baseline"]["all_cores"] = ac
             if args.card_blocks > 0 and args.config == "c2" and T == 1 and not pnum:

@@ -17,7 +17,7 @@ if os.path.exists(path):
     try:
         old = json.load(open(path))
         out = {k: v for k, v in old.items() if isinstance(v, dict) and all(isinstance(x, dict) for x in v.values())
-               and k in ("c2", "c2_t4", "c3", "c2_preshift", "c2_sparse")}
+               and k in ("c2", "c2_t4", "c3", "c3_t4", "c2_preshift", "c2_sparse", "c2_fullwin")}
     except Exception:
         out = {}
 for arg in sys.argv[1:]:
@@ -26,7 +26,8 @@ for arg in sys.argv[1:]:
     shutil.copy(os.path.join(src, "summary.md"), os.path.join(ROOT, "profiles", tag + "_rocprofv3_summary.md"))
     shutil.copy(os.path.join(src, "kernel_stats.csv"), os.path.join(ROOT, "profiles", tag + "_kernel_stats.csv"))
     out[key] = json.load(open(os.path.join(src, "hbm_traffic.json")))
-    out[key]["_source"] = {"summary": "profiles/%s_rocprofv3_summary.md" % tag,
+    sha = out[key].pop("_csrc_sha16", None)
+    out[key]["_source"] = {"csrc_sha16": sha, "summary": "profiles/%s_rocprofv3_summary.md" % tag,
                            "formula": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch: FETCH_SIZE doubled for "
                                       "gfx950 as MI355X_MICROARCH.md (HBM section) prescribes"}
 json.dump(out, open(path, "w"), indent=1, sort_keys=True)

@@ -17,6 +17,10 @@ def short(name):
     m = re.search(r"k_correlate_sub<\w+, \w+, \w+, (\w+)", name)
     if m:
         return "k_correlate_sub" if m.group(1) in ("true", "1") else "k_correlate_sub(two-kernel form)"
+    # k_correlate<FMT, STD, MULTI, DUMP, RLO, RHI, SEG>: SEG = the (block, section) items of long blocks
+    m = re.search(r"k_correlate<[^>]*, (\w+)>", name)
+    if m and m.group(1) in ("true", "1"):
+        return "k_correlate_seg"
     for k in ("k_carrier_pruned", "k_carrier_dit", "k_carrier_sub_pruned", "k_carrier_sub", "k_carrier_small",
               "k_carrier", "k_select_dit", "k_select", "k_fit_preshift", "k_fit", "k_finish",
               "k_correlate_sub", "k_correlate_small", "k_correlate", "k_combine", "k_preshift",
@@ -93,4 +97,7 @@ if acc:
             traffic[k] = {"fetch_kib_raw": f, "write_kib": w, "bytes_per_launch": int((2 * f + w) * 1024)}
             if k in clocks:
                 traffic[k]["effective_clock_ghz"] = clocks[k]
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from thrifty_amd import build
+    traffic["_csrc_sha16"] = build.csrc_hash()      # the kernel sources these counters belong to
     json.dump(traffic, open(os.path.join(root, "hbm_traffic.json"), "w"), indent=1)

@@ -257,6 +257,35 @@ def test_card_stream_rejects_malformed_lines():
     assert block_data.CardStream(io.BytesIO(b"# only comments\n\n"), 4096).next_batch(1) is None
 
 
+# ---------------------------------------------------------------- no hidden knobs in the shipped library
+def test_default_build_reads_no_environment_variables():
+    """A detector's output and scheduling depend on its settings and on thr_create_ex's explicit
+    arguments only.  The development switches (THR_DEV_STRIDE0 reads block 0's samples for every
+    block, THR_NO_PRUNE swaps the carrier kernel, the timeline stamps) exist only behind -DTHR_DEV,
+    which thrifty_amd/build.py never sets: the default library holds no THR_* name to look up."""
+    import subprocess
+    from thrifty_amd import build
+    lib = build.LIB
+    names = subprocess.check_output(["strings", "-a", lib]).decode("latin-1").split("\n")
+    assert [n for n in names if re.match(r"^THR_[A-Z0-9_]+$", n)] == []
+    # (the library does import getenv: rocPRIM's device-radix-sort configuration inside identify.hip
+    # reads its own variables; none of ours.)  In our sources every getenv sits inside #ifdef THR_DEV
+    csrc = os.path.join(ROOT, "thrifty_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".hpp")):
+            continue
+        depth_dev = []
+        for ln in open(os.path.join(csrc, f)):
+            t = ln.strip()
+            if t.startswith("#if"):
+                depth_dev.append(t.startswith("#ifdef THR_DEV"))
+            elif t.startswith("#endif") and depth_dev:
+                depth_dev.pop()
+            elif "getenv(" in t and not t.startswith("//"):
+                assert any(depth_dev), (f, t)
+    assert "THR_DEV" not in open(os.path.join(ROOT, "thrifty_amd", "build.py")).read()
+
+
 # ---------------------------------------------------------------- the product never touches the oracle
 def test_product_package_does_not_import_the_oracle():
     """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/:

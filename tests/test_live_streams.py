@@ -6,6 +6,7 @@ import threading
 import time
 
 import numpy as np
+import pytest
 
 from thrifty_amd import _native, block_data, detect, fastdet, toads_data
 
@@ -132,7 +133,7 @@ class _FakeEngine(object):
     open = 0
 
 
-def _bare_detector(recs, blocks, batch_size, max_wait=float("inf")):
+def _bare_detector(recs, blocks, batch_size, max_wait=float("inf"), max_fill=float("inf"), known_not_live=True):
     d = detect.Detector.__new__(detect.Detector)
     d.settings = detect.DetectorSettings(64, 16, 8, (0, 15, 0), (0, -1), np.ones(8), (0, 15, 0))
     d._card = d._raw = None
@@ -141,7 +142,8 @@ def _bare_detector(recs, blocks, batch_size, max_wait=float("inf")):
     d._engine = _FakeEngine(recs)
     from collections import deque
     d._ready, d._exhausted, d.only_detections = deque(), False, False
-    d._in_flight, d.max_wait = None, max_wait
+    d._in_flight, d.max_wait, d.max_fill = None, max_wait, max_fill
+    d._read_error, d._known_not_live = None, known_not_live
     return d
 
 
@@ -323,3 +325,97 @@ def test_a_live_source_is_not_read_ahead_of():
     w.close()
     assert [r.block for _, r in d] == [1, 2]
     assert eng.open == 0
+
+
+def test_a_source_that_does_not_say_whether_it_is_live_gets_bounded_latency_and_no_read_ahead():
+    """Any user generator / filter / socket reader has no `.live`.  It must neither be waited on
+    for a whole batch (batch_size blocks at a receiver's 200 blocks/s = seconds) nor be read
+    ahead of: filling a batch stops after `max_fill`, and the next batch is pulled only when the
+    caller asks for it."""
+    settings = detect.DetectorSettings(64, 16, 8, (0, 15, 0), (0, -1), np.ones(8), (0, 15, 0))
+    pulled = []
+
+    def slow():
+        for i in range(6):
+            time.sleep(0.03)
+            pulled.append(i)
+            yield float(i), i, np.zeros(64, dtype=np.complex64)
+
+    # what Detector.__init__ derives for such a source (no GPU here: the engine is faked)
+    assert getattr(slow(), "live", None) is None
+    recs = np.zeros(6, dtype=_native.RECORD_DTYPE)
+    d = _bare_detector(recs, slow(), batch_size=1024, max_fill=detect._UNKNOWN_FILL_S, known_not_live=False)
+    t0 = time.perf_counter()
+    first = next(d)
+    assert time.perf_counter() - t0 < 0.15 and first[1].block == 0
+    assert len(pulled) <= 3 and d._in_flight is None          # nothing pulled behind the caller's back
+    assert [r.block for _, r in d] == [1, 2, 3, 4, 5]
+    # a reader that declares itself file-backed fills whole batches and is read ahead of
+    class Listed(list):
+        live = False
+    assert detect.Detector.__init__.__defaults__ is not None
+    d2 = _bare_detector(recs, [(float(i), i, np.zeros(64, dtype=np.complex64)) for i in range(6)], batch_size=2)
+    next(d2)
+    assert d2._in_flight is not None
+
+
+def test_defaults_follow_the_live_attribute():
+    """max_wait / max_fill as Detector.__init__ derives them from `.live` (True / False / absent)."""
+    import inspect
+    src = inspect.getsource(detect.Detector.__init__)
+    assert "_UNKNOWN_FILL_S if live is None" in src and "_SLOW_SOURCE_S if live else" in src
+    assert detect._UNKNOWN_FILL_S <= 0.1 and detect._SLOW_SOURCE_S <= 0.01
+
+
+def test_an_error_in_the_read_ahead_does_not_swallow_the_batch_before_it():
+    """Reference: everything before a malformed line is emitted, then the loop dies.  The batch
+    that was being collected when the NEXT batch failed to read must still be handed out."""
+    recs = np.zeros(8, dtype=_native.RECORD_DTYPE)
+    recs["flags"] = 3
+
+    def source():
+        for i in range(5):
+            yield float(i), i, np.zeros(64, dtype=np.complex64)
+        raise ValueError("malformed .card line")
+
+    d = _bare_detector(recs, source(), batch_size=3)
+    out = []
+    with pytest.raises(ValueError, match="malformed"):
+        for det, res in d:
+            out.append(res.block)
+    assert out == [0, 1, 2, 3, 4]           # batch 0 AND the partial batch before the bad item
+    assert d._engine.open == 0
+    assert list(d) == []
+
+
+def test_a_partial_record_is_not_ready():
+    """A producer that does not flush at record boundaries (stdio's 4 KiB buffering) leaves half a
+    line / half a block in the pipe: next_batch() would block on it, so ready() must say no."""
+    raw = np.arange(128, dtype=np.uint8)
+    line = block_data.card_line(1.0, 0, raw).encode()
+    rfd, wfd = os.pipe()
+    with os.fdopen(rfd, "rb") as r, os.fdopen(wfd, "wb", buffering=0) as w:
+        cs = block_data.CardStream(r, 64)
+        w.write(b"# a comment line\n" + line[:40])
+        released = []
+        assert not cs.ready(release=lambda: released.append(1))      # half a line has arrived
+        assert released == [1]                                      # ... and was taken in, after release()
+        w.write(line[40:])
+        assert cs.ready()
+        assert cs.next_batch(8)[1].tolist() == [0]
+        assert not cs.ready()
+    rfd, wfd = os.pipe()
+    with os.fdopen(rfd, "rb") as r, os.fdopen(wfd, "wb", buffering=0) as w:
+        # (realistic sizes: reads larger than the BufferedReader's 8 KiB go straight to the pipe;
+        # smaller ones may park bytes in its internal buffer, where select() cannot see them --
+        # ready() then errs on the safe side and says no)
+        rs = block_data.RawStream(r, 8192, 2048)      # 12288 new bytes per block
+        step = 2 * (8192 - 2048)
+        w.write(bytes(step // 2))
+        assert not rs.ready()                          # half a block
+        w.write(bytes(step - step // 2))
+        assert rs.ready()
+        w.write(bytes(step * 3))
+        assert rs.next_batch(8)[0] == "c64" and rs.ready()       # the lead-in block; three more wait
+        got = rs.next_batch(8)
+        assert got[0] == "u8" and len(got[2]) == 3 and not rs.ready()

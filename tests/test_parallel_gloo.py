@@ -316,9 +316,28 @@ def test_sharded_env_needs_the_marker(monkeypatch):
     monkeypatch.setenv("WORLD_SIZE", "4")
     monkeypatch.delenv("THRIFTY_SHARDED", raising=False)
     assert parallel.sharded_env() == (0, None, 0)
+    monkeypatch.delenv("TORCHELASTIC_RUN_ID", raising=False)
+    assert parallel.sharded_env(4) == (0, None, 0)          # not torchrun's: `--gpus 4` re-launches
     monkeypatch.setenv("THRIFTY_SHARDED", "1")
     monkeypatch.setenv("LOCAL_RANK", "1")
     assert parallel.sharded_env() == (1, 4, 1)
+
+
+def test_a_rank_that_torchrun_started_directly_never_relaunches(monkeypatch):
+    """`torchrun --nproc-per-node 4 -m thrifty_amd.detect --gpus 4 ...`: every child sees RANK /
+    WORLD_SIZE and torchrun's run id but no THRIFTY_SHARDED.  It IS a rank (re-launching from
+    inside it would start 4 x 4 processes and four writers of one file); a world size that
+    contradicts --gpus is refused, and without --gpus the environment is ignored."""
+    monkeypatch.delenv("THRIFTY_SHARDED", raising=False)
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "none")
+    monkeypatch.setenv("RANK", "2")
+    monkeypatch.setenv("LOCAL_RANK", "2")
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    assert parallel.sharded_env(4) == (2, 4, 2)
+    assert parallel.sharded_env(1) == (0, None, 0)
+    with pytest.raises(SystemExit) as exc:
+        parallel.sharded_env(8)
+    assert "4 ranks" in str(exc.value)
 
 
 def test_gpus_without_an_output_file_is_refused():

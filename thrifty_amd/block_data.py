@@ -239,12 +239,35 @@ class CardStream(object):
         """True if the input is a regular file read through mmap (no read buffer of our own)."""
         return isinstance(self._buf, mmap.mmap)
 
-    def ready(self):
-        """True if next_batch() would not have to WAIT for the source: a mapped file, unconsumed
-        text in the buffer, or a descriptor that is readable right now (data or EOF).  A Detector
-        only reads ahead of the batch it is about to hand out when this holds -- on a live pipe the
-        results of what HAS arrived must not wait for the next line."""
-        return self.mapped or self._eof or self._end > self._pos or _readable_within(self.stream, 0)
+    def _has_complete_record(self):
+        """A whole DATA line (newline included) is buffered at or after the read position."""
+        p, end, buf = self._pos, self._end, self._buf
+        while p < end:
+            k = buf.find(b"\n", p, end)
+            if k < 0:
+                return False
+            c = buf[p]
+            if not (c in (0x23, 0x0A, 0x0D) or buf[p:p + 19] == b"Using Volk machine:" or buf[p:p + 6] == b"linux;"):
+                return True
+            p = k + 1       # comment / blank / banner line: next_batch skips it
+        return False
+
+    def ready(self, release=None):
+        """True if next_batch() would not have to WAIT for the source: a mapped file, the end of
+        the stream, or a COMPLETE record in the buffer -- a partial line (a producer that does not
+        flush at line ends) is not one.  Bytes waiting in the pipe are taken in first (what has
+        arrived, never blocking); that rewrites the buffer the previous batch's text lives in, so
+        `release` -- a callable that returns once the engine has copied that text -- is called
+        before.  A Detector only reads ahead of the batch it is about to hand out when this holds:
+        on a live pipe the results of what HAS arrived must not wait for the next line."""
+        if self.mapped or self._eof or self._has_complete_record():
+            return True
+        if not _readable_within(self.stream, 0):
+            return False
+        if release is not None:
+            release()
+        self._fill()
+        return self._eof or self._has_complete_record()
 
     def shard(self, rank, world):
         """Restrict a mapped .card file to the rank-th of `world` contiguous byte ranges, cut at
@@ -424,12 +447,31 @@ class RawStream(object):
         """True if the input is a regular file read through mmap."""
         return self._map is not None
 
-    def ready(self):
-        """True if next_batch() would not have to WAIT for the source (see CardStream.ready)."""
+    def ready(self, release=None):
+        """True if next_batch() would not have to WAIT for the source: a mapped file, the end of
+        the stream, or a whole block's worth of new samples buffered (see CardStream.ready; bytes
+        waiting in the pipe are taken in first, after `release()`)."""
         if self._map is not None or self._eof:
             return True
-        pending = self._have - self._consumed - 2 * self.history
-        return pending >= 2 * self.new or _readable_within(self.stream, 0)
+        carry, step = 2 * self.history, 2 * self.new
+        if self._have - self._consumed - carry >= step:
+            return True
+        if not _readable_within(self.stream, 0):
+            return False
+        if release is not None:
+            release()
+        self._slide(self._consumed)
+        self._consumed = 0
+        if len(self._buf) < carry + step:          # (room for one block at least; next_batch grows it)
+            self._buf.extend(bytes(carry + step - len(self._buf)))
+        if len(self._buf) > self._have:
+            view = memoryview(self._buf)[self._have:]
+            got = _read_arrived(self.stream, view)
+            del view
+            if got == 0:
+                self._eof = True
+            self._have += got
+        return self._eof or self._have - carry >= step
 
     def shard(self, rank, world):
         """Restrict a mapped raw file to this rank's contiguous block range.  The lead-in blocks
@@ -459,7 +501,10 @@ class RawStream(object):
         need_end = want_end if need_end is None else need_end
         if len(self._buf) < want_end:
             self._buf.extend(bytes(want_end - len(self._buf)))
-        while self._have < need_end and not self._eof:
+        # (bytes already waiting in the pipe are taken too, even if ready()'s top-up has satisfied
+        # `need_end` before this call: a batch is what HAS arrived, not the first block of it)
+        while not self._eof and (self._have < need_end or
+                                 (self._have < want_end and _readable_within(self.stream, 0))):
             view = memoryview(self._buf)[self._have:want_end]
             got = _read_arrived(self.stream, view)
             del view

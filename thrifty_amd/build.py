@@ -25,8 +25,25 @@ def _hipcc():
     return exe
 
 
+def csrc_hash():
+    """sha256 (first 16 hex digits) over the kernel sources and headers: profiles/hbm_traffic.json
+    records the hash its counter passes were taken on, bench.py flags a mismatch (`traffic_stale`)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(SOURCES + [x for x in HEADERS if not x.startswith("..")]):
+        h.update(name.encode())
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(LIB):
+        return True
+    try:       # objects / library of another flag set (a dev variant): rebuild
+        if open(os.path.join(CSRC, ".build_flags")).read() != " ".join(os.environ.get("THR_EXTRA_CFLAGS", "").split()):
+            return True
+    except OSError:
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
@@ -43,13 +60,27 @@ def build_native(force=False, verbose=False):
     jobs = []
     objs = []
     # an object is rebuilt when its source, any shared header or this file is newer than it (every
-    # translation unit includes the shared headers); THR_EXTRA_CFLAGS builds are never reused
+    # translation unit includes the shared headers) -- or when the objects on disk were compiled
+    # with a different flag set: the stamp file names the THR_EXTRA_CFLAGS they belong to, so a
+    # default build after a dev-variant build (scripts/build_variant.sh) never links leftovers
     common = [os.path.join(CSRC, hname) for hname in HEADERS] + [os.path.abspath(__file__)]
     newest_common = max(os.path.getmtime(d) for d in common)
+    stamp = os.path.join(CSRC, ".build_flags")
+    flags_now = " ".join(extra)
+    try:
+        flags_then = open(stamp).read()
+    except OSError:
+        flags_then = None
+    if flags_then != flags_now:
+        force = True
+        if os.path.exists(LIB):
+            os.remove(LIB)           # a half-finished rebuild must not leave a mixed library behind
+        with open(stamp, "w") as f:
+            f.write(flags_now)
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(obj)
-        if (not force and not extra and os.path.exists(obj) and
+        if (not force and os.path.exists(obj) and
                 os.path.getmtime(obj) > max(newest_common, os.path.getmtime(os.path.join(CSRC, src)))):
             continue
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",

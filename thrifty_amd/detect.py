@@ -29,6 +29,7 @@ DetectorSettings = namedtuple("DetectorSettings", [
 
 
 _SLOW_SOURCE_S = 0.002   # inter-arrival time above which a LIVE source ends the batch being filled
+_UNKNOWN_FILL_S = 0.05   # a source that does not say whether it is live: longest time spent FILLING one batch
 _YIELD_DATA_BATCH = 64    # blocks per batch with yield_data (each drags two N-point dumps along)
 
 
@@ -62,19 +63,32 @@ class Detector(object):
     _multi = False            # MultiTemplateDetector: settings.template is [n_templates, len]
 
     def __init__(self, settings, blocks=None, rxid=-1, yield_data=False, batch_size=None,
-                 device_id=0, _preshift_num=0, _fastdet=False, max_wait=None):
-        """`max_wait` (seconds): a classic `(timestamp, idx, block)` iterator whose next() takes
-        longer than this ends the batch being filled (what has arrived is processed instead of
-        waiting for a full batch).  Default: 2 ms if the source says it is live (`.live` true: a
-        reader over a pipe / tty), else no limit -- a CPU-bound iterator (host decode, gzip, a GC
-        pause) is slow without being live, and one-block batches would only make it slower."""
+                 device_id=0, _preshift_num=0, _fastdet=False, max_wait=None, max_fill=None):
+        """Batching a classic `(timestamp, idx, block)` iterator must not hold results back the way
+        the reference's per-block loop never did.  What ends the batch being filled (what has
+        arrived is processed instead of waiting for a full batch) depends on what the source says
+        about itself through a `.live` attribute (block_data's readers have one; a wrapper around
+        them should pass it on):
+          * `.live` true (a reader over a pipe / socket / tty): a next() that takes longer than
+            `max_wait` (default 2 ms) ends the batch, and the following batch is never read ahead;
+          * `.live` false (a regular file, an in-memory list): no limit, batches fill up and the
+            next one is read while this one's results are handed out;
+          * no `.live` at all (any user generator, filter or socket reader): a batch is filled for
+            at most `max_fill` seconds (default 50 ms) and never read ahead -- a CPU-bound source
+            (host decode, gzip) still gets batches of hundreds of blocks, a live one a latency of
+            50 ms instead of batch_size blocks' worth of waiting.
+        `max_wait` / `max_fill` given explicitly apply to any source."""
         if batch_size is None:      # ~64 MiB of u8 samples per engine batch (the staging chunk size)
             batch_size = max(64, min(65536, (64 << 20) // (2 * int(settings.block_len))))
             if yield_data:          # every block of a batch holds two N-point stage dumps in _ready
                 batch_size = min(batch_size, _YIELD_DATA_BATCH)
+        live = getattr(blocks, "live", None)
+        self._known_not_live = live is not None and not live
         if max_wait is None:
-            max_wait = _SLOW_SOURCE_S if getattr(blocks, "live", False) else float("inf")
-        self.max_wait = float(max_wait)
+            max_wait = _SLOW_SOURCE_S if live else float("inf")
+        if max_fill is None:
+            max_fill = _UNKNOWN_FILL_S if live is None else float("inf")
+        self.max_wait, self.max_fill = float(max_wait), float(max_fill)
         self.settings = settings
         # a CardStream is consumed in whole batches with the base64 payloads decoded on the GPU
         self._card = blocks if isinstance(blocks, CardStream) and not yield_data else None
@@ -98,6 +112,7 @@ class Detector(object):
         self._ready = deque()
         self._exhausted = False
         self._in_flight = None      # the submitted batch whose records have not been collected yet
+        self._read_error = None     # an exception the read-ahead hit: raised once the batch before it is out
         # batch readers only (CardStream / RawStream): hand out detections only, skipping the
         # per-block Python objects of everything else (set by detector_cli under --quiet)
         self.only_detections = False
@@ -229,7 +244,7 @@ class Detector(object):
         before that batch's host-to-device copies are done (a mapped file is never overwritten)."""
         reader = self._card if self._card is not None else self._raw
         if prev is not None and reader is not None and not reader.mapped:
-            self._engine.inputs_consumed(prev)
+            self._engine.inputs_consumed(prev)      # (again after _may_read_ahead's: returns at once)
         if self._card is not None:
             batch = self._card.next_batch(self.batch_size)
             if batch is None:
@@ -248,15 +263,23 @@ class Detector(object):
             # lead-in blocks that still contain the all-zero initial history
             return stamps, idxs, self._engine.submit(data, idxs)
         items = []
+        t_fill = time.perf_counter()
         while len(items) < self.batch_size and not self._exhausted:
             t0 = time.perf_counter()
             try:
                 items.append(next(self.blocks))
             except StopIteration:
                 self._exhausted = True
+            except Exception as exc:
+                if not items:
+                    raise
+                # the blocks read before the bad one are still processed and handed out (the
+                # reference's loop had emitted them); the error follows them
+                self._read_error, self._exhausted = exc, True
             # a live source slower than ~500 blocks/s (a receiver delivers ~200) gains nothing
             # from batching: process what has arrived instead of waiting for a full batch
-            if time.perf_counter() - t0 > self.max_wait:
+            now = time.perf_counter()
+            if now - t0 > self.max_wait or now - t_fill > self.max_fill:
                 break
         if not items:
             return None
@@ -270,28 +293,37 @@ class Detector(object):
         """-> (stamps, idxs, recs) of the next batch in input order, or None at the end.  The
         batch after it is submitted BEFORE this one is waited for, so the device (and the H2D
         staging of the next inputs) works while the caller formats what it was handed."""
+        if self._in_flight is None and self._read_error is not None:
+            exc, self._read_error = self._read_error, None
+            self._exhausted = True
+            raise exc
         cur = self._in_flight if self._in_flight is not None else self._submit_next()
         self._in_flight = None
         if cur is None:
             return None
         if self.yield_data:
             return cur
-        if not self._exhausted and self._may_read_ahead():
+        if not self._exhausted and self._read_error is None and self._may_read_ahead(cur[2]):
             try:
                 self._in_flight = self._submit_next(cur[2])
-            except Exception:
-                self._engine.collect(cur[2])     # never leave a ticket open behind an error
-                raise
+            except Exception as exc:
+                # the NEXT batch is unreadable (a malformed line, an engine error): this batch's
+                # results still go out first, as the reference's per-line loop would have emitted
+                # everything before the bad input; the error is raised by the call after this one
+                self._read_error = exc
         stamps, idxs, ticket = cur
         return self._flat(stamps, idxs, self._engine.collect(ticket))
 
-    def _may_read_ahead(self):
+    def _may_read_ahead(self, prev=None):
         """Reading the NEXT batch before handing out this one must not delay it: fine on files and
-        on sources with data pending, not on a live source that would have to be waited for."""
+        on readers that hold a whole record already, not on a source that may have to be waited
+        for -- a live one, or one that does not say (`.live` absent).  `prev`: the ticket in
+        flight; a reader that tops up its ONE buffer waits for that batch's copies first."""
         reader = self._card if self._card is not None else self._raw
         if reader is not None:
-            return reader.ready()
-        return self.max_wait == float("inf")
+            return reader.ready(release=None if prev is None or reader.mapped
+                                else (lambda: self._engine.inputs_consumed(prev)))
+        return self._known_not_live
 
     def _package(self, results, groups):
         """Flat per-record results -> the items next() hands out (this class: as they are)."""
@@ -315,7 +347,7 @@ class Detector(object):
         self._ready.extend(self._package(self._results(stamps, idxs, recs), groups))
 
     def _more(self):
-        return not self._exhausted or self._in_flight is not None
+        return not self._exhausted or self._in_flight is not None or self._read_error is not None
 
     def iter_detected_records(self):
         """Batches of (timestamps float64[k], records[k]) of the DETECTED blocks only, in input
@@ -513,10 +545,10 @@ def detector_cli(detector_class, parser=None, extra_args=None, argv=None):
     from thrifty_amd import parallel
     argv = list(sys.argv[1:] if argv is None else argv)
     gpus = parallel.peek_gpus(argv)
-    # a rank of a sharded run is a process that THIS CLI re-launched (or that was started with
-    # THRIFTY_SHARDED=1 on purpose): RANK / WORLD_SIZE inherited from an unrelated torchrun, MPI
-    # wrapper or container job do not turn a plain `thrifty detect` into one
-    rank, world, local = parallel.sharded_env()
+    # a rank of a sharded run is a process that THIS CLI re-launched, or that torchrun started
+    # with as many ranks as --gpus asks for; RANK / WORLD_SIZE inherited from an unrelated
+    # launcher do not turn a plain `thrifty detect` into one (parallel.sharded_env)
+    rank, world, local = parallel.sharded_env(gpus)
     if gpus > 1 and world is None:
         if not any(a in ("-o", "--output", "-a", "--append") or a.startswith(("--output=", "--append="))
                    or (a[:2] in ("-o", "-a") and len(a) > 2 and a[1] != "-") for a in argv):

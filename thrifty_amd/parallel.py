@@ -66,11 +66,25 @@ def torchrun_env():
     return 0, None, 0
 
 
-def sharded_env():
-    """(rank, world, local_rank) of a rank that `relaunch_under_torchrun` started (it sets
-    THRIFTY_SHARDED=1), else (0, None, 0) -- whatever RANK / WORLD_SIZE the environment holds."""
+def sharded_env(gpus=1):
+    """(rank, world, local_rank) of a rank of a sharded `--gpus N` run, else (0, None, 0).
+
+    A rank is a process that `relaunch_under_torchrun` started (it sets THRIFTY_SHARDED=1) -- or one
+    that the user started with torch.distributed.run themselves (`torchrun ... -m
+    thrifty_amd.detect --gpus N`: torchrun's own TORCHELASTIC_RUN_ID is set and WORLD_SIZE == N):
+    such a process must never re-launch, or N ranks would start N x N processes writing one file.
+    RANK / WORLD_SIZE of a different size under `--gpus N` is refused; without `--gpus` whatever
+    RANK / WORLD_SIZE an unrelated launcher, MPI wrapper or container job left in the
+    environment does not turn a plain `thrifty detect` into a rank."""
     if os.environ.get("THRIFTY_SHARDED") == "1":
         return torchrun_env()
+    rank, world, local = torchrun_env()
+    if gpus > 1 and world is not None and "TORCHELASTIC_RUN_ID" in os.environ:
+        if world != gpus:
+            raise SystemExit("--gpus %d inside a torch.distributed.run job of %d ranks: start one rank "
+                             "per GPU (--nproc-per-node %d) or drop the launcher and let --gpus start "
+                             "the ranks" % (gpus, world, gpus))
+        return rank, world, local
     return 0, None, 0
 
 
