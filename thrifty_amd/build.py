@@ -26,11 +26,12 @@ def _hipcc():
 
 
 def csrc_hash():
-    """sha256 (first 16 hex digits) over the kernel sources and headers: profiles/hbm_traffic.json
-    records the hash its counter passes were taken on, bench.py flags a mismatch (`traffic_stale`)."""
+    """sha256 (first 16 hex digits) over the kernel sources and headers (everything but api.hip,
+    the host side): profiles/hbm_traffic.json records the hash its counter passes were taken on,
+    bench.py flags a mismatch (`traffic_stale`)."""
     import hashlib
     h = hashlib.sha256()
-    for name in sorted(SOURCES + [x for x in HEADERS if not x.startswith("..")]):
+    for name in sorted([x for x in SOURCES if x != "api.hip"] + [x for x in HEADERS if not x.startswith("..")]):
         h.update(name.encode())
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(f.read())

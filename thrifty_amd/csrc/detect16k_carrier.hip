@@ -24,7 +24,28 @@ using namespace k16;
 // =========================================================================
 // K_A: carrier stage
 // =========================================================================
-template <int FMT, bool WANT_STD, bool DUMP>
+// For a power pmax > 0: *mag = sqrtf(pmax) (correctly rounded) and the return value is the smallest
+// float p with sqrtf(p) == *mag -- every power in [that, pmax] has the maximum's float32 magnitude.
+// A correctly rounded square root is monotone, so the set is an interval; its lower edge is the
+// square of the midpoint between *mag and its predecessor (exact in double: 25 bits squared), which
+// no float equals (an odd 25-bit integer squared is odd: 49 or 50 significant bits), so there are
+// no ties to break.  pmax <= 0 (an all-zero window): 0, everything ties.
+__device__ __forceinline__ float sqrt_preimage_lo(float pmax, float* mag) {
+    const float m = sqrtf(pmax > 0.f ? pmax : 0.f);
+    *mag = m;
+    if (!(m > 0.f)) return 0.f;
+    if (!(m < __builtin_inff())) return pmax;    // (overflowed power: only itself)
+    const float below = __uint_as_float(__float_as_uint(m) - 1u);
+    const double mid = 0.5 * (double(m) + double(below));
+    const double lo = mid * mid;
+    float f = float(lo);
+    if (double(f) <= lo) f = __uint_as_float(__float_as_uint(f) + 1u);
+    return f;
+}
+
+// ALLBINS: the window is the whole spectrum -- the reference's default carrier_window '0--1'
+// (settings.py:75-80): no window test, and a thread's bins ascend with k3.
+template <int FMT, bool WANT_STD, bool DUMP, bool ALLBINS>
 __global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples, int n_blocks,
                                                 DevCfg cfg, const cpx* __restrict__ tables,
                                                 CarStats* __restrict__ stats,
@@ -46,7 +67,8 @@ __global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples
                  opaque_tid());
     for (int b = blockIdx.x; b < n_blocks; b += gridDim.x) {
         // (previous block's pass-3 LDS reads all precede its reduction barrier)
-        fwd_pass1_pre(lds, cur, tw0, tw1);
+        float energy;
+        fwd_pass1_pre(lds, cur, tw0, tw1, &energy);
         // next block's samples, into the registers pass 1 has just consumed: issued now, used
         // one iteration later (no second register set, no copies)
         if (b + int(gridDim.x) < n_blocks)
@@ -60,38 +82,66 @@ __global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples
         fwd_pass3(lds, v);
 
         // ---- statistics over the spectrum held in registers
+        // First-max inside the (wrapping) window over float32 MAGNITUDES, as the reference takes it
+        // (np.argmax of np.abs, carrier_detect.py:146): powers an ulp apart can round to the same
+        // |X|, and then the lowest window index wins.  Taking sqrtf of all 32 bins and comparing
+        // (|X|, index) pairs bin by bin cost more than the transform itself (1100 of the kernel's
+        // 2000 instructions per wave and block); instead: the maximum POWER first (one v_max3 per
+        // two bins, a DPP max per wave), ONE correctly rounded sqrtf of it per wave, the smallest
+        // power that still rounds to that magnitude (sqrt_preimage_lo), and a second sweep that
+        // names the lowest window index among the bins at or above it -- the same bin the
+        // bin-by-bin comparison finds: sqrtf is monotone, so exactly the powers in [plo, max] share
+        // the maximum's magnitude.  Across waves the key (|X| bits, -index) decides as before.
         const int t = opaque_tid();
         const int kbase = (t >> 5) + 16 * (t & 31);
-        float sums[2] = {0.f, 0.f};
-        float pw[R3];
-        // first-max inside the (wrapping) window over float32 MAGNITUDES, as the reference takes
-        // it (np.argmax of np.abs, carrier_detect.py:146): powers an ulp apart can round to the
-        // same |X|, and then the lowest window index wins.  This thread's bins are visited in
-        // increasing k, which is increasing window index except across the wrap -- so compare
-        // (|X|, wi) lexicographically via '>' / '==' + '<'
-        float bestm = -1.0f;
-        unsigned bestwi = 0;
+        float pw[R3];          // powers (the seven neighbours of the peak are picked from them)
+        float ew[R3];          // the same inside the window, -1 outside
+        float tmax = -1.0f;
+        float smag = 0.f;
+        const unsigned wbase = unsigned(kbase - cfg.win_lo);
         static_for<R3>([&](auto K) {
             constexpr int k3 = decltype(K)::value;
             const float p = cnorm(v[brev(k3, R3)]);
-            const float m = sqrtf(p);
-            pw[k3] = m;
-            sums[0] += p;
-            if constexpr (WANT_STD) sums[1] += m;
-            const unsigned wi = unsigned(kbase + 512 * k3 - cfg.win_lo) & unsigned(N - 1);
-            const bool take = wi < unsigned(cfg.win_count) &&
-                              (m > bestm || (m == bestm && wi < bestwi));
-            bestm = take ? m : bestm;
-            bestwi = take ? wi : bestwi;
+            pw[k3] = p;
+            if constexpr (WANT_STD) smag += __builtin_amdgcn_sqrtf(p);
+            if constexpr (ALLBINS) {
+                ew[k3] = p;
+            } else {
+                const unsigned wi = (wbase + unsigned(512 * k3)) & unsigned(N - 1);
+                ew[k3] = wi < unsigned(cfg.win_count) ? p : -1.0f;
+            }
+            tmax = __builtin_fmaxf(tmax, ew[k3]);
         });
+        const float wmax = wave_max_f32(tmax);
+        float wmag;
+        const float plo = sqrt_preimage_lo(wmax, &wmag);
+        // second sweep: lowest window index among the bins whose power is >= plo.  Almost no bin
+        // is: the test of a bin is ONE v_cmp and a wave-uniform branch over its (empty) lane mask
+        unsigned cand = 0xFFFFFFFFu;
+        static_for<R3>([&](auto K) {
+            constexpr int k3 = R3 - 1 - decltype(K)::value;       // downwards: with ALLBINS the lowest sticks
+            const bool hit = ew[k3] >= plo;                        // (NaN, outside (-1): never; plo >= 0)
+            if (__builtin_amdgcn_ballot_w64(hit) != 0) {
+                if constexpr (ALLBINS) {
+                    cand = hit ? unsigned(kbase + 512 * k3) : cand;
+                } else {
+                    const unsigned wi = (wbase + unsigned(512 * k3)) & unsigned(N - 1);
+                    cand = (hit && wi < cand) ? wi : cand;
+                }
+            }
+        });
+        const unsigned wwi = wave_min_u32(cand);
         unsigned long long best =
-            bestm < 0.f ? 0ull
-                        : ((unsigned long long)__float_as_uint(bestm) << 32) | (0xFFFFFFFFu - bestwi);
+            wmax < 0.f ? 0ull : ((unsigned long long)__float_as_uint(wmag) << 32) | (0xFFFFFFFFu - wwi);
+        // sum |X|^2 = N sum |x|^2 (Parseval) from the samples pass 1 held; sum |X| only for the
+        // stddev term (v_sqrt_f32 to 1 ulp: it feeds a variance, not a comparison of bins)
+        float sums[2] = {energy, smag};
         double tot[2];
         block_reduce<WANT_STD ? 2 : 1, NT / 64, true>(reinterpret_cast<float(&)[WANT_STD ? 2 : 1]>(sums),
                                        reinterpret_cast<double(&)[WANT_STD ? 2 : 1]>(tot), best,
                                        sc_red, parity);
         parity ^= 1;
+        tot[0] *= double(N);
         const unsigned wi = 0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu);
         int peak_idx = int(wi) + cfg.win_lo;
         if (peak_idx > N) peak_idx -= N;  // sic: '>' (carrier_detect.py:151)
@@ -103,12 +153,14 @@ __global__ __launch_bounds__(NT) void k_carrier(const void* __restrict__ samples
         {
             const unsigned u = unsigned(kbase - peak_idx + 3) & unsigned(N - 1);
             const unsigned r = u & 511u, k3s = (32u - (u >> 9)) & 31u;
-            float val = 0.f;
-            static_for<R3>([&](auto K) {
-                constexpr int k3 = decltype(K)::value;
-                val = (k3s == unsigned(k3)) ? pw[k3] : val;
-            });
-            if (r < 7u) st->nb[r] = val;
+            if (r < 7u) {      // (at most two lanes of a wave, none in half of the waves)
+                float val = 0.f;
+                static_for<R3>([&](auto K) {
+                    constexpr int k3 = decltype(K)::value;
+                    val = (k3s == unsigned(k3)) ? pw[k3] : val;
+                });
+                st->nb[r] = sqrtf(val);
+            }
         }
         if constexpr (DUMP) {
             cpx* out = dump_fft + size_t(b) * N;
@@ -568,16 +620,18 @@ namespace {
 typedef void (*carrier_fn)(const void*, int, DevCfg, const cpx*, CarStats*, cpx*);
 
 #ifdef THR_DEV_MINIMAL  // compile-time experiments only: one variant each, fast rebuilds
-carrier_fn carrier_variant(int, bool, bool) { return &k_carrier<THR_IN_U8, false, false>; }
+carrier_fn carrier_variant(int, bool, bool, bool) { return &k_carrier<THR_IN_U8, false, false, true>; }
 #else
 template <int FMT, bool STD>
-carrier_fn pick_carrier(bool dump) {
-    return dump ? &k_carrier<FMT, STD, true> : &k_carrier<FMT, STD, false>;
+carrier_fn pick_carrier(bool dump, bool all) {
+    // (stage dumps: the windowed form serves every window)
+    if (dump) return &k_carrier<FMT, STD, true, false>;
+    return all ? &k_carrier<FMT, STD, false, true> : &k_carrier<FMT, STD, false, false>;
 }
-carrier_fn carrier_variant(int fmt, bool want_std, bool dump) {
+carrier_fn carrier_variant(int fmt, bool want_std, bool dump, bool all) {
     if (fmt == THR_IN_U8)
-        return want_std ? pick_carrier<THR_IN_U8, true>(dump) : pick_carrier<THR_IN_U8, false>(dump);
-    return want_std ? pick_carrier<THR_IN_C64, true>(dump) : pick_carrier<THR_IN_C64, false>(dump);
+        return want_std ? pick_carrier<THR_IN_U8, true>(dump, all) : pick_carrier<THR_IN_U8, false>(dump, all);
+    return want_std ? pick_carrier<THR_IN_C64, true>(dump, all) : pick_carrier<THR_IN_C64, false>(dump, all);
 }
 #endif
 }  // namespace
@@ -593,9 +647,9 @@ hipError_t prepare_16k_carrier() {
     }
     for (int fmt = 0; fmt < 2; ++fmt)
         for (int st = 0; st < 2; ++st)
-            for (int d = 0; d < 2; ++d) {
+            for (int d = 0; d < 3; ++d) {     // dump, windowed, all bins
                 hipError_t e = hipFuncSetAttribute(
-                    reinterpret_cast<const void*>(carrier_variant(fmt, st, d)),
+                    reinterpret_cast<const void*>(carrier_variant(fmt, st, d == 0, d == 2)),
                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
                 if (e != hipSuccess) return e;
             }
@@ -615,7 +669,9 @@ hipError_t launch_carrier_16k(int fmt, const void* samples, int n_blocks, const 
                            reinterpret_cast<const cpx*>(tables), reinterpret_cast<const cpx*>(twn), stats);
         return hipGetLastError();
     }
-    carrier_fn fn = carrier_variant(fmt, cfg.car_want_std != 0, dump_fft != nullptr);
+    // (the whole spectrum as window: win_lo 0, every bin -- the reference's default '0--1')
+    carrier_fn fn = carrier_variant(fmt, cfg.car_want_std != 0, dump_fft != nullptr,
+                                    cfg.win_lo == 0 && cfg.win_count == N);
     hipLaunchKernelGGL(fn, dim3(grid), dim3(NT), LDS_BYTES, stream, samples, n_blocks, cfg,
                        reinterpret_cast<const cpx*>(tables), stats, reinterpret_cast<cpx*>(dump_fft));
     return hipGetLastError();
