@@ -30,7 +30,8 @@ extern "C" {
 /* 4: + thr_frame_card (addition only) */
 /* 5: + thr_submit / thr_submit_card / thr_submit_stream / thr_collect / thr_inputs_consumed / thr_poll (asynchronous host
  *    boundary), thr_set_stream_default, thr_format_toad (additions only) */
-/* 6: + thr_create_ex (explicit variant and kernel-path selection), thr_plan_sections (additions only).
+/* 6: + thr_create_ex (explicit variant and kernel-path selection), thr_plan_sections,
+ *    thr_host_register / thr_host_unregister, thr_input_window (additions only).
  *    No environment variable changes what a handle computes or how it schedules any more. */
 #define THR_ABI_VERSION 6
 
@@ -217,6 +218,35 @@ int thr_detect(thr_handle* h, const void* samples, int format, const int64_t* bl
 int thr_frame_card(const char* text, size_t text_len, int block_len, int at_eof, size_t max_records,
                    double* timestamps, int64_t* block_idx, int64_t* payload_off, size_t* n_records,
                    size_t* consumed);
+
+/*
+ * Page-lock caller memory that the host entry points read from -- typically the mmap of the input
+ * file (`thrifty detect rx.card` / `--raw`): the chunk copies of thr_detect / thr_detect_card /
+ * thr_detect_stream and their thr_submit_* forms then run as DMA straight from the page cache and
+ * RETURN AT ONCE, instead of occupying the calling thread for the length of each copy while the
+ * HIP runtime stages pageable memory (same PCIe rate either way -- measured 56 GB/s on MI355X --
+ * but the host thread frames the next chunk and formats the previous one's output meanwhile).
+ * Purely an optimisation: everything works on unregistered memory, and a failed registration
+ * (THR_ERR_DEVICE: locked-memory limit, exotic mapping) leaves nothing behind.  The range is
+ * widened to whole pages; read-only and private file mappings are fine.  No handle: the lock
+ * belongs to the process.  Unregister (same pointer) before unmapping; inputs of open tickets
+ * must have been consumed (thr_inputs_consumed / thr_collect).
+ */
+int thr_host_register(const void* p, size_t bytes);
+int thr_host_unregister(const void* p);
+/*
+ * The streaming form, for inputs of any size: declare [p, p + bytes) -- the mmap of the input file
+ * -- as the window this handle's host entry points will read FRONT TO BACK.  A worker thread of
+ * the library page-locks it 128 MiB at a time, at most 1 GiB ahead of the chunk copies, and
+ * unlocks what they have left behind, so the locking costs neither the caller's time (it runs
+ * beside the copies: measured 10-40 ms per GiB, about what the staging of pageable memory costs the
+ * calling thread) nor more locked memory than that, however large the file.  Source ranges
+ * outside the window, behind its read position or far ahead of it are copied as ordinary pageable
+ * memory, as is everything once a lock is refused -- results never depend on the window.
+ * (NULL, 0) closes it; thr_destroy does too.  Not while tickets are open (THR_ERR_STATE).  The
+ * mapping must stay valid until the window is closed.
+ */
+int thr_input_window(thr_handle* h, const void* p, size_t bytes);
 
 int thr_detect_card(thr_handle* h, const char* text, size_t text_len, const int64_t* payload_off,
                     const int64_t* block_idx, size_t n_blocks, thr_record* out);

@@ -61,3 +61,83 @@ def test_bad_payloads_are_rejected(golden):
     _, idxs, buf, offs = CardStream(io.BytesIO(line.encode()), 16384).next_batch(4)
     rec = eng.detect_card(buf, offs, idxs)[:, 0]
     assert rec[0]["block_idx"] == 7 and rec[0]["corr_sample"] == g["sample"][0]
+
+
+def test_mapped_input_file_is_page_locked_and_gives_the_same_records(golden, tmp_path):
+    """`thrifty detect rx.card` / `--raw rx.bin` on a regular file: the mapping is the engine's
+    input window (thr_input_window: a library thread page-locks it ahead of the chunk copies, which
+    are then asynchronous DMA from the page cache), closed when the last batch is out; records are
+    those of the pageable path, byte for byte."""
+    g = golden("c2")
+    n = int(g["block_len"])
+    text = (card_text(g) * 40).encode()          # 640 lines: several engine batches of 64
+    path = tmp_path / "rx.card"
+    path.write_bytes(text)
+    outs = []
+    for pin in (True, False):
+        with open(path, "rb") as f:
+            det = Detector(settings_of(g), CardStream(f, n), rxid=0, batch_size=64, pin_input=pin)
+            assert det._pin == pin
+            outs.append(b"".join(det.iter_toad_text()))
+            assert det._pin is False                              # window closed at the end of the run
+    assert outs[0] == outs[1] and outs[0].count(b"\n") > 300
+    # raw stream file
+    raw = np.concatenate([g["blocks"][i][: 2 * (n - int(g["history_len"]))] for i in range(len(g["blocks"]))] * 8)
+    rpath = tmp_path / "rx.bin"
+    rpath.write_bytes(raw.tobytes())
+    routs = []
+    for pin in (True, False):
+        with open(rpath, "rb") as f:
+            det = Detector(settings_of(g), block_data.RawStream(f, n, int(g["history_len"])), rxid=0,
+                           batch_size=16, pin_input=pin)
+            assert det._pin == pin
+            routs.append([(d, r.block, r.soa) for d, r in det])
+    assert routs[0] == routs[1] and len(routs[0]) > 100
+    # thr_host_register (whole-range form) on an ordinary buffer: best effort, refusal is harmless
+    pin = F.HostPin(memoryview(bytearray(1 << 20)), limit=16)
+    assert not pin.ok and "limit" in pin.why
+    buf = np.zeros(1 << 22, dtype=np.uint8)
+    pin = F.HostPin(buf)
+    assert pin.ok, pin.why
+    pin.close()
+    assert not pin.ok
+
+
+def test_input_window_on_a_file_larger_than_the_lock_ahead_distance(golden, tmp_path):
+    """1.2 GB of .card text: more than the 1 GiB the worker may lock ahead, so segments are
+    locked, read and unlocked on the go; a second pass over the same Engine re-opens the window;
+    reading a range behind the window falls back to a pageable copy.  Same records every way."""
+    g = golden("c2")
+    n = int(g["block_len"])
+    lines = card_text(g).encode().split(b"\n")[:-1]
+    nlines = len(lines) * (30000 // len(lines))
+    path = tmp_path / "big.card"
+    with open(path, "wb") as f:
+        for i in range(nlines):
+            f.write(lines[i % len(lines)] + b"\n")
+    st = settings_of(g)
+    with open(path, "rb") as f:
+        det = Detector(st, CardStream(f, n), rxid=0)
+        assert det._pin and path.stat().st_size > (900 << 20)
+        text = b"".join(det.iter_toad_text())
+    per = b"".join(Detector(st, CardStream(io.BytesIO(b"\n".join(lines) + b"\n"), n), rxid=0).iter_toad_text())
+    assert per.count(b"\n") > 0 and text.count(b"\n") == per.count(b"\n") * (nlines // len(lines))
+    # an Engine with a window: a range behind the read position and a range outside it both work
+    import mmap
+    with open(path, "rb") as f:
+        mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+        cs = CardStream(io.BytesIO(b"\n".join(lines[i % len(lines)] for i in range(70)) + b"\n"), n)
+        stamps, idxs, buf, offs = cs.next_batch(64)
+        eng = engine_for(g, max_batch=64)
+        ref = eng.detect_card(buf, offs, idxs)
+        eng.input_window(mm)
+        cs2 = CardStream(f, n)
+        b2 = cs2.next_batch(64)
+        inside = eng.detect_card(b2[2], b2[3], b2[1])          # from the window
+        outside = eng.detect_card(buf, offs, idxs)              # a private copy: not in the window
+        again = eng.detect_card(b2[2], b2[3], b2[1])           # the same range once more
+        eng.input_window(None)
+        assert inside.tobytes() == ref.tobytes() == outside.tobytes() == again.tobytes()
+        eng.close()
+        del cs2, b2
+        mm.close()

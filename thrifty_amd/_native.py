@@ -24,7 +24,7 @@ ABI_VERSION = 6     # THR_ABI_VERSION of include/thrifty_hip.h
 
 EXPORTS = [
     "thr_abi_version", "thr_last_error", "thr_create", "thr_destroy", "thr_detect",
-    "thr_create_preshift", "thr_create_fastdet", "thr_create_ex", "thr_plan_sections", "thr_detect_card", "thr_detect_stream", "thr_detect_stream_device", "thr_detect_device", "thr_sync", "thr_set_stream", "thr_compact_device",
+    "thr_create_preshift", "thr_create_fastdet", "thr_create_ex", "thr_plan_sections", "thr_host_register", "thr_host_unregister", "thr_input_window", "thr_detect_card", "thr_detect_stream", "thr_detect_stream_device", "thr_detect_device", "thr_sync", "thr_set_stream", "thr_compact_device",
     "thr_profile_enable", "thr_profile_read", "thr_kernel_name", "thr_debug_fft",
     "thr_debug_stage", "thr_identify", "thr_frame_card",
     "thr_submit", "thr_submit_card", "thr_submit_stream", "thr_collect", "thr_inputs_consumed", "thr_poll",
@@ -114,6 +114,9 @@ def load_library():
     lib.thr_create.argtypes = [C.POINTER(ThrSettings), C.POINTER(vp)]
     lib.thr_create_preshift.argtypes = [C.POINTER(ThrSettings), C.c_int, C.POINTER(vp)]
     lib.thr_create_fastdet.argtypes = [C.POINTER(ThrSettings), C.POINTER(vp)]
+    lib.thr_input_window.argtypes = [vp, vp, C.c_size_t]
+    lib.thr_host_register.argtypes = [vp, C.c_size_t]
+    lib.thr_host_unregister.argtypes = [vp]
     ip = C.POINTER(C.c_int)
     lib.thr_plan_sections.argtypes = [C.c_int, C.c_int, C.c_int, ip] + [C.c_int * 8] * 5
     lib.thr_create_ex.argtypes = [C.POINTER(ThrSettings), C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
@@ -231,6 +234,54 @@ def identify(rxid, block, timestamp, carrier_bin, carrier_offset, energy, freq_r
     return txid, keep.astype(bool), order[:n_kept.value]
 
 
+class HostPin(object):
+    """thr_host_register over a bytes-like object (an mmap of the input file): page-locks it so
+    that the engine's chunk copies are asynchronous DMA out of the page cache.  Best effort:
+    `.ok` False (and nothing locked) if the range is larger than `limit` bytes -- by default a
+    quarter of the memory the kernel says is available -- or the runtime refuses; the engine
+    works the same on unlocked memory.  close() (or garbage collection) unlocks."""
+
+    def __init__(self, buf, limit=None):
+        self._ptr, self.ok, self.why = None, False, ""
+        arr = np.frombuffer(buf, dtype=np.uint8)
+        if limit is None:
+            limit = _available_memory() // 4
+        if arr.size == 0 or arr.size > limit:
+            self.why = "%d bytes against a limit of %d" % (arr.size, limit)
+            return
+        try:
+            lib = load_library()
+            rc = lib.thr_host_register(arr.ctypes.data, arr.size)
+        except Exception as exc:       # no library / no device: the caller's engine will say so itself
+            self.why = str(exc)
+            return
+        if rc != 0:
+            self.why = lib.thr_last_error().decode()
+            return
+        self._lib, self._ptr, self.ok = lib, arr.ctypes.data, True
+
+    def close(self):
+        if self._ptr is not None:
+            self._lib.thr_host_unregister(self._ptr)
+            self._ptr, self.ok = None, False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _available_memory():
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                return int(ln.split()[1]) * 1024
+    except (OSError, ValueError):
+        pass
+    return 1 << 33
+
+
 def plan_sections(block_len, history_len, template_len):
     """thr_plan_sections: the overlap-save plan of a long block's correlate stage (host-only).
     Returns a list of dicts (start, win_lo, win_hi, sum_lo, sum_hi), block coordinates; [] when the
@@ -282,8 +333,9 @@ class Engine(object):
 
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.thr_destroy(self._h)
+            self._lib.thr_destroy(self._h)      # (closes an input window too)
             self._h = None
+            self._window = None
 
     def __del__(self):
         try:
@@ -391,6 +443,19 @@ class Engine(object):
                                                       C.byref(got), C.byref(t)))
         assert got.value == nb
         return Ticket(t.value, out, None)
+
+    def input_window(self, buf=None):
+        """thr_input_window: declare `buf` (bytes-like: the mmap of the input file, or a slice of
+        it) as the range the host entry points will read front to back -- a library thread
+        page-locks it a bounded distance ahead of the copies, which then are asynchronous DMA.
+        None closes the window.  The caller keeps `buf` alive until then."""
+        if buf is None:
+            _check(self._lib, self._lib.thr_input_window(self._h, None, 0))
+            self._window = None
+            return
+        arr = np.frombuffer(buf, dtype=np.uint8)
+        _check(self._lib, self._lib.thr_input_window(self._h, arr.ctypes.data, arr.size))
+        self._window = arr
 
     def collect(self, ticket):
         """thr_collect: wait for the ticket's batch -> its records [B, n_templates]."""

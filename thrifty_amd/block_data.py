@@ -252,6 +252,13 @@ class CardStream(object):
             p = k + 1       # comment / blank / banner line: next_batch skips it
         return False
 
+    def mapped_span(self):
+        """The bytes of the mapped file this reader will hand out (its shard), as a memoryview --
+        what a consumer may page-lock for DMA (thrifty_amd._native.HostPin); None if not mapped."""
+        if not self.mapped:
+            return None
+        return memoryview(self._buf)[self._pos:self._end]
+
     def ready(self, release=None):
         """True if next_batch() would not have to WAIT for the source: a mapped file, the end of
         the stream, or a COMPLETE record in the buffer -- a partial line (a producer that does not
@@ -446,6 +453,18 @@ class RawStream(object):
     def mapped(self):
         """True if the input is a regular file read through mmap."""
         return self._map is not None
+
+    def mapped_span(self):
+        """The bytes of the mapped file this reader will hand out (its shard, with the history in
+        front of its first block), as a memoryview; None if not mapped (see CardStream)."""
+        if self._map is None:
+            return None
+        step, carry = 2 * self.new, 2 * self.history
+        lo = max(0, self._off - carry)
+        hi = len(self._map)
+        if self._stop_idx is not None:
+            hi = min(hi, self._off + max(0, self._stop_idx - self._next_idx) * step)
+        return memoryview(self._map)[lo:hi]
 
     def ready(self, release=None):
         """True if next_batch() would not have to WAIT for the source: a mapped file, the end of

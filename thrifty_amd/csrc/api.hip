@@ -8,7 +8,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <charconv>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
+
+#include <sys/mman.h>
 #include <utility>
 #include <vector>
 
@@ -93,6 +98,160 @@ struct EventPair {
 
 }  // namespace
 
+// thr_input_window(): a caller mapping (the input file) that the host entry points read
+// sequentially.  A worker thread page-locks it one 128 MiB segment at a time, a bounded distance
+// ahead of the chunk copies, and unlocks what lies behind them: the copies are then asynchronous
+// DMA out of the page cache (they return at once instead of occupying the calling thread while the
+// runtime stages pageable memory), the locking itself -- 10 to 40 ms per GiB, as much host time as
+// the staging it replaces -- runs beside the caller instead of in front of it, and never more than
+// kAhead segments are locked whatever the size of the file.
+struct InputWindow {
+    static constexpr size_t kSeg = size_t(128) << 20;
+    static constexpr size_t kAhead = 8;       // segments the worker may run ahead of `consumed` (1 GiB)
+    uintptr_t base = 0, end = 0;              // page-aligned span; base == 0: no window
+    size_t n_seg = 0;
+    size_t reg_lo = 0, reg_hi = 0;            // segments [reg_lo, reg_hi) are locked now
+    size_t consumed = 0;                      // segments below this one are not needed any more
+    bool stop = false, failed = false;
+    int device = 0;
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv;
+    // page-table population runs in front of the locking, on threads of its own: locking pages
+    // that are already mapped goes at ~100 GB/s, faulting them in one by one inside
+    // hipHostRegister at ~30 (measured), and the fabric copies run at 56
+    static constexpr int kPopulators = 3;
+    std::thread populators[kPopulators];
+    std::vector<unsigned char> populated;      // per segment: its pages are mapped
+    size_t pop_next = 0;                       // next segment a populator takes
+
+    void populate_run() {
+        std::unique_lock<std::mutex> lk(mu);
+        while (!stop) {
+            if (pop_next < consumed) pop_next = consumed;
+            if (pop_next < n_seg && pop_next < consumed + kAhead) {
+                const size_t sgm = pop_next++;
+                lk.unlock();
+                void* at = reinterpret_cast<void*>(seg_lo(sgm));
+#ifdef MADV_POPULATE_READ
+                int rc = madvise(at, seg_len(sgm), MADV_POPULATE_READ);
+#else
+                int rc = -1;
+#endif
+                if (rc != 0) {     // older kernels: touch a byte of every page
+                    volatile const unsigned char* q = static_cast<const unsigned char*>(at);
+                    unsigned acc = 0;
+                    for (size_t i = 0; i < seg_len(sgm); i += 4096) acc += q[i];
+                    (void)acc;
+                }
+                lk.lock();
+                populated[sgm] = 1;
+                cv.notify_all();
+                continue;
+            }
+            cv.wait(lk);
+        }
+    }
+
+    uintptr_t seg_lo(size_t s) const { return base + s * kSeg; }
+    size_t seg_len(size_t s) const { return size_t(std::min<uintptr_t>(end, seg_lo(s) + kSeg) - seg_lo(s)); }
+
+    void run() {
+        (void)hipSetDevice(device);
+        std::unique_lock<std::mutex> lk(mu);
+        while (!stop) {
+            if (reg_lo < std::min(consumed, reg_hi)) {
+                const size_t sgm = reg_lo;
+                lk.unlock();
+                (void)hipHostUnregister(reinterpret_cast<void*>(seg_lo(sgm)));
+                lk.lock();
+                ++reg_lo;
+                continue;
+            }
+            if (!failed && reg_hi < n_seg && reg_hi < consumed + kAhead) {
+                if (reg_hi < consumed) {      // the reader skipped ahead: nothing in between is wanted
+                    reg_lo = reg_hi = consumed;
+                    continue;
+                }
+                const size_t sgm = reg_hi;
+                if (!populated[sgm]) {        // (a populator has it, or will take it next)
+                    cv.wait(lk);
+                    continue;
+                }
+                lk.unlock();
+                const hipError_t rc = hipHostRegister(reinterpret_cast<void*>(seg_lo(sgm)), seg_len(sgm),
+                                                      hipHostRegisterDefault);
+                if (rc != hipSuccess) (void)hipGetLastError();
+                lk.lock();
+                if (rc == hipSuccess)
+                    ++reg_hi;
+                else
+                    failed = true;            // (locked-memory limit, exotic mapping): pageable copies from here on
+                cv.notify_all();
+                continue;
+            }
+            cv.wait(lk);
+        }
+        for (size_t sgm = reg_lo; sgm < reg_hi; ++sgm) {
+            lk.unlock();
+            (void)hipHostUnregister(reinterpret_cast<void*>(seg_lo(sgm)));
+            lk.lock();
+        }
+        reg_lo = reg_hi = 0;
+    }
+
+    void open(const void* p, size_t bytes, int dev) {
+        close();
+        const uintptr_t page = 4096;
+        base = reinterpret_cast<uintptr_t>(p) & ~(page - 1);
+        end = (reinterpret_cast<uintptr_t>(p) + bytes + page - 1) & ~(page - 1);
+        n_seg = size_t((end - base + kSeg - 1) / kSeg);
+        reg_lo = reg_hi = consumed = pop_next = 0;
+        populated.assign(n_seg, 0);
+        stop = failed = false;
+        device = dev;
+        worker = std::thread([this] { run(); });
+        for (auto& t : populators) t = std::thread([this] { populate_run(); });
+    }
+
+    void close() {
+        if (!worker.joinable()) return;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        worker.join();
+        for (auto& t : populators) t.join();
+        base = end = 0;
+        n_seg = 0;
+    }
+
+    // [src, src + bytes) is about to be copied: wait until its segments are locked.  False: copy
+    // it as pageable memory (outside the window, behind it, too far ahead, or locking failed).
+    bool acquire(const void* src, size_t bytes) {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(src);
+        if (base == 0 || bytes == 0 || a < base || a + bytes > end) return false;
+        const size_t s0 = size_t((a - base) / kSeg), s1 = size_t((a + bytes - 1 - base) / kSeg);
+        std::unique_lock<std::mutex> lk(mu);
+        if (failed || s0 < reg_lo || s1 >= consumed + kAhead) return false;
+        cv.wait(lk, [&] { return failed || reg_hi > s1; });
+        return !failed && s0 >= reg_lo;
+    }
+
+    // every copy that ends at or before `upto` has completed
+    void release_below(uintptr_t upto) {
+        if (base == 0 || upto <= base) return;
+        const size_t sgm = size_t((std::min(upto, end) - base) / kSeg);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (sgm <= consumed) return;
+            consumed = sgm;
+        }
+        cv.notify_all();
+    }
+};
+
 struct thr_handle {
     thr_settings cfg{};
     thr::DevCfg dev{};
@@ -163,7 +322,9 @@ struct thr_handle {
         uint64_t slot_ticket[kPipeDepth] = {};
         uint64_t next_ticket = 1;
         int async_open = 0;
+        uintptr_t win_end[kPipeDepth] = {};    // input window: end of the chunk's source range (0: not windowed)
     } hp;
+    InputWindow win;
     // single-chunk staging of the test hooks (lazy)
     void* d_in = nullptr;
     size_t d_in_bytes = 0;
@@ -418,9 +579,35 @@ int ensure_pipe(thr_handle* h) {
 // kernels of the previous chunk run meanwhile.  (Measured and not adopted: our own pinned
 // staging filled by 3-6 host threads with one chunk of look-ahead -- 54 GB/s in some runs,
 // 29-33 GB/s in others on the same box, and never ahead below 48 MiB per chunk.)
-int pipe_h2d(thr_handle* h, void* d_dst, const void* src, size_t bytes) {
+// With an input window (thr_input_window) around `src` the range is page-locked by then: one
+// asynchronous copy per locked segment (a copy never straddles two registrations), the call
+// returns at once and buffer b remembers how far the window has been read.
+int pipe_h2d(thr_handle* h, int b, void* d_dst, const void* src, size_t bytes) {
+    h->hp.win_end[b] = 0;
+    if (h->win.acquire(src, bytes)) {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(src);
+        size_t done = 0;
+        while (done < bytes) {
+            const uintptr_t at = a + done;
+            const uintptr_t seg_end = h->win.base + (size_t((at - h->win.base) / InputWindow::kSeg) + 1) * InputWindow::kSeg;
+            const size_t n = std::min<size_t>(bytes - done, size_t(seg_end - at));
+            HIP_TRY(hipMemcpyAsync(static_cast<char*>(d_dst) + done, reinterpret_cast<const void*>(at), n,
+                                   hipMemcpyHostToDevice, h->hp.copy));
+            done += n;
+        }
+        h->hp.win_end[b] = a + bytes;
+        return THR_OK;
+    }
     HIP_TRY(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, h->hp.copy));
     return THR_OK;
+}
+
+// buffer b's chunk has left host memory (its H2D event or its done event has been waited for)
+void pipe_inputs_done(thr_handle* h, int b) {
+    if (h->hp.win_end[b]) {
+        h->win.release_below(h->hp.win_end[b]);
+        h->hp.win_end[b] = 0;
+    }
 }
 
 // blocks per chunk of the host entry points: the staging buffers stay near 64 MiB each
@@ -444,6 +631,7 @@ int pipe_drain(thr_handle* h, int b) {
     auto& p = h->hp;
     if (p.pend_n[b] == 0) return THR_OK;
     HIP_TRY(hipEventSynchronize(p.ev_done[b]));
+    pipe_inputs_done(h, b);
     std::memcpy(p.pend_dst[b], p.h_rec[b], p.pend_n[b] * sizeof(thr_record));
     const size_t n = p.pend_n[b], first = p.pend_first[b];
     p.pend_n[b] = 0;
@@ -806,6 +994,44 @@ int thr_create_preshift(const thr_settings* s, int num_shifts, thr_handle** out)
     return create_preshift(s, num_shifts, out, THR_PATH_AUTO);
 }
 
+namespace {
+constexpr uintptr_t kPage = 4096;
+}
+int thr_host_register(const void* p, size_t bytes) {
+    if (!p || bytes == 0) return fail(THR_ERR_ARG, "thr_host_register: empty range");
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p) & ~(kPage - 1);
+    const uintptr_t e = (reinterpret_cast<uintptr_t>(p) + bytes + kPage - 1) & ~(kPage - 1);
+    const hipError_t rc = hipHostRegister(reinterpret_cast<void*>(a), size_t(e - a), hipHostRegisterDefault);
+    if (rc != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(THR_ERR_DEVICE, "hipHostRegister(%zu bytes) failed: %s", size_t(e - a), hipGetErrorString(rc));
+    }
+    return THR_OK;
+}
+
+int thr_host_unregister(const void* p) {
+    if (!p) return fail(THR_ERR_ARG, "thr_host_unregister: null");
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p) & ~(kPage - 1);
+    const hipError_t rc = hipHostUnregister(reinterpret_cast<void*>(a));
+    if (rc != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(THR_ERR_DEVICE, "hipHostUnregister failed: %s", hipGetErrorString(rc));
+    }
+    return THR_OK;
+}
+
+int thr_input_window(thr_handle* h, const void* p, size_t bytes) {
+    if (!h) return fail(THR_ERR_ARG, "thr_input_window: null handle");
+    if (hipSetDevice(h->device) != hipSuccess) return fail(THR_ERR_DEVICE, "hipSetDevice(%d) failed", h->device);
+    if (h->hp.async_open != 0)
+        return fail(THR_ERR_STATE, "thr_input_window: %d submitted batch(es) not collected yet", h->hp.async_open);
+    if (h->hp.copy) (void)hipStreamSynchronize(h->hp.copy);     // no copy may still read the old window
+    h->win.close();
+    for (auto& e : h->hp.win_end) e = 0;
+    if (p && bytes) h->win.open(p, bytes, h->device);
+    return THR_OK;
+}
+
 int thr_plan_sections(int block_len, int history_len, int template_len, int* n_sections, int* start,
                       int* win_lo, int* win_hi, int* sum_lo, int* sum_hi) {
     if (!n_sections || !start || !win_lo || !win_hi || !sum_lo || !sum_hi)
@@ -1014,6 +1240,8 @@ void thr_destroy(thr_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+    if (h->hp.copy) (void)hipStreamSynchronize(h->hp.copy);
+    h->win.close();
     if (h->hp.ready || h->hp.copy) {
         auto& p = h->hp;
         if (p.copy) {
@@ -1117,7 +1345,7 @@ static int chunk_samples(thr_handle* h, int b, const void* src, int format, size
     const size_t bytes = stride ? (nb - 1) * stride + blk_bytes : nb * blk_bytes;
     int rc;
     if ((rc = pipe_grow(&p.d_in[b], &p.in_bytes[b], bytes)) != THR_OK) return rc;
-    if ((rc = pipe_h2d(h, p.d_in[b], src, bytes)) != THR_OK) return rc;
+    if ((rc = pipe_h2d(h, b, p.d_in[b], src, bytes)) != THR_OK) return rc;
     p.idx_host[b].resize(nb);
     for (size_t i = 0; i < nb; ++i)
         p.idx_host[b][i] = block_idx ? (long long)block_idx[i] : (long long)(first_idx + int64_t(i));
@@ -1157,7 +1385,7 @@ static int chunk_card(thr_handle* h, int b, const char* text, size_t text_len, c
         p.off_host[b][i] = payload_off[first + i] - lo;
         p.idx_host[b][i] = block_idx ? (long long)block_idx[first + i] : (long long)(first + i);
     }
-    if ((rc = pipe_h2d(h, p.d_text[b], text + lo, span)) != THR_OK) return rc;
+    if ((rc = pipe_h2d(h, b, p.d_text[b], text + lo, span)) != THR_OK) return rc;
     HIP_TRY(hipMemcpyAsync(p.d_off[b], p.off_host[b].data(), nb * sizeof(long long),
                            hipMemcpyHostToDevice, p.copy));
     HIP_TRY(hipMemcpyAsync(p.d_idx[b], p.idx_host[b].data(), nb * sizeof(long long),
@@ -1444,6 +1672,7 @@ int thr_inputs_consumed(thr_handle* h, uint64_t ticket) {
         if (p.slot_ticket[b] != ticket) continue;
         HIP_TRY(hipSetDevice(h->device));
         HIP_TRY(hipEventSynchronize(p.ev_h2d[b]));   // recorded behind the chunk's last H2D copy
+        pipe_inputs_done(h, b);
         return THR_OK;
     }
     return fail(THR_ERR_STATE, "thr_inputs_consumed: ticket %llu is not open", (unsigned long long)ticket);

@@ -63,7 +63,8 @@ class Detector(object):
     _multi = False            # MultiTemplateDetector: settings.template is [n_templates, len]
 
     def __init__(self, settings, blocks=None, rxid=-1, yield_data=False, batch_size=None,
-                 device_id=0, _preshift_num=0, _fastdet=False, max_wait=None, max_fill=None):
+                 device_id=0, _preshift_num=0, _fastdet=False, max_wait=None, max_fill=None,
+                 pin_input=True):
         """Batching a classic `(timestamp, idx, block)` iterator must not hold results back the way
         the reference's per-block loop never did.  What ends the batch being filled (what has
         arrived is processed instead of waiting for a full batch) depends on what the source says
@@ -77,7 +78,8 @@ class Detector(object):
             at most `max_fill` seconds (default 50 ms) and never read ahead -- a CPU-bound source
             (host decode, gzip) still gets batches of hundreds of blocks, a live one a latency of
             50 ms instead of batch_size blocks' worth of waiting.
-        `max_wait` / `max_fill` given explicitly apply to any source."""
+        `max_wait` / `max_fill` given explicitly apply to any source.  `pin_input`: page-lock a
+        mapped input file ahead of the copies while it is read (thr_input_window; best effort)."""
         if batch_size is None:      # ~64 MiB of u8 samples per engine batch (the staging chunk size)
             batch_size = max(64, min(65536, (64 << 20) // (2 * int(settings.block_len))))
             if yield_data:          # every block of a batch holds two N-point stage dumps in _ready
@@ -109,6 +111,15 @@ class Detector(object):
             settings.carrier_window, settings.corr_thresh, carrier_len=settings.carrier_len,
             device_id=device_id, max_batch=self.batch_size, preshift_num=_preshift_num,
             fastdet=_fastdet)
+        # a mapped input file becomes the engine's input window: a library thread page-locks it a
+        # bounded distance ahead of the chunk copies, which are then asynchronous DMA out of the
+        # page cache -- this thread frames the next batch and formats the previous one meanwhile
+        self._pin = False
+        reader = self._card if self._card is not None else self._raw
+        span = reader.mapped_span() if reader is not None else None
+        if pin_input and span is not None and len(span):
+            self._engine.input_window(span)
+            self._pin = True
         self._ready = deque()
         self._exhausted = False
         self._in_flight = None      # the submitted batch whose records have not been collected yet
@@ -347,7 +358,11 @@ class Detector(object):
         self._ready.extend(self._package(self._results(stamps, idxs, recs), groups))
 
     def _more(self):
-        return not self._exhausted or self._in_flight is not None or self._read_error is not None
+        more = not self._exhausted or self._in_flight is not None or self._read_error is not None
+        if not more and getattr(self, "_pin", False):
+            self._engine.input_window(None)     # every batch has been collected: unlock the input's pages
+            self._pin = False
+        return more
 
     def iter_detected_records(self):
         """Batches of (timestamps float64[k], records[k]) of the DETECTED blocks only, in input
