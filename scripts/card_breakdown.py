@@ -6,15 +6,23 @@ import numpy as np
 from thrifty_amd import _native, block_data, synth
 from thrifty_amd.detect import Detector, DetectorSettings
 
-n, h = 16384, 4096
-tpl = synth.gold_template(10, 2)
-rng = np.random.default_rng(0)
-seed, _ = synth.synth_blocks(rng, 32, n, tpl, (1537, 13825))
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 pin = (sys.argv[2] != "nopin") if len(sys.argv) > 2 else True
+rng = np.random.default_rng(0)
+if len(sys.argv) > 3 and sys.argv[3] == "c1":      # bench.py's card_to_toad leg: the example detector.cfg
+    g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "c1.npz"))
+    n, h, tpl = int(g["block_len"]), int(g["history_len"]), g["template"]
+    ook = (tpl - tpl.min()) / (tpl.max() - tpl.min()) * 2 - 1
+    pad = h - len(tpl) + 1
+    seed, _ = synth.synth_blocks(rng, 32, n, ook, (pad // 2, n - len(tpl) + 1 - (pad - pad // 2)))
+    st = DetectorSettings(n, h, len(tpl), tuple(g["carrier_thresh"]), tuple(int(v) for v in g["carrier_window"]), tpl, tuple(g["corr_thresh"]))
+else:
+    n, h = 16384, 4096
+    tpl = synth.gold_template(10, 2)
+    seed, _ = synth.synth_blocks(rng, 32, n, tpl, (1537, 13825))
+    st = DetectorSettings(n, h, len(tpl), (0, 15, 0), (7, 110), tpl, (0, 15, 0))
 line = [block_data.card_line(1000.0 + i, i, seed[i % 32]) for i in range(32)]
 text = "".join(line[i % 32] for i in range(nb)).encode()
-st = DetectorSettings(n, h, len(tpl), (0, 15, 0), (7, 110), tpl, (0, 15, 0))
 tmp = tempfile.NamedTemporaryFile(suffix=".card", delete=False)
 tmp.write(text); tmp.close()
 for rep in range(3):
@@ -55,3 +63,15 @@ for rep in range(3):
         {k: round(v / nbatch * 1e3, 3) for k, v in T.items()}, nout))
     f.close()
 os.unlink(tmp.name)
+# the product loop itself (Detector.iter_toad_text: two batches ahead on a page-locked file)
+tmp2 = tempfile.NamedTemporaryFile(suffix=".card", delete=False)
+tmp2.write(text); tmp2.close()
+for rep in range(3):
+    with open(tmp2.name, "rb") as f:
+        t0 = time.perf_counter()
+        det = Detector(st, block_data.CardStream(f, n), rxid=0, pin_input=pin)
+        out = b"".join(det.iter_toad_text())
+        dt = time.perf_counter() - t0
+    print("Detector.iter_toad_text, whole job: %.0f blocks/s (depth %d, %d B of text)" % (nb / dt, det._depth, len(out)))
+    del det
+os.unlink(tmp2.name)

@@ -142,7 +142,7 @@ def _bare_detector(recs, blocks, batch_size, max_wait=float("inf"), max_fill=flo
     d._engine = _FakeEngine(recs)
     from collections import deque
     d._ready, d._exhausted, d.only_detections = deque(), False, False
-    d._in_flight, d.max_wait, d.max_fill = None, max_wait, max_fill
+    d._ahead, d._depth, d.max_wait, d.max_fill = deque(), 1, max_wait, max_fill
     d._read_error, d._known_not_live = None, known_not_live
     return d
 

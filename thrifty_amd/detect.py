@@ -122,7 +122,11 @@ class Detector(object):
             self._pin = True
         self._ready = deque()
         self._exhausted = False
-        self._in_flight = None      # the submitted batch whose records have not been collected yet
+        # submitted batches whose records have not been collected yet, oldest first: one ahead of
+        # the batch being handed out, two when the input is a page-locked file (the copies are
+        # asynchronous then, and the DMA engine stays busy while this thread formats)
+        self._ahead = deque()
+        self._depth = 2 if self._pin else 1
         self._read_error = None     # an exception the read-ahead hit: raised once the batch before it is out
         # batch readers only (CardStream / RawStream): hand out detections only, skipping the
         # per-block Python objects of everything else (set by detector_cli under --quiet)
@@ -212,7 +216,7 @@ class Detector(object):
         in flight the synchronous entry point would refuse to run (thr_detect waits for open
         tickets to be collected), so a direct detect() between two next() calls rides the
         ticket interface too."""
-        if self._in_flight is None or self.yield_data:
+        if not self._ahead or self.yield_data:
             return self._engine.detect(arr, idx)
         step = self.batch_size
         return np.concatenate([self._engine.collect(self._engine.submit(arr[s:s + step], idx[s:s + step]))
@@ -304,26 +308,45 @@ class Detector(object):
         """-> (stamps, idxs, recs) of the next batch in input order, or None at the end.  The
         batch after it is submitted BEFORE this one is waited for, so the device (and the H2D
         staging of the next inputs) works while the caller formats what it was handed."""
-        if self._in_flight is None and self._read_error is not None:
+        if not self._ahead and self._read_error is not None:
             exc, self._read_error = self._read_error, None
             self._exhausted = True
             raise exc
-        cur = self._in_flight if self._in_flight is not None else self._submit_next()
-        self._in_flight = None
-        if cur is None:
-            return None
+        if not self._ahead:
+            first = self._submit_next()
+            if first is None:
+                return None
+            self._ahead.append(first)
         if self.yield_data:
-            return cur
-        if not self._exhausted and self._read_error is None and self._may_read_ahead(cur[2]):
+            return self._ahead.popleft()
+        while (len(self._ahead) <= self._depth and not self._exhausted and self._read_error is None
+               and self._may_read_ahead(self._ahead[-1][2])):
             try:
-                self._in_flight = self._submit_next(cur[2])
+                nxt = self._submit_next(self._ahead[-1][2])
             except Exception as exc:
-                # the NEXT batch is unreadable (a malformed line, an engine error): this batch's
-                # results still go out first, as the reference's per-line loop would have emitted
-                # everything before the bad input; the error is raised by the call after this one
+                # the NEXT batch is unreadable (a malformed line, an engine error): the batches
+                # before it still go out first, as the reference's per-line loop would have emitted
+                # everything before the bad input; the error is raised once they are out
                 self._read_error = exc
+                break
+            if nxt is None:
+                break
+            self._ahead.append(nxt)
+        cur = self._ahead.popleft()
         stamps, idxs, ticket = cur
         return self._flat(stamps, idxs, self._engine.collect(ticket))
+
+    @property
+    def _in_flight(self):
+        """The oldest submitted batch not collected yet (None: nothing in flight)."""
+        return self._ahead[0] if self._ahead else None
+
+    def _drop_ahead(self):
+        """The iteration ends here (the reference's loop died on this block): never leave a ticket open."""
+        while self._ahead:
+            pending = self._ahead.popleft()
+            if not self.yield_data:
+                self._engine.collect(pending[2])
 
     def _may_read_ahead(self, prev=None):
         """Reading the NEXT batch before handing out this one must not delay it: fine on files and
@@ -343,7 +366,7 @@ class Detector(object):
     def _refill(self):
         got = self._next_records()
         if got is None:
-            if self._in_flight is None:
+            if not self._ahead:
                 self._exhausted = True
             return
         if self.yield_data:
@@ -358,7 +381,7 @@ class Detector(object):
         self._ready.extend(self._package(self._results(stamps, idxs, recs), groups))
 
     def _more(self):
-        more = not self._exhausted or self._in_flight is not None or self._read_error is not None
+        more = not self._exhausted or bool(self._ahead) or self._read_error is not None
         if not more and getattr(self, "_pin", False):
             self._engine.input_window(None)     # every batch has been collected: unlock the input's pages
             self._pin = False
@@ -385,9 +408,7 @@ class Detector(object):
                 yield np.asarray(stamps, dtype=np.float64)[keep], recs[keep]
             if len(bad):
                 self._exhausted = True
-                if self._in_flight is not None and not self.yield_data:
-                    self._engine.collect(self._in_flight[2])
-                self._in_flight = None
+                self._drop_ahead()
                 self._result(stamps[stop], int(idxs[stop]), recs[stop])   # raises
 
     def iter_toad_text(self):
@@ -415,9 +436,7 @@ class Detector(object):
         if isinstance(item, _Deferred):
             self._ready.clear()
             self._exhausted = True      # the reference's loop died here
-            if self._in_flight is not None and not self.yield_data:
-                self._engine.collect(self._in_flight[2])
-            self._in_flight = None
+            self._drop_ahead()
             raise item.exc
         return item
 
