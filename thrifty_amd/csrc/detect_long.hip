@@ -512,7 +512,7 @@ __device__ __forceinline__ void combine_at(const cpx* __restrict__ d, const cpx*
     u[0] = d[m];
 #pragma unroll
     for (int k0 = 1; k0 < R0; ++k0) u[k0] = cmulc(d[size_t(k0) * M + m], twn[(m * k0) & nl_mask]);
-    dft_dif<R0, +1>(u);
+    dft_reg<R0, +1>(u);
 #pragma unroll
     for (int n0 = 0; n0 < R0; ++n0) out[n0] = u[brev(n0, R0)];
 }
@@ -589,7 +589,7 @@ struct PeakTail {
                 u[0] = dv[0];
 #pragma unroll
                 for (int k0 = 1; k0 < R0; ++k0) u[k0] = cmulc(dv[k0], wv[k0]);
-                dft_dif<R0, +1>(u);
+                dft_reg<R0, +1>(u);
                 cpx sel = u[0];
 #pragma unroll
                 for (int n0 = 1; n0 < R0; ++n0) sel = (n / M == n0) ? u[brev(n0, R0)] : sel;
@@ -687,8 +687,8 @@ __device__ __forceinline__ void combine_impl(const DevCfg& cfg, const cpx* __res
                 u0[k0] = cmulc(cpx{q[u][k0].x, q[u][k0].y}, cmul(wb0[k0], s[u][k0]));
                 u1[k0] = cmulc(cpx{q[u][k0].z, q[u][k0].w}, cmul(wb1[k0], s[u][k0]));
             }
-            dft_dif<R0, +1>(u0);
-            dft_dif<R0, +1>(u1);
+            dft_reg<R0, +1>(u0);
+            dft_reg<R0, +1>(u1);
 #pragma unroll
             for (int n0 = 0; n0 < R0; ++n0) {
 #pragma unroll
@@ -789,8 +789,8 @@ __device__ __forceinline__ void combine_own(const DevCfg& cfg, const cpx* stab, 
                 u0[k0] = cmulc(a0, cmul(wb0[k0], s));
                 u1[k0] = cmulc(a1, cmul(wb1[k0], s));
             }
-            dft_dif<R0, +1>(u0);
-            dft_dif<R0, +1>(u1);
+            dft_reg<R0, +1>(u0);
+            dft_reg<R0, +1>(u1);
 #pragma unroll
             for (int n0 = 0; n0 < R0; ++n0) {
 #pragma unroll

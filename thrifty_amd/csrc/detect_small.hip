@@ -129,8 +129,8 @@ __device__ __forceinline__ void small_pass1(cpx* lds, const RAW& raw, int g, int
             }
         }
         if constexpr (R1 > 1) {
-            dft_dif<R1, -1>(v0);
-            dft_dif<R1, -1>(v1);
+            dft_reg<R1, -1>(v0);
+            dft_reg<R1, -1>(v1);
         }
         cpx pa, pb;
         if constexpr (PH) {
@@ -181,8 +181,8 @@ __device__ __forceinline__ void small_passC(const cpx* lds, int g, int tb, cpx* 
             v1[k1] = cpx{q.z, q.w};
         }
         if constexpr (R1 > 1) {
-            dft_dif<R1, +1>(v0);
-            dft_dif<R1, +1>(v1);
+            dft_reg<R1, +1>(v0);
+            dft_reg<R1, +1>(v1);
         }
         static_for<R1>([&](auto K) {
             constexpr int n1 = decltype(K)::value;

@@ -138,8 +138,8 @@ __device__ __forceinline__ void fwd_pass1(cpx* lds, const RAW& raw,
         }
     }
     if (energy != nullptr) *energy = e;
-    dft_dif<R1, -1>(v0);
-    dft_dif<R1, -1>(v1);
+    dft_reg<R1, -1>(v0);
+    dft_reg<R1, -1>(v1);
     const int n2 = t >> 4, mp = 2 * (t & 15);
     const cpx* tA = lds + OFF_A;
     const cpx* tB = lds + OFF_B;
@@ -235,8 +235,8 @@ __device__ __forceinline__ void fwd_pass1_pre(cpx* lds, const RAW& raw, const cp
         }
         if (energy != nullptr) *energy = e;
     }
-    dft_dif<R1, -1>(v0);
-    dft_dif<R1, -1>(v1);
+    dft_reg<R1, -1>(v0);
+    dft_reg<R1, -1>(v1);
     const int n2 = t >> 4, mp = 2 * (t & 15);
     f4* out = reinterpret_cast<f4*>(lds + n2 * CHUNK + mp);
     static_for<R1>([&](auto K) {
@@ -265,7 +265,7 @@ __device__ __forceinline__ void fwd_pass2(cpx* lds) {
     cpx v[R2];
 #pragma unroll
     for (int n2 = 0; n2 < R2; ++n2) v[n2] = lds_b64(base + n2 * CHUNK);
-    dft_dif<R2, -1>(v);
+    dft_reg<R2, -1>(v);
     static_assert(KEEP % 2 == 0, "outputs are twiddled in pairs");
     static_for<KEEP / 2>([&](auto K) {
         constexpr int k2 = 2 * decltype(K)::value;
@@ -290,7 +290,7 @@ __device__ __forceinline__ void fwd_pass3(const cpx* lds, cpx* v) {
         v[2 * j] = cpx{q.x, q.y};
         v[2 * j + 1] = cpx{q.z, q.w};
     }
-    dft_dif<R3, -1>(v);
+    dft_reg<R3, -1>(v);
 }
 
 // ------------------------------------------------------------ inverse passes
@@ -305,7 +305,7 @@ __device__ __forceinline__ void inv_passA(cpx* lds, cpx* z) {
         constexpr int k3 = decltype(K)::value;
         v[k3] = z[brev(k3, R3)];
     });
-    dft_dif<R3, +1>(v);
+    dft_reg<R3, +1>(v);
     const cpx* tC = lds + OFF_C + k2;
     f4* dst = reinterpret_cast<f4*>(lds + (t >> 5) * ROW + k2 * CHUNK);
     static_for<R3 / 2>([&](auto J) {
@@ -341,7 +341,7 @@ __device__ __forceinline__ void inv_passB(cpx* lds, const cpx* __restrict__ gtw 
         cpx w[R2 / 2];
 #pragma unroll
         for (int n2 = 0; n2 < R2 / 2; ++n2) w[n2] = tw[n2 * 32];
-        dft_dif<R2, +1>(v);
+        dft_reg<R2, +1>(v);
         static_for<2>([&](auto H) {
             constexpr int h = decltype(H)::value;
             static_for<R2 / 4>([&](auto K) {
@@ -366,7 +366,7 @@ __device__ __forceinline__ void inv_passB(cpx* lds, const cpx* __restrict__ gtw 
         cpx w[R2];
 #pragma unroll
         for (int n2 = 0; n2 < R2; ++n2) w[n2] = tw[n2 * 32];
-        dft_dif<R2, +1>(v);
+        dft_reg<R2, +1>(v);
         static_for<R2 / 2>([&](auto K) {
             constexpr int n2 = 2 * decltype(K)::value;
             cpx y0, y1;
@@ -376,7 +376,7 @@ __device__ __forceinline__ void inv_passB(cpx* lds, const cpx* __restrict__ gtw 
         });
         return;
     }
-    dft_dif<R2, +1>(v);
+    dft_reg<R2, +1>(v);
     const cpx b = lds[OFF_B + k1 * 32 + n3];
     const cpx* tA = lds + OFF_A + k1 * 32;
     static_for<R2>([&](auto K) {
@@ -400,8 +400,8 @@ __device__ __forceinline__ void inv_passC(const cpx* lds, cpx* c0, cpx* c1) {
         c0[k1] = cpx{q.x, q.y};
         c1[k1] = cpx{q.z, q.w};
     }
-    dft_dif<R1, +1>(c0);
-    dft_dif<R1, +1>(c1);
+    dft_reg<R1, +1>(c0);
+    dft_reg<R1, +1>(c1);
 }
 
 }  // namespace thr
