@@ -81,6 +81,54 @@ def test_single_block_detect_and_yield_data(golden):
     assert line.startswith("blk=0; carrier: no ")
 
 
+def test_sync_and_soa_estimate_are_callable_like_the_references(golden):
+    """The body of the reference's Detector.detect (detect.py:60-78), written against the two
+    sub-objects as an analysis script would: `shifted_fft, carrier_info = det.sync(block)`, then
+    `detected, corr_info, corr = det.soa_estimate(shifted_fft)` -- same values as det.detect(),
+    as the goldens and as the oracle's intermediates."""
+    from oracle import thrifty_np as onp
+    g = golden("c2")
+    st = settings_of(g)
+    det = Detector(st, None, rxid=0)
+    assert det.sync.thresh_coeffs == st.carrier_thresh and det.sync.window == st.carrier_window
+    assert det.sync.weights is None and det.soa_estimate.corr_len == 16384 - 1023 + 1
+    assert det.soa_estimate.thresh_coeffs == st.corr_thresh
+    orc = onp.OracleDetector(16384, 4096, g["template"], tuple(g["carrier_thresh"]),
+                             tuple(int(v) for v in g["carrier_window"]), tuple(g["corr_thresh"]))
+    seen = 0
+    for i in range(len(g["blocks"])):
+        if g["index_error"][i]:
+            continue
+        blk = block_data.IQBlock(block_data.raw_to_complex(g["blocks"][i]), g["blocks"][i])
+        shifted_fft, cinfo = det.sync(blk)
+        assert cinfo.bin == g["cbin"][i]
+        np.testing.assert_allclose(cinfo.energy, g["cenergy"][i], rtol=2e-5)
+        np.testing.assert_allclose(cinfo.noise, g["cnoise"][i], rtol=2e-5)
+        if not g["carrier_det"][i]:
+            assert shifted_fft is None and cinfo.offset == 0
+            with pytest.raises(NotImplementedError):
+                det.soa_estimate(np.zeros(16384, dtype=np.complex64))
+            continue
+        np.testing.assert_allclose(cinfo.offset, g["coff"][i], atol=2e-4)
+        detected, sinfo, corr = det.soa_estimate(shifted_fft)
+        assert detected == bool(g["det"][i]) and sinfo.sample == g["sample"][i]
+        np.testing.assert_allclose(sinfo.energy, g["energy"][i], rtol=2e-5)
+        np.testing.assert_allclose(sinfo.offset, g["soff"][i] if detected else 0, atol=5e-6)
+        assert corr.shape == (16384 - 1023 + 1,)
+        assert int(np.argmax(np.abs(corr[1537:13825]))) + 1537 == sinfo.sample
+        (res,), ((xh, co),) = orc.detect_u8(0, g["blocks"][i], want_data=True)
+        assert np.linalg.norm(shifted_fft - xh) / np.linalg.norm(xh) < 5e-6
+        assert np.linalg.norm(corr - co) / np.linalg.norm(co) < 5e-6
+        d2, r2 = det.detect(0.0, 0, blk)                     # the one-call form agrees
+        assert d2 == detected and r2.corr_info.sample == sinfo.sample and r2.corr_info.energy == sinfo.energy
+        with pytest.raises(NotImplementedError):             # only the latest sync()'s spectrum
+            det.soa_estimate(shifted_fft.copy())
+        seen += 1
+    assert seen >= 4
+    with pytest.raises(NotImplementedError):
+        det.sync.detector(np.ones(16384, dtype=np.float32))
+
+
 def test_index_error_is_mirrored(golden):
     g = golden("c2_straddle")
     det = Detector(settings_of(g), None)

@@ -50,6 +50,82 @@ class _Deferred(object):
         self.exc = exc
 
 
+class _SyncStage(object):
+    """`Detector.sync`: what the reference's `DefaultSynchronizer` offers an analysis script
+    (carrier_sync.py:30-118) -- the attributes `thresh_coeffs`, `window`, `weights` and the call
+    `sync(signal) -> (shifted_fft or None, CarrierSyncInfo)` -- evaluated by the engine for ONE
+    block (carrier stage, Dirichlet fit, frequency shift, FFT#2; `thr_debug_stage` returns the
+    shifted spectrum in natural order).  Read-only: `detector` / `interpolator` / `shifter` are
+    stages of fused kernels and cannot be replaced (the reference's own subclasses that do so
+    are separate detectors here: `PreshiftDetector`, `FastDetector`)."""
+
+    def __init__(self, det, settings):
+        self._det = det
+        self.thresh_coeffs = settings.carrier_thresh
+        self.window = settings.carrier_window
+        self.weights = None
+        self._last = None       # (id of the shifted_fft handed out, record, corr) of the latest block
+
+    def sync(self, signal):
+        det = self._det
+        arr = det._stack([signal])
+        rec = det._run(arr, np.zeros(1, dtype=np.int64))[0, 0]
+        _, result = det._result(0.0, 0, rec)
+        if result.corr_info is None:
+            self._last = None
+            return None, result.carrier_info
+        xhat, corr = det._engine.debug_stage(arr)
+        shifted_fft = xhat[0]
+        self._last = (shifted_fft, rec, corr[0][:det.soa_estimate.corr_len])
+        return shifted_fft, result.carrier_info
+
+    __call__ = sync
+
+    def detect(self, fft_mag):
+        raise NotImplementedError(
+            "the carrier detector runs inside the engine's carrier kernel, on a block's samples: "
+            "call sync(block) -- or Detector.detect(timestamp, block_idx, block) -- instead")
+
+    detector = detect
+
+    def interpolator(self, fft_mag, peak_idx):
+        raise NotImplementedError("the Dirichlet fit runs inside the engine (k_fit): call sync(block)")
+
+    def shifter(self, signal, shift):
+        raise NotImplementedError("the frequency shift is fused into the correlate kernel: call sync(block)")
+
+
+class _SoaStage(object):
+    """`Detector.soa_estimate`: the attributes of the reference's `SoaEstimator`
+    (soa_estimator.py:63-92: `template`, `template_energy`, `corr_len`, `window`,
+    `thresh_coeffs`) and the call `soa_estimate(fft) -> (detected, CorrDetectionInfo, corr)` for
+    the spectrum `Detector.sync(block)` has just returned -- the pair of calls that makes up the
+    body of the reference's `Detector.detect` (detect.py:60-78).  Any other spectrum would have to be
+    correlated from host memory, which the engine has no entry point for."""
+
+    def __init__(self, det, settings, template, corr_len):
+        self._det = det
+        self.template = template
+        self.template_energy = float(np.sum(np.abs(template) ** 2))
+        self.corr_len = corr_len
+        self.thresh_coeffs = settings.corr_thresh
+        self.window = unique_window(settings.block_len, settings.history_len, template.shape[-1])
+
+    def soa_estimate(self, fft):
+        last = self._det.sync._last
+        if last is None or fft is not last[0]:
+            raise NotImplementedError(
+                "soa_estimate() takes the shifted spectrum that Detector.sync(block) returned for "
+                "the latest block; arbitrary spectra cannot be handed to the engine")
+        _, rec, corr = last
+        detected = bool(int(rec["flags"]) & _native.FLAG_CORR)
+        info = toads_data.CorrDetectionInfo(int(rec["corr_sample"]), float(rec["corr_offset"]) if detected else 0,
+                                            float(rec["corr_energy"]), float(rec["corr_noise"]))
+        return detected, info, corr
+
+    __call__ = soa_estimate
+
+
 class Detector(object):
     """All-in-one carrier sync + matched filter + SoA estimator, batched on the GPU.
 
@@ -132,13 +208,10 @@ class Detector(object):
         # per-block Python objects of everything else (set by detector_cli under --quiet)
         self.only_detections = False
         corr_len = settings.block_len - template.shape[-1] + 1
-        # descriptive twins of the reference's sub-objects (read-only facts)
-        self.sync = SimpleNamespace(thresh_coeffs=settings.carrier_thresh,
-                                    window=settings.carrier_window, weights=None)
-        self.soa_estimate = SimpleNamespace(
-            template=template, template_energy=float(np.sum(np.abs(template) ** 2)),
-            corr_len=corr_len, thresh_coeffs=settings.corr_thresh,
-            window=unique_window(settings.block_len, settings.history_len, template.shape[-1]))
+        # twins of the reference's sub-objects (detect.py:46-58): the same attributes, and CALLABLE
+        # like them -- evaluated by the engine, one block at a time (_SyncStage / _SoaStage below)
+        self.sync = _SyncStage(self, settings)
+        self.soa_estimate = _SoaStage(self, settings, template, corr_len)
 
     # ------------------------------------------------------------------ core
     def _stack(self, blocks):
