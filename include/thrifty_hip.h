@@ -141,7 +141,10 @@ int thr_create_fastdet(const thr_settings* settings, thr_handle** out);
 /*
  * The three constructors above in one call, plus an explicit choice of kernel path.  `variant`:
  * THR_VARIANT_DEFAULT (thr_create), THR_VARIANT_PRESHIFT (thr_create_preshift; variant_arg =
- * num_shifts) or THR_VARIANT_FASTDET (thr_create_fastdet).  `path`:
+ * num_shifts | THR_INTERP_* << 16: the bank size and the carrier interpolator, one of the reference's
+ * thrifty/experimental/carrier_interpolators.py -- parabolic (:44-49, what thr_create_preshift uses
+ * and the reference's default), none (:17), gaussian (:52-58), cosine (:92-100); float32 like the
+ * magnitudes they are given) or THR_VARIANT_FASTDET (thr_create_fastdet).  `path`:
  *   THR_PATH_AUTO         what the other constructors use: the fastest kernels for the block
  *                         length (LDS-resident for 1024 ... 65536, multi-pass otherwise);
  *   THR_PATH_MULTIPASS    the generic multi-pass pipeline (Stockham passes through HBM) whatever
@@ -157,6 +160,10 @@ int thr_create_fastdet(const thr_settings* settings, thr_handle** out);
 #define THR_VARIANT_DEFAULT 0
 #define THR_VARIANT_PRESHIFT 1
 #define THR_VARIANT_FASTDET 2
+#define THR_INTERP_PARABOLIC 0
+#define THR_INTERP_NONE 1
+#define THR_INTERP_GAUSSIAN 2
+#define THR_INTERP_COSINE 3
 #define THR_PATH_AUTO 0
 #define THR_PATH_MULTIPASS 1
 #define THR_PATH_UNSECTIONED 2
@@ -335,8 +342,9 @@ int thr_poll(thr_handle* h, uint64_t ticket, int* done);
  * str(int), every other float as Python's repr() of the value widened to a double (what
  * '{}'.format gives for a float and for an np.float32).  with_rxid / with_txid: prepend the
  * ids like serialize() does for values that are not None (txid = the record's template_id:
- * multi-template detection); carrier_offset_f32: round the carrier offset to float32 first
- * (PreshiftDetector's np.float32 offset).  `out_capacity` must be >= n * THR_TOAD_LINE_MAX.
+ * multi-template detection); carrier_offset_f32: 1 = round the carrier offset to float32 first
+ * (PreshiftDetector's np.float32 offset), 2 = print it as an integer (its interpolator `none`
+ * returns the int 0).  `out_capacity` must be >= n * THR_TOAD_LINE_MAX.
  * Host only, no device, handle-free.
  */
 #define THR_TOAD_LINE_MAX 384

@@ -289,6 +289,36 @@ def parabolic_offset(mag, peak_idx):
         return (c - a) / (4 * b - 2 * a - 2 * c)
 
 
+def no_offset(mag, peak_idx):
+    """experimental/carrier_interpolators.py:17-18."""
+    return 0
+
+
+def gaussian_offset(mag, peak_idx):
+    """The parabola through the LOGARITHMS of the three magnitudes
+    (experimental/carrier_interpolators.py:52-58; float32 in, float32 out)."""
+    a, b, c = mag[peak_idx - 1], mag[peak_idx], mag[peak_idx + 1]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        a, b, c = np.log(a), np.log(b), np.log(c)
+        return (c - a) / (4 * b - 2 * a - 2 * c)
+
+
+def cosine_offset(mag, peak_idx):
+    """experimental/carrier_interpolators.py:92-100."""
+    a, b, c = mag[peak_idx - 1], mag[peak_idx], mag[peak_idx + 1]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        cos_omega = (a + c) / (2 * b)
+        if cos_omega > 1:
+            return 0
+        omega = np.arccos(cos_omega)
+        theta = np.arctan((a - c) / (2 * b * np.sin(omega)))
+        return -theta / omega
+
+
+CARRIER_INTERPOLATORS = {"parabolic": parabolic_offset, "none": no_offset,
+                         "gaussian": gaussian_offset, "cosine": cosine_offset}
+
+
 class PreshiftBank(object):
     """`num` template spectra, pre-shifted by -0.5 .. 0.5 bins (detect_preshift.py:24-45)."""
 
@@ -316,11 +346,12 @@ class OraclePreshiftDetector(object):
     block, and the residual sub-bin offset picks the nearest pre-shifted template."""
 
     def __init__(self, block_len, history_len, template, carrier_thresh, carrier_window,
-                 corr_thresh, num=21):
+                 corr_thresh, num=21, interpolator="parabolic"):
         self.block_len, self.history_len = block_len, history_len
         self.new_len = block_len - history_len
         self.bank = TemplateBank(template, block_len, history_len)   # energy, window
         self.shifted = PreshiftBank(template, block_len, num)
+        self.interpolate = CARRIER_INTERPOLATORS[interpolator]   # detect_preshift.py:57-58
         self.carrier_thresh, self.carrier_window = carrier_thresh, carrier_window
         self.corr_thresh = corr_thresh
         self.last = None        # (int_shift, frac_shift, template index) of the last block
@@ -335,7 +366,7 @@ class OraclePreshiftDetector(object):
         self.last = None
         if not det:
             return BlockResult(False, None, CarrierStage(det, idx, off, peak, noise, thr), None)
-        off = parabolic_offset(mag, idx)           # carrier_sync.py:68-70
+        off = self.interpolate(mag, idx)           # carrier_sync.py:68-70
         car = CarrierStage(det, idx, off, peak, noise, thr)
         # the reference's peak index is an np.int64 (argmax + start), so int64 + float32 -> float64
         shift = -(np.int64(idx) + off)             # carrier_sync.py:71

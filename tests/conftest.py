@@ -19,6 +19,12 @@ def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
 
 
+def golden_blocks(g):
+    """Input blocks of a fixture: its own, or those of the fixture it names as `src` (the
+    interpolator variants of the preshift fixtures share the base fixture's inputs)."""
+    return g["blocks"] if "blocks" in g.files else load_golden(str(g["src"]))["blocks"]
+
+
 @pytest.fixture(scope="session")
 def golden():
     return load_golden

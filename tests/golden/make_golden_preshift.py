@@ -21,11 +21,12 @@ builtins.xrange = range
 
 from thrifty import block_data  # noqa: E402
 from thrifty.detect import DetectorSettings  # noqa: E402
+from thrifty.experimental import carrier_interpolators  # noqa: E402
 from thrifty.experimental.detect_preshift import PreshiftDetector  # noqa: E402
 from thrifty.signal_utils import Signal  # noqa: E402
 
 
-def run(src_name, out_name, num, take=None):
+def run(src_name, out_name, num, take=None, interpolator="parabolic"):
     g = np.load(os.path.join(HERE, src_name + ".npz"))
     st = DetectorSettings(int(g["block_len"]), int(g["history_len"]), len(g["template"]),
                           tuple(g["carrier_thresh"]), tuple(int(v) for v in g["carrier_window"]),
@@ -35,10 +36,11 @@ def run(src_name, out_name, num, take=None):
         blocks, idx = blocks[take], idx[take]
     nb = len(blocks)
     rxid = int(g["rxid"])
-    det = PreshiftDetector(st, None, rxid=rxid, num=num)
+    det = PreshiftDetector(st, None, rxid=rxid, num=num,
+                           interpolator=carrier_interpolators.INTERPOLATORS[interpolator])
     out = {
         "carrier_det": np.zeros(nb, bool), "det": np.zeros(nb, bool),
-        "cbin": np.zeros(nb, np.int64), "coff": np.zeros(nb, np.float32),
+        "cbin": np.zeros(nb, np.int64), "coff": np.zeros(nb, np.float32),   # (`none` returns the int 0)
         "cenergy": np.zeros(nb, np.float32), "cnoise": np.zeros(nb, np.float32),
         "sample": np.full(nb, -1, np.int64), "soff": np.zeros(nb),
         "energy": np.zeros(nb), "noise": np.zeros(nb), "soa": np.full(nb, np.nan),
@@ -70,11 +72,16 @@ def run(src_name, out_name, num, take=None):
                 carrier_thresh=np.array(st.carrier_thresh, float),
                 carrier_window=np.array(st.carrier_window, np.int64),
                 corr_thresh=np.array(st.corr_thresh, float), template=np.asarray(st.template),
-                rxid=rxid, num=num, blocks=blocks, block_idx=np.asarray(idx, np.int64),
+                rxid=rxid, num=num, interpolator=interpolator, blocks=blocks, block_idx=np.asarray(idx, np.int64),
                 toad="\n".join(lines),
                 versions="numpy %s scipy %s python %s" % (np.__version__, scipy.__version__,
                                                            sys.version.split()[0]))
     meta.update(out)
+    if interpolator != "parabolic":
+        # the input blocks are those of fixture `src_name` (whole, in order): not stored again
+        assert take is None
+        del meta["blocks"]
+        meta["src"] = src_name
     path = os.path.join(HERE, out_name + ".npz")
     np.savez_compressed(path, **meta)
     print("%-22s blocks=%d carrier=%d det=%d index_error=%d  %.0f KiB" % (
@@ -88,3 +95,7 @@ if __name__ == "__main__":
     run("c2_stddev", "preshift_c2_stddev", 11)         # stddev threshold terms, other bank size
     run("c1", "preshift_c1", 101, take=slice(0, 6))    # float64 template, CLI's --num 101
     run("small", "preshift_small", 21)                 # N = 4096
+    # the reference's other three-point carrier interpolators (experimental/carrier_interpolators.py)
+    for name in ("none", "gaussian", "cosine"):
+        run("c2", "preshift_c2_" + name, 21, interpolator=name)
+    run("c2_straddle", "preshift_c2_straddle_gaussian", 21, interpolator="gaussian")

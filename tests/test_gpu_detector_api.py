@@ -117,8 +117,10 @@ def test_sync_and_soa_estimate_are_callable_like_the_references(golden):
         assert corr.shape == (16384 - 1023 + 1,)
         assert int(np.argmax(np.abs(corr[1537:13825]))) + 1537 == sinfo.sample
         (res,), ((xh, co),) = orc.detect_u8(0, g["blocks"][i], want_data=True)
-        assert np.linalg.norm(shifted_fft - xh) / np.linalg.norm(xh) < 5e-6
-        assert np.linalg.norm(corr - co) / np.linalg.norm(co) < 5e-6
+        # (the shift follows each side's own carrier-offset estimate, equal to <= 2e-4 bins: a phase
+        # ramp of up to 2 pi 2e-4 / sqrt(12) over the block on top of the transform's 1e-6)
+        assert np.linalg.norm(shifted_fft - xh) / np.linalg.norm(xh) < 5e-5
+        assert np.linalg.norm(corr - co) / np.linalg.norm(co) < 5e-5
         d2, r2 = det.detect(0.0, 0, blk)                     # the one-call form agrees
         assert d2 == detected and r2.corr_info.sample == sinfo.sample and r2.corr_info.energy == sinfo.energy
         with pytest.raises(NotImplementedError):             # only the latest sync()'s spectrum

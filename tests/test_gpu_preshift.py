@@ -13,18 +13,26 @@ from thrifty_amd.experimental.detect_preshift import PreshiftDetector
 
 pytestmark = pytest.mark.gpu
 
-FIXTURES = ["preshift_c2", "preshift_c2_straddle", "preshift_c2_stddev", "preshift_c1", "preshift_small"]
+from conftest import golden_blocks
+
+FIXTURES = ["preshift_c2", "preshift_c2_straddle", "preshift_c2_stddev", "preshift_c1", "preshift_small",
+            # the reference's other three-point carrier interpolators (carrier_interpolators.py)
+            "preshift_c2_none", "preshift_c2_gaussian", "preshift_c2_cosine", "preshift_c2_straddle_gaussian"]
+
+
+def interp_of(g):
+    return str(g["interpolator"]) if "interpolator" in g.files else "parabolic"
 
 
 def engine_for(g, **kw):
     return F.Engine(int(g["block_len"]), int(g["history_len"]), g["template"],
                     tuple(g["carrier_thresh"]), tuple(int(v) for v in g["carrier_window"]),
-                    tuple(g["corr_thresh"]), preshift_num=int(g["num"]), **kw)
+                    tuple(g["corr_thresh"]), preshift_num=int(g["num"]), interpolator=interp_of(g), **kw)
 
 
 def check_records(rec, g):
     """bit-exact bin / sample index / verdicts; offsets and energies to the stated tolerance."""
-    n = len(g["blocks"])
+    n = len(golden_blocks(g))
     assert len(rec) == n
     for i in range(n):
         r = rec[i]
@@ -50,7 +58,7 @@ def check_records(rec, g):
 @pytest.mark.parametrize("name", FIXTURES)
 def test_matches_reference_goldens(golden, name):
     g = golden(name)
-    rec = engine_for(g, max_batch=8).detect(g["blocks"], g["block_idx"])[:, 0]
+    rec = engine_for(g, max_batch=8).detect(golden_blocks(g), g["block_idx"])[:, 0]
     check_records(rec, g)
     # the debug word carries the roll and the bank index the reference would have used
     for i in range(len(rec)):
@@ -109,14 +117,23 @@ def test_random_blocks_match_oracle(num):
     assert hits > 200 and bank_flips <= 1
 
 
-def test_detector_class_serialises_like_the_reference(golden):
-    g = golden("preshift_c2")
+@pytest.mark.parametrize("name", ["preshift_c2", "preshift_c2_none", "preshift_c2_gaussian", "preshift_c2_cosine"])
+def test_detector_class_serialises_like_the_reference(golden, name):
+    from thrifty_amd.experimental import carrier_interpolators
+    g = golden(name)
+    gb = golden_blocks(g)
     st = DetectorSettings(int(g["block_len"]), int(g["history_len"]), len(g["template"]),
                           tuple(g["carrier_thresh"]), tuple(int(v) for v in g["carrier_window"]),
                           g["template"], tuple(g["corr_thresh"]))
-    blocks = [(1000.0 + i, int(g["block_idx"][i]), g["blocks"][i]) for i in range(len(g["blocks"]))]
-    det = PreshiftDetector(st, blocks, rxid=int(g["rxid"]), num=int(g["num"]), batch_size=7)
+    blocks = [(1000.0 + i, int(g["block_idx"][i]), gb[i]) for i in range(len(gb))]
+    # the reference passes the interpolator FUNCTION (detect_preshift.py:48-58)
+    det = PreshiftDetector(st, blocks, rxid=int(g["rxid"]), num=int(g["num"]), batch_size=7,
+                           interpolator=carrier_interpolators.INTERPOLATORS[interp_of(g)])
     lines = [res.serialize() for detected, res in det if detected]
+    # ... and the engine-formatted text (thr_format_toad) is the same text
+    det2 = PreshiftDetector(st, blocks, rxid=int(g["rxid"]), num=int(g["num"]), batch_size=7,
+                            interpolator=interp_of(g))
+    assert [ln for chunk in det2.iter_toad_lines() for ln in chunk] == lines
     want = str(g["toad"]).split("\n")
     assert len(lines) == len(want)
     for a, b in zip(lines, want):
@@ -124,6 +141,9 @@ def test_detector_class_serialises_like_the_reference(golden):
         assert fa[:3] == fb[:3] and fa[4] == fb[4] and fa[8] == fb[8]      # rxid ts block | sample | bin
         np.testing.assert_allclose(float(fa[3]), float(fb[3]), atol=2e-4)   # soa
         np.testing.assert_allclose([float(v) for v in fa[5:8]], [float(v) for v in fb[5:8]], rtol=1e-4, atol=1e-4)
+        if interp_of(g) == "none":
+            assert fa[9] == fb[9] == "0"                                   # none() returns the int 0
+            continue
         np.testing.assert_allclose(float(fa[9]), float(fb[9]), atol=2e-5)   # float32 carrier offset
         assert float(np.float32(float(fa[9]))) == float(fa[9])   # a widened float32, like the reference's
     with pytest.raises(NotImplementedError):

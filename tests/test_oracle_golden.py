@@ -170,7 +170,10 @@ def test_fft_bin(num):
 # ---- PreshiftDetector variant: fixtures from the reference's
 # ---- experimental/detect_preshift.py (tests/golden/make_golden_preshift.py)
 PRESHIFT_FIXTURES = ["preshift_c2", "preshift_c2_straddle", "preshift_c2_stddev", "preshift_c1",
-                     "preshift_small"]
+                     "preshift_small",
+                     # the reference's other three-point carrier interpolators
+                     "preshift_c2_none", "preshift_c2_gaussian", "preshift_c2_cosine",
+                     "preshift_c2_straddle_gaussian"]
 
 
 @pytest.mark.parametrize("name", PRESHIFT_FIXTURES)
@@ -178,9 +181,11 @@ def test_preshift_oracle_matches_reference_records(golden, name):
     g = golden(name)
     orc = onp.OraclePreshiftDetector(
         int(g["block_len"]), int(g["history_len"]), g["template"], tuple(g["carrier_thresh"]),
-        tuple(int(v) for v in g["carrier_window"]), tuple(g["corr_thresh"]), num=int(g["num"]))
+        tuple(int(v) for v in g["carrier_window"]), tuple(g["corr_thresh"]), num=int(g["num"]),
+        interpolator=str(g["interpolator"]) if "interpolator" in g.files else "parabolic")
+    from conftest import golden_blocks
     lines = []
-    for i, raw in enumerate(g["blocks"]):
+    for i, raw in enumerate(golden_blocks(g)):
         if g["index_error"][i]:
             with pytest.raises(IndexError):
                 orc.detect_u8(int(g["block_idx"][i]), raw)
@@ -192,7 +197,10 @@ def test_preshift_oracle_matches_reference_records(golden, name):
         assert car.energy == g["cenergy"][i] and car.noise == g["cnoise"][i]
         if not car.detected:
             continue
-        assert isinstance(car.offset, np.float32) and car.offset == g["coff"][i]
+        if "interpolator" in g.files and str(g["interpolator"]) == "none":
+            assert car.offset == 0 and isinstance(car.offset, int)
+        else:
+            assert isinstance(car.offset, np.float32) and car.offset == g["coff"][i]
         assert orc.last[1] == g["frac_shift"][i]
         cs = res.corr
         assert cs.sample == g["sample"][i]

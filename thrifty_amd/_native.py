@@ -31,6 +31,7 @@ EXPORTS = [
     "thr_set_stream_default", "thr_format_toad",
 ]
 VARIANT_DEFAULT, VARIANT_PRESHIFT, VARIANT_FASTDET = 0, 1, 2      # THR_VARIANT_*
+INTERPOLATORS = {"parabolic": 0, "none": 1, "gaussian": 2, "cosine": 3}      # THR_INTERP_*
 PATHS = {"auto": 0, "multipass": 1, "unsectioned": 2}             # THR_PATH_*
 MAX_IN_FLIGHT = 3       # THR_MAX_IN_FLIGHT
 TOAD_LINE_MAX = 384     # THR_TOAD_LINE_MAX
@@ -190,7 +191,7 @@ def format_toad(recs, timestamps, new_len, rxid=None, with_txid=False, carrier_o
     used = C.c_size_t(0)
     _check(lib, lib.thr_format_toad(recs.ctypes.data, ts.ctypes.data, n, int(new_len),
                                     0 if rxid is None else 1, 0 if rxid is None else int(rxid),
-                                    int(bool(with_txid)), int(bool(carrier_offset_f32)),
+                                    int(bool(with_txid)), int(carrier_offset_f32),
                                     buf.ctypes.data, buf.size, C.byref(used)))
     return buf[:used.value].tobytes()
 
@@ -299,13 +300,14 @@ class Engine(object):
 
     def __init__(self, block_len, history_len, templates, carrier_thresh, carrier_window,
                  corr_thresh, carrier_len=0, device_id=0, max_batch=256, preshift_num=0,
-                 fastdet=False, path="auto"):
+                 fastdet=False, path="auto", interpolator="parabolic"):
         """preshift_num > 0 selects the PreshiftDetector variant (thr_create_preshift);
         fastdet=True the fastdet-compatible one (thr_create_fastdet, power-domain thresholds).
         path: "auto" (the fastest kernels for the block length), "multipass" (the generic
         multi-pass pipeline whatever the length) or "unsectioned" (block_len 32768 / 65536: one
         long transform pair instead of overlap-save sections) -- thr_create_ex's THR_PATH_*; the
-        non-default paths are independent implementations kept for cross-checks."""
+        non-default paths are independent implementations kept for cross-checks.
+        interpolator (preshift variant): "parabolic" | "none" | "gaussian" | "cosine" (THR_INTERP_*)."""
         lib = load_library()
         tpl = np.ascontiguousarray(np.atleast_2d(np.asarray(templates, dtype=np.float64)))
         if tpl.ndim != 2:
@@ -323,7 +325,8 @@ class Engine(object):
         st.device_id, st.max_batch = int(device_id), int(max_batch)
         handle = C.c_void_p()
         variant = VARIANT_FASTDET if fastdet else VARIANT_PRESHIFT if preshift_num else VARIANT_DEFAULT
-        _check(lib, lib.thr_create_ex(C.byref(st), variant, int(preshift_num), PATHS[path], C.byref(handle)))
+        arg = int(preshift_num) | (INTERPOLATORS[interpolator] << 16 if preshift_num and not fastdet else 0)
+        _check(lib, lib.thr_create_ex(C.byref(st), variant, arg, PATHS[path], C.byref(handle)))
         self.path = path
         self.preshift_num = int(preshift_num)
         self._lib, self._h = lib, handle

@@ -964,7 +964,7 @@ const char* thr_kernel_name(int slot) {
 }
 
 static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out, int variant = -1,
-                       int path = THR_PATH_AUTO);
+                       int path = THR_PATH_AUTO, int interp = 0);
 
 int thr_create(const thr_settings* s, thr_handle** out) { return create_impl(s, 0, out); }
 
@@ -982,12 +982,15 @@ int thr_create_fastdet(const thr_settings* s, thr_handle** out) {
     return create_fastdet(s, out, THR_PATH_AUTO);
 }
 
-static int create_preshift(const thr_settings* s, int num_shifts, thr_handle** out, int path) {
+static int create_preshift(const thr_settings* s, int num_arg, thr_handle** out, int path) {
+    const int num_shifts = num_arg & 0xFFFF, interp = (num_arg >> 16) & 0xFFFF;
+    if (num_arg < 0 || interp > THR_INTERP_COSINE)
+        return fail(THR_ERR_ARG, "unknown carrier interpolator %d", interp);
     if (num_shifts < 1 || num_shifts > 4096)
         return fail(THR_ERR_ARG, "num_shifts %d out of range [1, 4096]", num_shifts);
     if (s && s->n_templates != 1)
         return fail(THR_ERR_ARG, "the preshift variant takes exactly one template");
-    return create_impl(s, num_shifts, out, -1, path);
+    return create_impl(s, num_shifts, out, -1, path, interp);
 }
 
 int thr_create_preshift(const thr_settings* s, int num_shifts, thr_handle** out) {
@@ -1070,7 +1073,8 @@ int thr_create_ex(const thr_settings* s, int variant, int variant_arg, int path,
 }
 
 
-static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out, int variant, int path) {
+static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out, int variant, int path,
+                       int interp) {
     if (!s || !out) return fail(THR_ERR_ARG, "thr_create: null argument");
     *out = nullptr;
     const int n = s->block_len;
@@ -1149,6 +1153,7 @@ static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out
             hipMemset(d.timeline, 0, 128 * sizeof(unsigned long long));
 #endif
         d.variant = variant >= 0 ? variant : (preshift_num ? 1 : 0);
+        d.interp = d.variant == 1 ? interp : 0;
         d.car_want_std = s->carrier_thresh[2] != 0.0;
         d.car_prune = 0;
         bool prune_ok = !d.car_want_std;
@@ -1846,7 +1851,10 @@ int thr_format_toad(const thr_record* recs, const double* timestamps, size_t n, 
         *p++ = ' ';
         p = put_int(p, r.carrier_bin);
         *p++ = ' ';
-        p = py_repr_double(p, carrier_offset_f32 ? double(float(r.carrier_offset)) : r.carrier_offset);
+        if (carrier_offset_f32 == 2)      // an int-typed offset (interpolator `none`): Python prints "0"
+            p = put_int(p, (long long)r.carrier_offset);
+        else
+            p = py_repr_double(p, carrier_offset_f32 ? double(float(r.carrier_offset)) : r.carrier_offset);
         *p++ = ' ';
         p = py_repr_double(p, double(r.carrier_energy));
         *p++ = ' ';

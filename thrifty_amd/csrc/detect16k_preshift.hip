@@ -101,11 +101,29 @@ __device__ __forceinline__ PreshiftVerdict preshift_verdict(const DevCfg& cfg, f
     v.carrier = peak_mag > thr;
     v.peak_mag = peak_mag;
     v.noise_rms = noise_rms;
-    v.index_error = v.carrier && peak_idx + 1 >= n;   // fft_mag[peak + 1] (carrier_interpolators.py:47)
+    // (every interpolator but `none` reads fft_mag[peak + 1]: carrier_interpolators.py:47,55,94)
+    v.index_error = v.carrier && cfg.interp != THR_INTERP_NONE && peak_idx + 1 >= n;
     if (v.index_error) v.carrier = false;
     const float b = peak_mag;
-    const float two_a = 2.0f * a, two_c = 2.0f * c, four_b = 4.0f * b;
-    v.offset = v.carrier ? (c - a) / ((four_b - two_a) - two_c) : 0.0f;
+    v.offset = 0.0f;
+    if (v.carrier) {
+        // float32 in, float32 out, operation by operation as NumPy evaluates the reference's lines
+        if (cfg.interp == THR_INTERP_PARABOLIC) {            // carrier_interpolators.py:44-49
+            const float two_a = 2.0f * a, two_c = 2.0f * c, four_b = 4.0f * b;
+            v.offset = (c - a) / ((four_b - two_a) - two_c);
+        } else if (cfg.interp == THR_INTERP_GAUSSIAN) {      // :52-58, the same on the logarithms
+            const float la = logf(a), lb = logf(b), lc = logf(c);
+            const float two_a = 2.0f * la, two_c = 2.0f * lc, four_b = 4.0f * lb;
+            v.offset = (lc - la) / ((four_b - two_a) - two_c);
+        } else if (cfg.interp == THR_INTERP_COSINE) {        // :92-100
+            const float cos_omega = (a + c) / (2.0f * b);
+            if (!(cos_omega > 1.0f)) {
+                const float omega = acosf(cos_omega);
+                const float theta = atanf((a - c) / ((2.0f * b) * sinf(omega)));
+                v.offset = -theta / omega;
+            }
+        }
+    }
     v.offset_f64 = double(v.offset);
     // shift = -(bin + offset), integer part rolled, rest -> nearest bank entry
     // (carrier_sync.py:71, detect_preshift.py:62-65,42-45; np.round == rint, half to even)

@@ -35,6 +35,7 @@ struct DevCfg {
                        // 2 any window of <= 122 bins (samples pre-shifted by win_lo - 3)
     const void* gtw;   // [16][1024] W_16384^(k1 q) for k_correlate's passes 1 and B (kernels compiled for the LDS-table form ignore it)
     int variant;       // 0 reference Detector, 1 PreshiftDetector, 2 fastdet-compatible (power-domain verdicts)
+    int interp;        // PreshiftDetector: carrier interpolator (THR_INTERP_*: 0 parabolic, 1 none, 2 gaussian, 3 cosine)
     // Overlap-save sections of the correlate stage (block_len > 16384, detect_seg.hip; 0 = none):
     // section g covers samples [seg_start[g], seg_start[g] + 16384) of a block.  In SECTION
     // coordinates (lag - seg_start[g]): it owns the window lags [seg_lo[g], seg_hi[g]) and, for the

@@ -42,6 +42,11 @@ def unique_window(block_len, history_len, template_len):
     return pad // 2, corr_len - (pad - pad // 2)
 
 
+def _offset_mode(offset_type):
+    """thr_format_toad's carrier_offset_f32 argument for a Detector's `_offset_type`."""
+    return 0 if offset_type is float else 2 if offset_type is int else 1
+
+
 class _Deferred(object):
     """An exception that belongs to one position of a batch: raised when that position is
     reached, after the results before it have been delivered."""
@@ -140,7 +145,7 @@ class Detector(object):
 
     def __init__(self, settings, blocks=None, rxid=-1, yield_data=False, batch_size=None,
                  device_id=0, _preshift_num=0, _fastdet=False, max_wait=None, max_fill=None,
-                 pin_input=True):
+                 pin_input=True, _interpolator="parabolic"):
         """Batching a classic `(timestamp, idx, block)` iterator must not hold results back the way
         the reference's per-block loop never did.  What ends the batch being filled (what has
         arrived is processed instead of waiting for a full batch) depends on what the source says
@@ -186,7 +191,7 @@ class Detector(object):
             settings.block_len, settings.history_len, template, settings.carrier_thresh,
             settings.carrier_window, settings.corr_thresh, carrier_len=settings.carrier_len,
             device_id=device_id, max_batch=self.batch_size, preshift_num=_preshift_num,
-            fastdet=_fastdet)
+            fastdet=_fastdet, interpolator=_interpolator)
         # a mapped input file becomes the engine's input window: a library thread page-locks it a
         # bounded distance ahead of the chunk copies, which are then asynchronous DMA out of the
         # page cache -- this thread frames the next batch and formats the previous one meanwhile
@@ -490,7 +495,7 @@ class Detector(object):
         `DetectionResult.serialize()`, byte for byte) -- what `detector_cli --quiet -o` writes."""
         for stamps, recs in self.iter_detected_records():
             yield _native.format_toad(recs, stamps, self.new_len, rxid=self.rxid, with_txid=self._multi,
-                                      carrier_offset_f32=self._offset_type is not float)
+                                      carrier_offset_f32=_offset_mode(self._offset_type))
 
     def iter_toad_lines(self):
         """The same as lists of lines (str, no line ends)."""

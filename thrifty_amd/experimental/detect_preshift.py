@@ -18,24 +18,35 @@ import argparse
 import numpy as np
 
 from thrifty_amd.detect import Detector, detector_cli
-from thrifty_amd.experimental.carrier_interpolators import parabolic
+from thrifty_amd.experimental.carrier_interpolators import INTERPOLATORS, parabolic
 
 NUM_TEMPLATES = 21
 
 
 class PreshiftDetector(Detector):
-    """Same constructor as the reference (detect_preshift.py:48-60).  `interpolator` must be
-    `parabolic` (the reference default and the only one with a device implementation);
-    `corr_shift` is accepted and ignored -- the reference constructor forces it off too
+    """Same constructor as the reference (detect_preshift.py:48-60).  `interpolator`: one of
+    `carrier_interpolators.none / parabolic / gaussian / cosine` (the function or its name; the
+    reference default is `parabolic`; `None` keeps the default too, as in the reference, where it
+    leaves the Detector's own interpolator in place -- which here is not a device stage of this
+    variant).  `corr_shift` is accepted and ignored -- the reference constructor forces it off too
     (detect_preshift.py:60)."""
 
-    _fit_reach = 1                 # parabolic() reads fft_mag[peak + 1]
+    _fit_reach = 1                 # the three-point interpolators read fft_mag[peak + 1]
     _offset_type = np.float32      # float32 magnitudes in -> float32 offset out, as in the reference
 
     def __init__(self, settings, blocks=None, rxid=-1, yield_data=False, num=NUM_TEMPLATES,
                  interpolator=parabolic, corr_shift=False, batch_size=None, device_id=0):
-        if interpolator is not parabolic and interpolator != "parabolic":
-            raise NotImplementedError("only the parabolic carrier interpolator runs on the device")
+        names = dict((fn, name) for name, fn in INTERPOLATORS.items())
+        if interpolator is None:
+            interpolator = parabolic
+        name = names.get(interpolator, interpolator if isinstance(interpolator, str) else None)
+        if name not in INTERPOLATORS:
+            raise NotImplementedError("carrier interpolators with a device implementation: %s "
+                                      "(pass the function from thrifty_amd.experimental."
+                                      "carrier_interpolators or its name)" % ", ".join(sorted(INTERPOLATORS)))
+        self.interpolator = name
+        if name == "none":
+            self._offset_type = int      # none() returns the int 0: the .toad column reads "0"
         if yield_data:
             raise NotImplementedError("yield_data is not available in the preshift variant")
         if np.asarray(settings.template).ndim != 1:
@@ -45,7 +56,7 @@ class PreshiftDetector(Detector):
         self.corr_shift = False
         super(PreshiftDetector, self).__init__(settings, blocks, rxid, yield_data,
                                                batch_size=batch_size, device_id=device_id,
-                                               _preshift_num=self.num)
+                                               _preshift_num=self.num, _interpolator=name)
         self.shifts = np.linspace(-0.5, 0.5, self.num)   # TemplateShifts.shifts
 
 

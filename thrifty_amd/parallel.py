@@ -129,6 +129,7 @@ def run_sharded(detections, rank, world, local, output_file, backend="nccl"):
     import torch
     import torch.distributed as dist
     from thrifty_amd import _native
+    from thrifty_amd.detect import _offset_mode
 
     if backend == "nccl":       # RCCL; "gloo" (CPU tensors) is for the tests of this function
         dev = torch.device("cuda", local)
@@ -167,7 +168,7 @@ def run_sharded(detections, rank, world, local, output_file, backend="nccl"):
             text = _native.format_toad(
                 recs[s:s + step], stamps[s:s + step], detections.new_len, rxid=detections.rxid,
                 with_txid=getattr(detections, "_multi", False),
-                carrier_offset_f32=getattr(detections, "_offset_type", float) is not float)
+                carrier_offset_f32=_offset_mode(getattr(detections, "_offset_type", float)))
             output_file.write(text.decode("ascii"))
         output_file.flush()
     dist.barrier()
