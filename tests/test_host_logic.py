@@ -483,3 +483,27 @@ def test_native_card_framing_equals_python_framing():
     cs = block_data.CardStream(io.BytesIO(b"hello\n"), n)
     with pytest.raises(ValueError):
         cs.next_batch(4)
+
+
+def test_bench_gpus_n_starts_its_own_ranks_and_fails_loudly_without_a_gpu():
+    """`python bench.py --gpus 2` with no torchrun around it re-launches itself under
+    torch.distributed.run (what the driver's launch line does); on a box without an MI355X every
+    rank then refuses to run -- there is no CPU fallback to time."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("a GPU is present: the GPU suite runs this for real")
+    except ImportError:
+        pytest.skip("no torch")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo",
+                          "--steps", "1", "--warmup", "0", "--legs", "none", "--cpu-seconds", "0"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode != 0
+    assert res.stderr.count("bench.py needs an MI355X; there is no CPU fallback") >= 1
+    assert "torch.distributed" in res.stderr          # the ranks were started by the launcher
+    assert not [ln for ln in res.stdout.split("\n") if ln.startswith("{")]     # and no line was fabricated
