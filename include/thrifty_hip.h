@@ -116,7 +116,8 @@ int thr_create(const thr_settings* settings, thr_handle** out);
  * point then behaves as documented with these semantics: carrier_offset is the float32
  * parabola offset; THR_FLAG_INDEX_ERROR marks carrier_bin + 1 >= block_len (where the
  * reference's fft_mag[peak+1] raises); `reserved` = (uint32 rolled shift << 32) | bank
- * index.  One template only; thr_debug_* stage dumps are unavailable.  block_len 16384
+ * index.  One template only; thr_debug_stage dumps (np.roll(FFT#1, shift) and the correlation,
+ * what the reference class returns under yield_data) need a THR_PATH_MULTIPASS handle.  block_len 16384
  * runs ONE fused kernel per block (FFT, verdict, gather-multiply, IFFT); other lengths
  * use the multi-pass pipeline.
  */

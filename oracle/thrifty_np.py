@@ -356,8 +356,16 @@ class OraclePreshiftDetector(object):
         self.corr_thresh = corr_thresh
         self.last = None        # (int_shift, frac_shift, template index) of the last block
 
-    def detect_block(self, block_idx, x):
+    def detect_block(self, block_idx, x, want_data=False):
+        """want_data: also return (rolled FFT#1, correlation) -- what the reference class hands out
+        under yield_data (detect.py:60-78 with the shifter / despreader of detect_preshift.py:62-80)."""
+        out = self._detect_block(block_idx, x)
+        data, self._data = self._data, None
+        return (out, data) if want_data else out
+
+    def _detect_block(self, block_idx, x):
         assert len(x) == self.block_len
+        self._data = None
         spec = np.fft.fft(x)                       # complex64 in -> complex64 out
         mag = np.abs(spec)
         det, idx, peak, noise, thr = carrier_detect(mag, self.carrier_thresh,
@@ -376,6 +384,7 @@ class OraclePreshiftDetector(object):
         j = self.shifted.nearest(frac)
         self.last = (int_shift, frac, j)
         corr = np.fft.ifft(rolled * self.shifted.spectra_conj[j])[: self.shifted.corr_len]
+        self._data = (rolled, corr)
         # the rest is soa_estimator.py:78-92 unchanged (noise from the rolled complex64 FFT#1)
         cmag = np.abs(corr)
         pk, peak_mag = corr_peak(cmag, self.bank.window)
@@ -386,8 +395,8 @@ class OraclePreshiftDetector(object):
         cs = CorrStage(cdet, pk, coff, peak_mag, cnoise, cthr)
         return BlockResult(cdet, self.new_len * block_idx + pk + coff, car, cs)
 
-    def detect_u8(self, block_idx, raw):
-        return self.detect_block(block_idx, iq_u8_to_c64(raw))
+    def detect_u8(self, block_idx, raw, want_data=False):
+        return self.detect_block(block_idx, iq_u8_to_c64(raw), want_data)
 
 
 # --------------------------------------------------------------------------

@@ -161,3 +161,42 @@ def test_index_error_is_raised_like_the_reference(golden):
     bad = int(np.flatnonzero(g["index_error"])[0])
     with pytest.raises(IndexError):
         det.detect(0.0, 0, g["blocks"][bad])
+
+
+@pytest.mark.parametrize("name,n_check", [("preshift_c2", 6), ("preshift_small", 6)])
+def test_yield_data_returns_the_rolled_spectrum_and_the_correlation(golden, name, n_check):
+    """Reference: PreshiftDetector(..., yield_data=True).detect() -> (detected, result, rolled
+    FFT#1, correlation) (detect.py:60-78 with detect_preshift.py:62-80).  Served by the multi-pass
+    kernels; records equal the fused kernel's, dumps equal the oracle's intermediates."""
+    g = golden(name)
+    n, h = int(g["block_len"]), int(g["history_len"])
+    st = DetectorSettings(n, h, len(g["template"]), tuple(g["carrier_thresh"]),
+                          tuple(int(v) for v in g["carrier_window"]), g["template"], tuple(g["corr_thresh"]))
+    det = PreshiftDetector(st, None, rxid=0, yield_data=True, num=int(g["num"]))
+    plain = PreshiftDetector(st, None, rxid=0, num=int(g["num"]))
+    orc = onp.OraclePreshiftDetector(n, h, g["template"], tuple(g["carrier_thresh"]),
+                                     tuple(int(v) for v in g["carrier_window"]), tuple(g["corr_thresh"]),
+                                     num=int(g["num"]))
+    seen = 0
+    for i in range(len(g["blocks"])):
+        if g["index_error"][i]:
+            continue
+        detected, res, rolled, corr = det.detect(1.0, int(g["block_idx"][i]), g["blocks"][i])
+        d2, r2 = plain.detect(1.0, int(g["block_idx"][i]), g["blocks"][i])
+        assert detected == d2 == bool(g["det"][i])
+        assert res.carrier_info.bin == r2.carrier_info.bin == g["cbin"][i]
+        if not g["carrier_det"][i]:
+            assert rolled is None and corr is None and res.corr_info is None
+            continue
+        assert res.corr_info.sample == r2.corr_info.sample == g["sample"][i]
+        np.testing.assert_allclose(res.corr_info.energy, r2.corr_info.energy, rtol=2e-5)
+        _, (orolled, ocorr) = orc.detect_u8(int(g["block_idx"][i]), g["blocks"][i], want_data=True)
+        assert rolled.shape == (n,) and corr.shape == ocorr.shape == (n - len(g["template"]) + 1,)
+        assert np.linalg.norm(rolled - orolled) / np.linalg.norm(orolled) < 2e-6
+        assert np.linalg.norm(corr - ocorr) / np.linalg.norm(ocorr) < 1e-5
+        lo, hi = det.soa_estimate.window
+        assert int(np.argmax(np.abs(corr[lo:hi]))) + lo == res.corr_info.sample
+        seen += 1
+        if seen >= n_check:
+            break
+    assert seen >= 4

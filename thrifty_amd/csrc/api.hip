@@ -701,7 +701,8 @@ int run_batch_fast(thr_handle* h, const void* d_samples_all, int format,
     if (h->preshift_num) {
         const int grid = std::min(n_blocks_all, h->n_cu);
         if (dump_fft || dump_xhat || dump_corr || carrier_only)
-            return fail(THR_ERR_ARG, "stage dumps are not available in the preshift variant");
+            return fail(THR_ERR_ARG, "the fused preshift kernel has no stage dumps: create the handle with "
+                                     "THR_PATH_MULTIPASS (thr_create_ex) for them");
         {
             ProfScope p(h, 2);   // the fused kernel is accounted in k_correlate's slot
             HIP_TRY(thr::launch_preshift_16k(format, d_samples_all, n_blocks_all, h->dev, h->d_tables,
@@ -777,20 +778,24 @@ int run_batch_generic(thr_handle* h, const void* d_samples, int format,
                                    hipMemcpyDeviceToDevice, h->stream));
         if (carrier_only) continue;
         if (h->preshift_num) {
-            if (dump_xhat || dump_corr)
-                return fail(THR_ERR_ARG, "stage dumps are not available in the preshift variant");
             {
                 ProfScope p(h, 1);
                 HIP_TRY(thr::launch_fit_preshift(nb, h->dev, h->preshift_num, h->d_stats,
                                                  d_block_idx ? d_block_idx + off : nullptr,
                                                  h->d_shifts, out, h->stream));
             }
+            float2* cc = nullptr;
             {
                 ProfScope p(h, 2);
                 HIP_TRY(thr::generic_preshift_correlate(nb, h->dev, h->d_twn, h->d_bank, h->d_shifts,
                                                         out, h->d_gen_scratch, spectrum,
-                                                        h->d_corr_stats, h->stream));
+                                                        h->d_corr_stats,
+                                                        dump_xhat ? dump_xhat + size_t(off) * n : nullptr,
+                                                        dump_corr ? &cc : nullptr, h->stream));
             }
+            if (dump_corr && cc)
+                HIP_TRY(hipMemcpyAsync(dump_corr + size_t(off) * n, cc, size_t(nb) * n * sizeof(float2),
+                                       hipMemcpyDeviceToDevice, h->stream));
             ProfScope p(h, 3);
             HIP_TRY(thr::launch_finish(nb, h->dev, h->d_corr_stats, out, h->d_work_count, h->stream));
             continue;

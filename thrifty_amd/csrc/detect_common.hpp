@@ -183,6 +183,8 @@ hipError_t generic_preshift_correlate(int n_blocks, const DevCfg& cfg, const flo
                                       const float2* bank_nat, const ShiftParams* shifts,
                                       const thr_record* records, float2* scratch,
                                       const float2* spectrum, CorrStats* corr_stats,
-                                      hipStream_t stream);
+                                      float2* dump_rolled, float2** keep_corr, hipStream_t stream);
+// (dump_rolled / keep_corr: the stage dumps of yield_data -- np.roll(FFT#1, round(shift)), natural
+// order, [block][n], written for carrier-positive blocks; where the correlation was left)
 
 }  // namespace thr

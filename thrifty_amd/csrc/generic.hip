@@ -196,8 +196,9 @@ __global__ __launch_bounds__(256) void g_mult(const cpx2* __restrict__ xhat,
 }
 
 // ---- preshift variant: roll(X, s)[k] * conj(T_bank)[k] / N, evaluated as X[k'] * Tc[(k' + s) mod N]
-// (the product comes out rotated by -s, which only modulates the correlation's phase;
-// carrier_sync.py:241-245, detect_preshift.py:67-70)
+// (written at the ROLLED index, k = i + s: out[k] = roll(X, s)[k] * Tc_j[k], the reference's product
+// term for term -- carrier_sync.py:241-245, detect_preshift.py:67-70 -- so that the correlation is
+// the reference's, phase included, for the stage dumps of yield_data)
 __global__ __launch_bounds__(256) void g_mult_preshift(const cpx2* __restrict__ spectrum,
                                                        const cpx2* __restrict__ bank, int n,
                                                        int log2n, int n_blocks,
@@ -209,7 +210,20 @@ __global__ __launch_bounds__(256) void g_mult_preshift(const cpx2* __restrict__ 
     if (b >= n_blocks) return;
     if (!(records[b].flags & THR_FLAG_CARRIER)) return;
     const ShiftParams* sp = shifts + b;
-    out[gid] = gmul(spectrum[gid], bank[size_t(sp->bank) * n + ((i + sp->si_mod) & (n - 1))]);
+    const int k = (i + sp->si_mod) & (n - 1);
+    out[size_t(b) * n + k] = gmul(spectrum[gid], bank[size_t(sp->bank) * n + k]);
+}
+
+// ---- stage dump of the preshift variant: np.roll(FFT#1, round(shift)) (carrier_sync.py:241-245)
+__global__ __launch_bounds__(256) void g_roll(const cpx2* __restrict__ spectrum, int n, int log2n,
+                                              int n_blocks, const ShiftParams* __restrict__ shifts,
+                                              const thr_record* __restrict__ records,
+                                              cpx2* __restrict__ out) {
+    const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int b = int(gid >> log2n), i = int(gid & size_t(n - 1));
+    if (b >= n_blocks) return;
+    if (!(records[b].flags & THR_FLAG_CARRIER)) return;
+    out[size_t(b) * n + ((i + shifts[b].si_mod) & (n - 1))] = spectrum[gid];
 }
 
 // ---- correlation statistics of one block per workgroup (soa_estimator.py:137-143 + sums)
@@ -380,7 +394,7 @@ hipError_t generic_preshift_correlate(int n_blocks, const DevCfg& cfg, const flo
                                       const float2* bank_nat, const ShiftParams* shifts,
                                       const thr_record* records, float2* scratch,
                                       const float2* spectrum, CorrStats* corr_stats,
-                                      hipStream_t stream) {
+                                      float2* dump_rolled, float2** keep_corr, hipStream_t stream) {
     const int n = cfg.block_len, log2n = ilog2(n);
     cpx2* a = reinterpret_cast<cpx2*>(scratch);
     cpx2* b = a + size_t(n_blocks) * n;
@@ -398,6 +412,10 @@ hipError_t generic_preshift_correlate(int n_blocks, const DevCfg& cfg, const flo
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(g_corr_stats, dim3(n_blocks), blk, 0, stream, corr, spec, cfg, 0, records,
                        corr_stats);
+    if (keep_corr) *keep_corr = reinterpret_cast<float2*>(corr);
+    if (dump_rolled)
+        hipLaunchKernelGGL(g_roll, grid, blk, 0, stream, spec, n, log2n, n_blocks, shifts, records,
+                           reinterpret_cast<cpx2*>(dump_rolled));
     return hipGetLastError();
 }
 

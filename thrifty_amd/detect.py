@@ -145,7 +145,7 @@ class Detector(object):
 
     def __init__(self, settings, blocks=None, rxid=-1, yield_data=False, batch_size=None,
                  device_id=0, _preshift_num=0, _fastdet=False, max_wait=None, max_fill=None,
-                 pin_input=True, _interpolator="parabolic"):
+                 pin_input=True, _interpolator="parabolic", _path="auto"):
         """Batching a classic `(timestamp, idx, block)` iterator must not hold results back the way
         the reference's per-block loop never did.  What ends the batch being filled (what has
         arrived is processed instead of waiting for a full batch) depends on what the source says
@@ -191,7 +191,7 @@ class Detector(object):
             settings.block_len, settings.history_len, template, settings.carrier_thresh,
             settings.carrier_window, settings.corr_thresh, carrier_len=settings.carrier_len,
             device_id=device_id, max_batch=self.batch_size, preshift_num=_preshift_num,
-            fastdet=_fastdet, interpolator=_interpolator)
+            fastdet=_fastdet, interpolator=_interpolator, path=_path)
         # a mapped input file becomes the engine's input window: a library thread page-locks it a
         # bounded distance ahead of the chunk copies, which are then asynchronous DMA out of the
         # page cache -- this thread frames the next batch and formats the previous one meanwhile

@@ -47,8 +47,6 @@ class PreshiftDetector(Detector):
         self.interpolator = name
         if name == "none":
             self._offset_type = int      # none() returns the int 0: the .toad column reads "0"
-        if yield_data:
-            raise NotImplementedError("yield_data is not available in the preshift variant")
         if np.asarray(settings.template).ndim != 1:
             raise ValueError("PreshiftDetector takes one 1-D template")
         self.num = int(num)
@@ -56,7 +54,11 @@ class PreshiftDetector(Detector):
         self.corr_shift = False
         super(PreshiftDetector, self).__init__(settings, blocks, rxid, yield_data,
                                                batch_size=batch_size, device_id=device_id,
-                                               _preshift_num=self.num, _interpolator=name)
+                                               _preshift_num=self.num, _interpolator=name,
+                                               # (stage dumps -- the rolled FFT#1 and the correlation the
+                                               # reference returns under yield_data -- come from the
+                                               # multi-pass kernels; the fused kernel keeps neither)
+                                               _path="multipass" if yield_data else "auto")
         self.shifts = np.linspace(-0.5, 0.5, self.num)   # TemplateShifts.shifts
 
 
