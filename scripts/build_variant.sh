@@ -1,6 +1,6 @@
 #!/bin/bash
 # dev: build the library with extra compile flags into ab/<name>.so (for scripts/ab.sh), then
-# restore the default build.   scripts/build_variant.sh dev -DTHR_DEV
+# (afterwards `python -m thrifty_amd.build` restores the default: the flag stamp forces the rebuild).   scripts/build_variant.sh dev -DTHR_DEV
 set -e
 cd "$(dirname "$0")/.."
 NAME=$1; shift

@@ -38,7 +38,8 @@ def framed(raw, n, h, first, count):
 @pytest.mark.parametrize("n,h,bits,sps", [
     (16384, 4096, 10, 1.0),     # fast path, BASELINE C2 geometry
     (16384, 4920, 10, 1.0),     # example-config history (stride not a multiple of 64 bytes)
-    (32768, 4096, 11, 1.0),     # long path, R0 = 2
+    (32768, 4096, 11, 1.0),     # long path, R0 = 2 (three overlap-save sections on strided blocks)
+    (65536, 4098, 11, 2.0),     # BASELINE C3's template, five sections, stride not a multiple of 16 bytes
     (4096, 1024, 9, 1.0),       # short-block LDS path (4 blocks per workgroup)
     (8192, 2050, 10, 1.0),      # short blocks, block starts only 4-byte aligned (stride 12284 B)
     (2048, 502, 8, 1.0),        # 8 blocks per workgroup, stride 3092 B

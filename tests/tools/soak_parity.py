@@ -2,7 +2,8 @@
 the oracle spread over worker processes.  Usage: soak_parity.py [n_blocks] [procs] [variant]
 variant: default (BASELINE configs[1]) | preshift | fullwin (configs[1] with the reference's default
 carrier window '0--1': the full-spectrum carrier kernel) | c3 (configs[2]: 65536-sample blocks, the
-sectioned correlate stage) | c3u (the same through the unsectioned kernels)"""
+sectioned correlate stage) | c3u (the same through the unsectioned kernels) | n32k (32768-sample
+blocks, same template: three sections)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import multiprocessing as mp
@@ -15,6 +16,8 @@ def geometry(variant):
     """(block_len, carrier window, Gold bits, samples per chip)"""
     if variant in ("c3", "c3u"):
         return 65536, (7, 110), 11, 2.0
+    if variant == "n32k":          # 32768-sample blocks: three sections with unequal windows
+        return 32768, (7, 110), 11, 2.0
     return 16384, ((0, -1) if variant == "fullwin" else (7, 110)), 10, 1.0
 
 
