@@ -1190,14 +1190,28 @@ static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out
         rc = fail(THR_ERR_DEVICE, "%s failed (%s)", #expr, hipGetErrorString(hipGetLastError())); \
         break;                                                                        \
     }
-        if (h->fast) CREATE_TRY(thr::prepare_16k());
-        if (h->fast && preshift_num) CREATE_TRY(thr::prepare_preshift_16k());
-        if (h->small) CREATE_TRY(thr::prepare_small(n));
+        // (the > 64 KiB dynamic-LDS opt-in is per device and kernel, not per handle: each family of
+        // kernels is prepared once per device and process -- dozens of hipFuncSetAttribute calls
+        // that a second handle on the same device need not repeat)
+        static std::mutex prep_mu;
+        static std::vector<unsigned> prepared;      // per device: bit per kernel family / block length
+        auto once = [&](unsigned bit, auto&& fn) -> hipError_t {
+            std::lock_guard<std::mutex> lk(prep_mu);
+            if (prepared.size() <= size_t(h->device)) prepared.resize(size_t(h->device) + 1, 0u);
+            if (prepared[h->device] & bit) return hipSuccess;
+            const hipError_t e = fn();
+            if (e == hipSuccess) prepared[h->device] |= bit;
+            return e;
+        };
+        const unsigned len_bit = 1u << (8 + (31 - __builtin_clz(unsigned(n))) % 20);   // (per block length)
+        if (h->fast) CREATE_TRY(once(1u, [] { return thr::prepare_16k(); }));
+        if (h->fast && preshift_num) CREATE_TRY(once(2u, [] { return thr::prepare_preshift_16k(); }));
+        if (h->small) CREATE_TRY(once(len_bit, [&] { return thr::prepare_small(n); }));
         if (h->seg) {
-            CREATE_TRY(thr::prepare_seg());
+            CREATE_TRY(once(4u, [] { return thr::prepare_seg(); }));
         }
         if (h->lng) {
-            CREATE_TRY(thr::prepare_long(n));
+            CREATE_TRY(once(len_bit, [&] { return thr::prepare_long(n); }));
             const int r0 = n / 16384;
             // sub-batch: large enough to amortise the kernels' launch latency, ramps and tails
             // (the exchange rows no longer grow with it -- one row set per workgroup -- so the
