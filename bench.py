@@ -346,7 +346,7 @@ def preflight(torch, dist, dev, cdev, rank, world, local, total, first, shared_g
     if int(one.item()) != world:
         raise SystemExit("pre-flight: all_reduce over %s counted %d ranks, expected %d"
                          % (dist.get_backend(), int(one.item()), world))
-    mine = {"rank": rank, "local_rank": local, "device": torch.cuda.get_device_name(dev),
+    mine = {"rank": rank, "local_rank": local, "cuda": dev.index, "device": torch.cuda.get_device_name(dev),
             "pci": getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None),
             "blocks": [first, first + total], "pid": os.getpid()}
     everyone = [None] * world
@@ -358,7 +358,7 @@ def preflight(torch, dist, dev, cdev, rank, world, local, total, first, shared_g
             raise SystemExit("pre-flight: ranks do not tile the block range / share a device: %r" % (everyone,))
         print("pre-flight ok: backend %s, %d rank(s); per-rank blocks: %s" % (
             dist.get_backend(), world, ", ".join("r%d@cuda:%d [%d, %d)" % (
-                e["rank"], e["local_rank"], e["blocks"][0], e["blocks"][1]) for e in everyone)),
+                e["rank"], e["cuda"], e["blocks"][0], e["blocks"][1]) for e in everyone)),
             file=sys.stderr)
 
 
