@@ -141,3 +141,30 @@ def test_input_window_on_a_file_larger_than_the_lock_ahead_distance(golden, tmp_
         eng.close()
         del cs2, b2
         mm.close()
+
+
+def test_device_ingest_equals_the_reference_native_card_reader(golden, tmp_path):
+    """The whole `.card` front end of the engine -- thr_frame_card framing, base64 decode on the
+    device -- against the reference's own native reader (fastcard/card_reader.c + lib/base64.c,
+    oracle/_ref): detection records from the text == records from the bytes the reference
+    decoded, byte for byte."""
+    from oracle import ref_readers
+    if not ref_readers.available():
+        pytest.skip("oracle/_ref/libfastcard_readers.so not built (needs the reference checkout)")
+    g = golden("c2")
+    n = int(g["block_len"])
+    path = tmp_path / "rx.card"
+    path.write_text("# capture\n" + card_text(g))
+    ref, rc = ref_readers.read_blocks(str(path), n, int(g["history_len"]), card=True)
+    assert rc == 1 and len(ref) == len(g["blocks"])
+    ref_bytes = np.stack([r[3] for r in ref])
+    assert np.array_equal(ref_bytes, g["blocks"])
+    eng = engine_for(g, max_batch=8)
+    with open(path, "rb") as f:
+        cs = CardStream(f, n)
+        stamps, idxs, buf, offs = cs.next_batch(1000)
+        rec_text = eng.detect_card(buf, offs, idxs)
+    assert [int(i) for i in idxs] == [r[2] for r in ref]
+    assert all(abs(ts - (r[0] + r[1] * 1e-6)) < 1e-9 for ts, r in zip(stamps, ref))
+    rec_ref = eng.detect(ref_bytes, np.asarray([r[2] for r in ref], dtype=np.int64))
+    assert rec_text.tobytes() == rec_ref.tobytes()
