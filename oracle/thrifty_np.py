@@ -15,6 +15,11 @@ test_soa_estimator.py, test_block_data.py, test_util.py).
 Exception: the fastdet-compatible section near the end is PARITY UNPINNED (its header says
 why); everything else is pinned as described above.
 
+Beside it: ``oracle/_ref/libfastcard_readers.so`` (``oracle/Makefile``, ``oracle/ref_readers.py``)
+-- the reference's own native block readers compiled from /root/reference -- checks the `.card` /
+raw-stream front end a second time (tests/test_ref_readers.py).  The rest of fastcard / fastdet
+needs FFTW3f / VOLK / librtlsdr / argp and cannot be built in this image.
+
 Each function cites the reference file:line it follows (paths relative to the
 reference checkout).  Third-party arithmetic: ``np.fft`` (pocketfft) and
 ``scipy.optimize.curve_fit`` (MINPACK lmdif) exactly as the reference calls
