@@ -81,6 +81,12 @@ __device__ __forceinline__ PreshiftVerdict fastdet_verdict(const DevCfg& cfg, fl
 
 // peak_mag, a, c = |X[peak]|, |X[peak-1]|, |X[peak+1]|
 // (peak_pow = |X[peak]|^2 as summed; only the fastdet verdict, which never takes roots, uses it)
+// PARABOLIC_ONLY: the interpolator is known at compile time to be the reference's default.  With
+// the choice a run-time one inside the fused kernel -- every thread evaluates the verdict -- the
+// logf / acosf / atanf / sinf branches cost k_preshift 17 % (2.32 against 1.92 ms per 32768 blocks)
+// although never taken: the same lesson as the L2-twiddle form of k_correlate, no run-time-selected
+// alternative code inside a hot kernel.
+template <bool PARABOLIC_ONLY = false>
 __device__ __forceinline__ PreshiftVerdict preshift_verdict(const DevCfg& cfg, float peak_pow_raw,
                                                             float peak_mag, float sum_mag2,
                                                             float sum_mag, int peak_idx, float a,
@@ -102,20 +108,20 @@ __device__ __forceinline__ PreshiftVerdict preshift_verdict(const DevCfg& cfg, f
     v.peak_mag = peak_mag;
     v.noise_rms = noise_rms;
     // (every interpolator but `none` reads fft_mag[peak + 1]: carrier_interpolators.py:47,55,94)
-    v.index_error = v.carrier && cfg.interp != THR_INTERP_NONE && peak_idx + 1 >= n;
+    v.index_error = v.carrier && (PARABOLIC_ONLY || cfg.interp != THR_INTERP_NONE) && peak_idx + 1 >= n;
     if (v.index_error) v.carrier = false;
     const float b = peak_mag;
     v.offset = 0.0f;
     if (v.carrier) {
         // float32 in, float32 out, operation by operation as NumPy evaluates the reference's lines
-        if (cfg.interp == THR_INTERP_PARABOLIC) {            // carrier_interpolators.py:44-49
+        if (PARABOLIC_ONLY || cfg.interp == THR_INTERP_PARABOLIC) {   // carrier_interpolators.py:44-49
             const float two_a = 2.0f * a, two_c = 2.0f * c, four_b = 4.0f * b;
             v.offset = (c - a) / ((four_b - two_a) - two_c);
-        } else if (cfg.interp == THR_INTERP_GAUSSIAN) {      // :52-58, the same on the logarithms
+        } else if (!PARABOLIC_ONLY && cfg.interp == THR_INTERP_GAUSSIAN) {   // :52-58, the same on the logarithms
             const float la = logf(a), lb = logf(b), lc = logf(c);
             const float two_a = 2.0f * la, two_c = 2.0f * lc, four_b = 4.0f * lb;
             v.offset = (lc - la) / ((four_b - two_a) - two_c);
-        } else if (cfg.interp == THR_INTERP_COSINE) {        // :92-100
+        } else if (!PARABOLIC_ONLY && cfg.interp == THR_INTERP_COSINE) {     // :92-100
             const float cos_omega = (a + c) / (2.0f * b);
             if (!(cos_omega > 1.0f)) {
                 const float omega = acosf(cos_omega);
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(64) void k_fit_preshift(int n_blocks, DevCfg cfg, i
     records[b] = preshift_record(vd, block_idx ? block_idx[b] : (long long)b, st.peak_idx);
 }
 
-template <int FMT, bool CAR_STD, bool COR_STD>
+template <int FMT, bool CAR_STD, bool COR_STD, bool PARABOLIC_ONLY>
 __global__ __launch_bounds__(NT) void k_preshift(const void* __restrict__ samples, int n_blocks,
                                                  DevCfg cfg, const cpx* __restrict__ tables,
                                                  const cpx* __restrict__ bank, int num,
@@ -259,7 +265,7 @@ __global__ __launch_bounds__(NT) void k_preshift(const void* __restrict__ sample
         const float pa = sc_nb[parity * 2], pc = sc_nb[parity * 2 + 1];
         parity ^= 1;
         const PreshiftVerdict vd =
-            preshift_verdict(cfg, __uint_as_float(unsigned(best >> 32)),
+            preshift_verdict<PARABOLIC_ONLY>(cfg, __uint_as_float(unsigned(best >> 32)),
                              sqrtf(__uint_as_float(unsigned(best >> 32))), (float)ctot[0],
                              CAR_STD ? (float)ctot[1] : 0.f, peak_idx, sqrtf(pa), sqrtf(pc), num);
         if (t == 0) records[b] = preshift_record(vd, block_idx ? block_idx[b] : (long long)b, peak_idx);
@@ -348,14 +354,19 @@ __global__ __launch_bounds__(NT) void k_preshift(const void* __restrict__ sample
 namespace {
 typedef void (*preshift_fn)(const void*, int, DevCfg, const cpx*, const cpx*, int,
                             const long long*, CorrStats*, thr_record*);
-template <int FMT>
+template <int FMT, bool PAR>
 preshift_fn pick_preshift(bool car_std, bool cor_std) {
-    if (car_std) return cor_std ? &k_preshift<FMT, true, true> : &k_preshift<FMT, true, false>;
-    return cor_std ? &k_preshift<FMT, false, true> : &k_preshift<FMT, false, false>;
+    if (car_std) return cor_std ? &k_preshift<FMT, true, true, PAR> : &k_preshift<FMT, true, false, PAR>;
+    return cor_std ? &k_preshift<FMT, false, true, PAR> : &k_preshift<FMT, false, false, PAR>;
 }
-preshift_fn preshift_variant(int fmt, bool car_std, bool cor_std) {
-    return fmt == THR_IN_U8 ? pick_preshift<THR_IN_U8>(car_std, cor_std)
-                            : pick_preshift<THR_IN_C64>(car_std, cor_std);
+// par: the carrier interpolator is the parabolic one (THR_INTERP_PARABOLIC; the fastdet variant's
+// verdict never reaches the interpolators)
+preshift_fn preshift_variant(int fmt, bool car_std, bool cor_std, bool par) {
+    if (par)
+        return fmt == THR_IN_U8 ? pick_preshift<THR_IN_U8, true>(car_std, cor_std)
+                                : pick_preshift<THR_IN_C64, true>(car_std, cor_std);
+    return fmt == THR_IN_U8 ? pick_preshift<THR_IN_U8, false>(car_std, cor_std)
+                            : pick_preshift<THR_IN_C64, false>(car_std, cor_std);
 }
 }  // namespace
 
@@ -370,12 +381,13 @@ hipError_t launch_fit_preshift(int n_blocks, const DevCfg& cfg, int num, const C
 hipError_t prepare_preshift_16k() {
     for (int fmt = 0; fmt < 2; ++fmt)
         for (int a = 0; a < 2; ++a)
-            for (int c = 0; c < 2; ++c) {
-                hipError_t e = hipFuncSetAttribute(
-                    reinterpret_cast<const void*>(preshift_variant(fmt, a, c)),
-                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-                if (e != hipSuccess) return e;
-            }
+            for (int c = 0; c < 2; ++c)
+                for (int par = 0; par < 2; ++par) {
+                    hipError_t e = hipFuncSetAttribute(
+                        reinterpret_cast<const void*>(preshift_variant(fmt, a, c, par != 0)),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+                    if (e != hipSuccess) return e;
+                }
     return hipSuccess;
 }
 
@@ -383,7 +395,8 @@ hipError_t launch_preshift_16k(int fmt, const void* samples, int n_blocks, const
                                const float2* tables, const float2* bank, int num,
                                const long long* block_idx, CorrStats* corr_stats,
                                thr_record* records, int grid, hipStream_t stream) {
-    preshift_fn fn = preshift_variant(fmt, cfg.car_want_std != 0, cfg.cor_want_std != 0);
+    preshift_fn fn = preshift_variant(fmt, cfg.car_want_std != 0, cfg.cor_want_std != 0,
+                                      cfg.interp == THR_INTERP_PARABOLIC);
     hipLaunchKernelGGL(fn, dim3(grid), dim3(NT), LDS_BYTES, stream, samples, n_blocks, cfg,
                        reinterpret_cast<const cpx*>(tables), reinterpret_cast<const cpx*>(bank), num,
                        block_idx, corr_stats, records);
