@@ -51,9 +51,15 @@ THRESH = (0, 15, 0)
 #          BASELINE config index, handles per GPU)
 CONFIGS = {
     "c2": dict(n=16384, h=4096, bits=10, sps=1.0, batch=32768, resident=1 << 20, idx=1, streams=2,
-               label="block_len=16384 history=4096 1023-chip Gold template (10-bit, 1 sample/chip)"),
-    "c3": dict(n=65536, h=4096, bits=11, sps=2.0, batch=16384, resident=1 << 18, idx=2, streams=2,
+               label="block_len=16384 history=4096 1023-chip Gold template"),
+    # (N > 16384 on ONE handle: both stages fill the chip, a second handle measured -1 %)
+    "c3": dict(n=65536, h=4096, bits=11, sps=2.0, batch=16384, resident=1 << 18, idx=2, streams=1,
                label="block_len=65536 history=4096 2047-chip Gold code at 2 samples/chip (W=4094)"),
+    # BASELINE configs[0]'s geometry (the reference's example/detector.cfg + example/template.npy, also
+    # what rpi/detector.cfg deploys) kernel-resident: the template and settings are the data fixture
+    # tests/golden/c1.npz (history 4920, 4914-sample extracted template, window bins 7..110)
+    "c1": dict(n=16384, h=4920, fixture="c1.npz", batch=32768, resident=1 << 19, idx=0, streams=2,
+               label="block_len=16384 history=4920 4914-sample extracted template (example/detector.cfg)"),
 }
 
 
@@ -64,7 +70,9 @@ LEGS = {"c3": dict(name="c3", T=1, mix="dense", batch=16384, resident=2 * 16384)
         "t4": dict(name="c2", T=4, mix="dense", batch=16384, resident=4 * 16384),
         "sparse": dict(name="c2", T=1, mix="sparse", batch=32768, resident=4 * 32768),
         "fullwin": dict(name="c2", T=1, mix="dense", batch=32768, resident=4 * 32768, window=(0, -1)),
-        "c3t4": dict(name="c3", T=4, mix="dense", batch=4096, resident=2 * 4096)}
+        "c3t4": dict(name="c3", T=4, mix="dense", batch=4096, resident=2 * 4096),
+        "c1": dict(name="c1", T=1, mix="dense", batch=32768, resident=4 * 32768),
+        "c1_sparse": dict(name="c1", T=1, mix="sparse", batch=32768, resident=4 * 32768)}
 
 
 def csrc_sha16():
@@ -115,6 +123,10 @@ def parse_args():
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl: RCCL, one GPU per rank (the real thing); gloo: every rank on cuda:0, "
                          "collectives on CPU tensors -- a rehearsal of the N-rank body on a 1-GPU box")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): every GPU runs the full per-GPU job (K x R launch batches, the "
+                         "config's resident blocks each); strong: the job one GPU would run -- BASELINE "
+                         "configs[3]: 1 Mi blocks in total -- split over the N ranks")
     ap.add_argument("--resident-blocks", type=int, default=0,
                     help="distinct blocks resident in HBM per rank (default per config: c2 1 Mi = 32 GiB)")
     return ap.parse_args()
@@ -271,11 +283,13 @@ def card_to_toad_leg(n_card):
     """BASELINE configs[0]: example detector.cfg + example template on a synthetic .card stream,
     the whole plumbing path text -> parse -> detect -> .toad text.  CPU = the oracle (what the
     reference does per line: base64 decode, (u8 - 127.4)/128, Detector.detect, serialize), one
-    core; GPU = thrifty_amd's `thrifty detect --quiet -o` path (CardStream framing, on-device
-    base64 decode, batched engine, column-wise .toad formatting).  The example template is a
-    data fixture (tests/golden/c1.npz holds it together with the example settings)."""
+    core; GPU = thrifty_amd's `thrifty detect --quiet -o` path: Detector.write_toad(), which for a
+    regular file is ONE library call (thr_run_card: host framing, on-device base64 decode, batched
+    engine, .toad text formatted and written by a library thread).  The same for the raw u8 form
+    of the stream (`--raw`, thr_run_stream).  The example template is a data fixture
+    (tests/golden/c1.npz holds it together with the example settings)."""
     import base64
-    import io
+    import tempfile
     from oracle import thrifty_np as onp
     from thrifty_amd import block_data, synth
     from thrifty_amd.detect import Detector, DetectorSettings
@@ -300,44 +314,74 @@ def card_to_toad_leg(n_card):
         if res.detected:
             cpu_out.append(onp.toad_line(0, float(ts), int(idx), res))
     t_cpu = time.perf_counter() - t0
-    # --- GPU: the CLI's quiet path
     st = DetectorSettings(n, h, len(tpl), cthr, cwin, tpl, xthr)
-    import tempfile
-    with tempfile.NamedTemporaryFile(suffix=".card") as tmp:     # a regular file, as `thrifty detect rx.card`
-        tmp.write(text)
-        tmp.flush()
+
+    def run_file(path, reader, out_path):
+        """`thrifty detect --quiet <path> -o <out_path>`: -> (seconds incl. Detector construction,
+        the library loop's own statistics)"""
+        with open(path, "rb") as f, open(out_path, "wb") as out:
+            t0 = time.perf_counter()      # (opening the reader and the engine handle is part of the job)
+            det = Detector(st, reader(f), rxid=0)
+            stats = det.write_toad(out)
+            out.flush()
+            return time.perf_counter() - t0, stats
+
+    out = {"config": "BASELINE configs[0]: example detector.cfg settings (block 16384, history %d, %d-sample "
+                     "template, window bins %d..%d) on a synthetic .card stream" % (h, len(tpl), cwin[0], cwin[1]),
+           "cpu_blocks_per_s": n_cpu / t_cpu, "cpu_blocks": n_cpu, "cpu_cores": 1}
+    with tempfile.TemporaryDirectory() as tmpd:
+        card, warm, toad = (os.path.join(tmpd, x) for x in ("rx.card", "warm.card", "rx.toad"))
+        with open(card, "wb") as f:      # a regular file, as `thrifty detect rx.card`
+            f.write(text)
         # warm-up, not timed: the first 8192 lines through the same path (a regular file: mapped,
         # input window, full-size batches), as W warm-up steps precede the timed steps of the main
         # leg -- code objects loaded, staging buffers of full size in the runtime's pool
         n_warm = min(8192, n_card)
-        with tempfile.NamedTemporaryFile(suffix=".card") as wtmp:
-            wtmp.write(b"\n".join(text.split(b"\n", n_warm)[:n_warm]) + b"\n")
-            wtmp.flush()
-            with open(wtmp.name, "rb") as wf:
-                warm = Detector(st, block_data.CardStream(wf, n), rxid=0)
-                list(warm.iter_toad_text())
-                del warm
-        with open(tmp.name, "rb") as f:
-            t0 = time.perf_counter()      # (opening the reader and the engine handle is part of the job)
-            det = Detector(st, block_data.CardStream(f, n), rxid=0)
-            toad_text = b"".join(det.iter_toad_text())          # the job's product: the .toad file's bytes
-            t_gpu = time.perf_counter() - t0
-            gpu_out = toad_text.decode("ascii").split("\n")[:-1]   # (for the check below, not timed)
-    same = [a.split()[:3] + [a.split()[4], a.split()[8]] for a in gpu_out[:len(cpu_out)]] == \
-           [b.split()[:3] + [b.split()[4], b.split()[8]] for b in cpu_out]
-    return {"config": "BASELINE configs[0]: example detector.cfg settings (block 16384, history %d, %d-sample "
-                      "template, window bins %d..%d) on a synthetic .card stream" % (h, len(tpl), cwin[0], cwin[1]),
-            "cpu_blocks_per_s": n_cpu / t_cpu, "cpu_blocks": n_cpu, "cpu_cores": 1,
-            "gpu_blocks_per_s": n_card / t_gpu, "gpu_blocks": n_card,
-            "gpu_includes": "a %.1f GB file in the page cache, after an untimed pass over its first 8192 lines; Detector construction, host framing, H2D of the base64 text (the mapped file is the "
-                            "engine's input window: page-locked ahead of the copies by a library thread, "
-                            "asynchronous DMA), device decode, detection, D2H, .toad text (thr_format_toad); "
-                            "batches ride thr_submit_card / thr_collect, one in flight ahead" % (len(text) / 1e9),
-            "detections_cpu": len(cpu_out), "detections_gpu": len(gpu_out),
-            "first_lines_agree_on_rxid_time_block_sample_bin": bool(same)}
+        with open(warm, "wb") as f:
+            f.write(b"\n".join(text.split(b"\n", n_warm)[:n_warm]) + b"\n")
+        run_file(warm, lambda f: block_data.CardStream(f, n), os.path.join(tmpd, "warm.toad"))
+        t_gpu, stats = run_file(card, lambda f: block_data.CardStream(f, n), toad)
+        gpu_out = open(toad, "rb").read().decode("ascii").split("\n")[:-1]   # (for the check below, not timed)
+        loop = (stats or {}).get("calls", [{}])[-1]
+        out.update({"gpu_blocks_per_s": n_card / t_gpu, "gpu_blocks": n_card,
+                    # the library loop alone (thr_run_card's own clock: no Detector construction)
+                    "gpu_loop_blocks_per_s": (loop["blocks"] / loop["total_s"]) if loop.get("total_s") else None,
+                    "gpu_loop_stats": {k: loop.get(k) for k in ("batches", "total_s", "frame_s", "submit_s", "wait_s",
+                                                                "format_s", "write_s")},
+                    "gpu_includes": "a %.1f GB file in the page cache, after an untimed pass over its first 8192 "
+                                    "lines; Detector construction, thr_run_card (host framing, H2D of the base64 "
+                                    "text out of the page-locked input window, device decode, detection, D2H, "
+                                    ".toad text formatted and written by a library thread), file on disk"
+                                    % (len(text) / 1e9),
+                    "detections_cpu": len(cpu_out), "detections_gpu": len(gpu_out)})
+        same = [a.split()[:3] + [a.split()[4], a.split()[8]] for a in gpu_out[:len(cpu_out)]] == \
+               [b.split()[:3] + [b.split()[4], b.split()[8]] for b in cpu_out]
+        out["outputs_agree"] = bool(same)       # rxid, time, block, sample, carrier bin of the first lines
+        # --- the raw form of the same stream (`thrifty detect --raw`): the blocks' NEW samples back to
+        # back, overlap framing on the device (thr_run_stream); the reference's zero-history lead-in
+        # goes through the complex64 path first
+        del text
+        step = 2 * (n - h)
+        rawp = os.path.join(tmpd, "rx.bin")
+        n_raw = n_card
+        with open(rawp, "wb") as f:
+            chunk = np.concatenate([seed_blocks[j][-step:] for j in range(64)]).tobytes()
+            for _ in range(n_raw // 64):
+                f.write(chunk)
+        run_file(rawp, lambda f: block_data.RawStream(f, n, h), os.path.join(tmpd, "warm2.toad"))
+        t_raw, rstats = run_file(rawp, lambda f: block_data.RawStream(f, n, h), os.path.join(tmpd, "raw.toad"))
+        out.update({"raw_gpu_blocks_per_s": (rstats or {}).get("blocks", 0) / t_raw,
+                    "raw_gpu_blocks": (rstats or {}).get("blocks", 0),
+                    "raw_detections_gpu": (rstats or {}).get("detections", 0)})
+    return out
 
 
-def preflight(torch, dist, dev, cdev, rank, world, local, total, first, shared_gpu=False):
+def parallel_cpu_budget():
+    from thrifty_amd import parallel
+    return parallel.cpu_budget()
+
+
+def preflight(torch, dist, dev, cdev, rank, world, local, total, first, shared_gpu=False, env_applied=None):
     """Fail early and legibly if the process group is not what the launch line says: RCCL sees
     `world` ranks, every rank has its own device, and the block ranges tile [0, world * total).
     (shared_gpu: the gloo rehearsal, where every rank computes on cuda:0 by design.)"""
@@ -348,7 +392,8 @@ def preflight(torch, dist, dev, cdev, rank, world, local, total, first, shared_g
                          % (dist.get_backend(), int(one.item()), world))
     mine = {"rank": rank, "local_rank": local, "cuda": dev.index, "device": torch.cuda.get_device_name(dev),
             "pci": getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None),
-            "blocks": [first, first + total], "pid": os.getpid()}
+            "blocks": [first, first + total], "pid": os.getpid(), "env": env_applied or {},
+            "cpus": parallel_cpu_budget()}
     everyone = [None] * world
     dist.all_gather_object(everyone, mine)
     if rank == 0:
@@ -360,6 +405,14 @@ def preflight(torch, dist, dev, cdev, rank, world, local, total, first, shared_g
             dist.get_backend(), world, ", ".join("r%d@cuda:%d [%d, %d)" % (
                 e["rank"], e["cuda"], e["blocks"][0], e["blocks"][1]) for e in everyone)),
             file=sys.stderr)
+        # the environment every rank runs with (parallel.rank_env: the same on both launch routes)
+        for e in everyone:
+            print("pre-flight env: rank %d pid %d %s; %d CPUs for %d rank(s)" % (
+                e["rank"], e["pid"], " ".join("%s=%s" % kv for kv in sorted(e["env"].items())),
+                e["cpus"], world), file=sys.stderr)
+        bad = [e["rank"] for e in everyone if e["env"] != everyone[0]["env"]]
+        if bad:
+            raise SystemExit("pre-flight: ranks %r run with a different environment than rank 0" % (bad,))
 
 
 class Leg(object):
@@ -372,14 +425,27 @@ class Leg(object):
         self.torch, self.F, self.dev, self.name, self.cfg = torch, F, dev, name, cfg
         self.n, self.h, self.T, self.mix, self.pnum = cfg["n"], cfg["h"], T, mix, pnum
         self.B = batch or cfg["batch"]
-        self.tpls = np.stack([synth.gold_template(cfg["bits"], 2 + i, cfg["sps"]) for i in range(T)]).astype(np.float64)
+        self.thresh = (THRESH, THRESH)
+        if "fixture" in cfg:
+            # the reference's example template + settings (a data fixture); the synthetic bursts use
+            # the template rescaled to [-1, 1] the way SURVEY 8(d)'s generator uses a +-1 code
+            g = np.load(os.path.join(ROOT, "tests", "golden", cfg["fixture"]), allow_pickle=False)
+            if T != 1:
+                raise SystemExit("config %s holds one template" % name)
+            tpl = np.asarray(g["template"], dtype=np.float64)
+            self.tpls = tpl[None, :]
+            synth_tpl = (tpl - tpl.min()) / (tpl.max() - tpl.min()) * 2 - 1
+            self.thresh = (tuple(float(v) for v in g["carrier_thresh"]), tuple(float(v) for v in g["corr_thresh"]))
+        else:
+            self.tpls = np.stack([synth.gold_template(cfg["bits"], 2 + i, cfg["sps"]) for i in range(T)]).astype(np.float64)
+            synth_tpl = self.tpls[0]
         self.wlen = self.tpls.shape[1]
         pad = self.h - self.wlen + 1
         self.window = (pad // 2, (self.n - self.wlen + 1) - (pad - pad // 2))
         n_handles = max(1, streams or cfg["streams"])
         self.cwin = tuple(carrier_window)
         self.sectioned = self.n > 16384 and not pnum and bool(F.plan_sections(self.n, self.h, self.wlen))
-        self.engs = [F.Engine(self.n, self.h, self.tpls, THRESH, self.cwin, THRESH, device_id=local,
+        self.engs = [F.Engine(self.n, self.h, self.tpls, self.thresh[0], self.cwin, self.thresh[1], device_id=local,
                               max_batch=self.B, preshift_num=pnum) for _ in range(n_handles)]
         self.resident_batches = max(1, (resident or cfg["resident"]) // self.B)
         self.total = self.resident_batches * self.B
@@ -387,7 +453,7 @@ class Leg(object):
         gen = torch.Generator(device=dev)
         gen.manual_seed(SEED + cfg["idx"] + 1 + seed_off)
         t0 = time.perf_counter()
-        self.data = synth_on_device(torch, dev, gen, self.total, self.n, self.tpls[0], self.window,
+        self.data = synth_on_device(torch, dev, gen, self.total, self.n, synth_tpl, self.window,
                                     1.0 if mix == "dense" else 0.1)
         torch.cuda.synchronize()
         self.t_gen = time.perf_counter() - t0
@@ -459,9 +525,12 @@ class Leg(object):
                            "k_carrier": "k_carrier_dit+k_select_dit"})
         return {rename.get(k, k): v for k, v in prof.items() if v[1] > 0}
 
-    def roofline(self, prof, solo_batches, fallback_ms):
-        """The recomputable roofline object of the dominant kernel: algorithmic bytes per launch
-        (2N + 64 T per block x blocks per launch) / its mean launch duration."""
+    def roofline(self, prof, solo_batches, fallback_ms, rate_per_gpu=None):
+        """-> (roofline, detail).  `roofline`: the recomputable object of the dominant kernel --
+        algorithmic bytes per launch (2N + 64 T per block x blocks per launch) / its mean
+        launch duration (HIP events on the launch stream) -- flat scalars only, so that the driver's
+        record keeps all of it.  `detail`: every kernel's mean duration, launches per batch and the
+        VALU view; it goes to the detail file / stderr, not into the contract line."""
         dom = max(prof, key=lambda k: prof[k][0]) if prof else None
         dom_ms, dom_cnt = prof[dom] if prof else (0.0, 0)
         if dom_cnt == 0:   # no profiled batch: fall back to the whole launch batch
@@ -478,9 +547,7 @@ class Leg(object):
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                key = (self.name + ("_t%d" % self.T if self.T > 1 else "") + ("_sparse" if self.mix != "dense" else "")
-                       + ("_fullwin" if self.cwin != tuple(WINDOW_BINS) else ""))
-                per_kernel = json.load(open(tpath)).get(key, {})
+                per_kernel = json.load(open(tpath)).get(self.traffic_key(), {})
                 # (the engine's carrier slot times whichever carrier kernel the window selects: the
                 # pruned one for the 7..110 window, the full-spectrum one for (0, -1))
                 alias = {"k_carrier": ["k_carrier" if self.cwin != tuple(WINDOW_BINS) else "k_carrier_pruned"],
@@ -498,32 +565,45 @@ class Leg(object):
                     stale = src.get("csrc_sha16") != csrc_sha16()
             except Exception:
                 traffic = clock = pipeline = stale = None
-        return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        alg_launch = self.bytes_per_block * units
+        comp = _compute_view(dom, self.n, self.T, units, avg_ms)
+        roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                # all kernels of one launch batch (carrier stage + fit + correlate + finish) / the
-                # batch's algorithmic bytes would be 1.0 if every block were fetched exactly once
-                "pipeline_traffic": pipeline,
+                "avg_launch_ms": avg_ms, "launches": dom_cnt, "blocks_per_launch": units,
+                "algorithmic_bytes_per_block": self.bytes_per_block,
+                "traffic_over_algorithmic": (traffic / alg_launch) if traffic else None,
+                # all kernels of one launch batch (carrier stage + fit + correlate + finish) over the
+                # batch's algorithmic bytes: 1.0 if every block were fetched exactly once
                 "pipeline_traffic_over_algorithmic": (pipeline / (self.bytes_per_block * float(self.B))
                                                       if pipeline else None),
-                "traffic_source": (src or {}).get("summary"), "traffic_stale": stale,
-                # GRBM_GUI_ACTIVE / duration of this kernel in the committed PMC pass (profiles/): the
-                # clock the part sustained under it (MI355X_MICROARCH.md, "DVFS give-back"); max 2.4
-                "effective_clock_ghz_profiled": clock, "avg_launch_ms": avg_ms,
-                "launches": dom_cnt, "blocks_per_launch": units,
-                "algorithmic_bytes_per_block": self.bytes_per_block,
-                "algorithmic_bytes_per_launch": self.bytes_per_block * units,
-                "all_kernels_ms": {k: v[0] / max(v[1], 1) for k, v in prof.items()},
-                "all_kernels_launches_per_batch": {k: v[1] / max(solo_batches, 1) for k, v in prof.items()},
-                # the kernels are VALU/LDS-bound, so the honest secondary view: nominal
-                # 5 N log2 N flop per transform done by THIS kernel (+ 6N per pointwise product)
-                # against the fp32 vector peak
-                "compute": _compute_view(dom, self.n, self.T, units, avg_ms)}
+                # the WHOLE pipeline against the HBM peak: this leg's blocks/s (per GPU, wall clock)
+                # x algorithmic bytes per block / 8 TB/s -- what the path as a whole achieves, beside
+                # the dominant kernel's own `frac`
+                "pipeline_frac": (rate_per_gpu * self.bytes_per_block / 1e9 / HBM_PEAK_GBS
+                                  if rate_per_gpu else None),
+                # the kernels are VALU/LDS-bound (about 80 flop per input byte): nominal 5 N log2 N flop
+                # per transform this kernel performs (+ 6N per pointwise product) / fp32 vector peak
+                "valu_frac": comp["frac"],
+                "traffic_source": (src or {}).get("summary"), "traffic_stale": stale}
+        detail = {"kernel": dom, "pipeline_traffic": pipeline, "traffic": traffic,
+                  # GRBM_GUI_ACTIVE / duration of this kernel in the committed PMC pass (profiles/): the
+                  # clock the part sustained under it (MI355X_MICROARCH.md, "DVFS give-back"); max 2.4
+                  "effective_clock_ghz_profiled": clock,
+                  "algorithmic_bytes_per_launch": alg_launch,
+                  "all_kernels_ms": {k: v[0] / max(v[1], 1) for k, v in prof.items()},
+                  "all_kernels_launches_per_batch": {k: v[1] / max(solo_batches, 1) for k, v in prof.items()},
+                  "compute": comp}
+        return roof, detail
+
+    def traffic_key(self):
+        """This workload's key in profiles/hbm_traffic.json (scripts/collect_profiles.py)."""
+        return (self.name + ("_t%d" % self.T if self.T > 1 else "") + ("_sparse" if self.mix != "dense" else "")
+                + ("_fullwin" if self.cwin != tuple(WINDOW_BINS) else ""))
 
     def workload_text(self):
-        return ("BASELINE configs[%d]: %s, %s mix, %d blocks per GPU resident in HBM as u8 IQ%s"
+        return ("BASELINE configs[%d]: %s, %s, %d blocks/GPU resident in HBM as u8 IQ%s"
                 % (4 if (self.T > 1 and self.n == 16384) else self.cfg["idx"], self.cfg["label"], self.mix,
-                   self.total,
-                   "" if self.cwin == tuple(WINDOW_BINS) else
+                   self.total, "" if self.cwin == tuple(WINDOW_BINS) else
                    "; carrier window %d..%d (the reference's default '0--1': every bin)" % self.cwin))
 
     def host_records(self, nblocks):
@@ -584,7 +664,7 @@ def oracle_parity(n, h, blocks_u8, template, gpu_rec, procs):
 
 def extra_leg(torch, F, synth, dev, local, key, seconds, cpu_ok):
     """One bounded leg of the default run: another single-GPU workload of BASELINE.json's configs,
-    timed over ~`seconds` after a calibration burst, with its own roofline object."""
+    timed over ~`seconds` after a calibration burst.  -> (compact object for the line, detail)."""
     spec = LEGS[key]
     t_leg = time.perf_counter()
     leg = Leg(torch, F, synth, dev, local, spec["name"], T=spec["T"], mix=spec["mix"], batch=spec["batch"],
@@ -595,31 +675,63 @@ def extra_leg(torch, F, synth, dev, local, key, seconds, cpu_ok):
     nb -= nb % len(leg.engs)
     leg.reset_profile()
     solo_every = max(2, nb // 6)
-    dt, solo = leg.timed(0, nb, solo_every)
+    if len(leg.engs) == 1:        # one handle: nothing overlaps, HIP events around every solo_every-th batch
+        leg.engs[0].profile_enable(solo_every)
+        dt, _ = leg.timed(0, nb, 0)
+        solo = (nb + solo_every - 1) // solo_every
+    else:
+        dt, solo = leg.timed(0, nb, solo_every)
     prof = leg.read_profile()
-    out = {"workload": leg.workload_text(), "value": nb * leg.B / dt, "unit": "blocks/s",
-           "launch_batches": nb, "blocks_per_launch_batch": leg.B, "blocks": nb * leg.B, "seconds": dt,
-           "ms_per_launch_batch": dt / nb * 1e3, "templates": leg.T, "handles_per_gpu": len(leg.engs),
-           "solo_profiled_batches": solo,
-           "roofline": leg.roofline(prof, solo, dt / nb * 1e3), "data_gen_s": leg.t_gen}
+    value = nb * leg.B / dt
+    roof, rdetail = leg.roofline(prof, solo, dt / nb * 1e3, value)
+    keep = ("kernel", "frac", "avg_launch_ms", "blocks_per_launch", "algorithmic_bytes_per_block",
+            "traffic_over_algorithmic", "pipeline_traffic_over_algorithmic", "pipeline_frac", "valu_frac",
+            "traffic_stale")
+    out = {"value": value, "blocks_per_launch_batch": leg.B, "templates": leg.T,
+           "handles_per_gpu": len(leg.engs)}
+    out.update({k: roof[k] for k in keep})
+    detail = {"workload": leg.workload_text(), "value": value, "unit": "blocks/s", "launch_batches": nb,
+              "blocks": nb * leg.B, "seconds": dt, "ms_per_launch_batch": dt / nb * 1e3,
+              "solo_profiled_batches": solo, "roofline": roof, "roofline_detail": rdetail,
+              "data_gen_s": leg.t_gen}
     if key == "c3" and cpu_ok:
         # the oracle check at benchmark shape: 2048 blocks of ONE 16384-block launch batch
         ns = 2048
         procs, _ = physical_cores()
-        out["cpu_baseline"] = oracle_parity(leg.n, leg.h, leg.data[:ns].cpu().numpy(), leg.tpls[0],
-                                             leg.host_records(ns), procs)
+        par = oracle_parity(leg.n, leg.h, leg.data[:ns].cpu().numpy(), leg.tpls[0], leg.host_records(ns), procs)
+        detail["cpu_baseline"] = par
+        out["parity_checked"], out["parity_mismatches"] = par["parity_checked"], par["parity_mismatches"]
     leg.close()
-    out["leg_wall_s"] = time.perf_counter() - t_leg
-    return out
+    detail["leg_wall_s"] = time.perf_counter() - t_leg
+    return out, detail
+
+
+def write_detail(detail, tag):
+    """Everything the contract line no longer carries (per-kernel times of every leg, the VALU view,
+    workload prose, CPU-leg samples): gpurun_out/bench_detail_<tag>.json -- gpurun_out/ is what comes
+    home from a GPU box -- and one line on stderr."""
+    text = json.dumps(detail)
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "bench_detail_%s.json" % tag), "w") as f:
+            f.write(text + "\n")
+    except OSError:
+        pass
+    print("bench detail: " + text, file=sys.stderr)
 
 
 def main():
     args = parse_args()
+    # the rank environment FIRST, before torch / the HIP runtime initialise: the same on every launch
+    # route (the driver's torch.distributed.run line, our own relaunch, a user's torchrun)
+    from thrifty_amd import parallel
+    env_applied = parallel.rank_env()
     import torch
     import torch.distributed as dist
 
     from thrifty_amd import _native as F
-    from thrifty_amd import parallel, synth
+    from thrifty_amd import synth
 
     cfg = CONFIGS[args.config]
     n, h = cfg["n"], cfg["h"]
@@ -656,11 +768,15 @@ def main():
     K, W, T = args.steps, args.warmup, args.templates
     pnum = args.preshift_num if args.variant == "preshift" else 0
     B = args.batch or cfg["batch"]
+    strong = args.scaling == "strong"
     # distinct blocks resident in HBM: up to the config's limit (c2: 1 Mi blocks = 32 GiB of u8 =
-    # BASELINE's "1M synthetic blocks"); longer runs cycle through them
+    # BASELINE's "1M synthetic blocks"); longer runs cycle through them.  --scaling strong: the
+    # config's blocks IN TOTAL (configs[3] as written: 1 Mi blocks sharded 8 ways), 1/world per rank
     resident = min(cfg["resident"], max(B, K * B)) if args.min_seconds <= 0 else cfg["resident"]
     if args.resident_blocks > 0:
         resident = max(B, args.resident_blocks)
+    if strong:
+        resident = max(B, resident // world)
     leg = Leg(torch, F, synth, dev, local, args.config, T=T, mix=args.mix, batch=B, resident=resident,
               streams=args.streams, pnum=pnum, seed_off=rank, first=0, carrier_window=tuple(args.carrier_window))
     total = leg.total
@@ -671,9 +787,17 @@ def main():
     engs, eng = leg.engs, leg.engs[0]
     if len(engs) == 1:
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    gather_method = None
     if use_dist:
         preflight(torch, dist, dev, cdev, rank, world, int(os.environ.get("LOCAL_RANK", "0")), total, first,
-                  shared_gpu=gloo)
+                  shared_gpu=gloo, env_applied=env_applied)
+        # one tiny record gather on the real backend (uneven counts, one empty rank), outside the
+        # timed region: a broken gather / padding path ends the run HERE with a sentence -- or the
+        # all_gather form takes over for the run
+        gather_method = parallel.gather_selftest(world, rank, cdev)
+        if rank == 0:
+            print("pre-flight gather selftest ok: method %s, counts %s" % (
+                gather_method, parallel.selftest_counts(world)), file=sys.stderr)
     kept = torch.zeros_like(leg.rec)
     torch.cuda.synchronize()
 
@@ -691,6 +815,9 @@ def main():
         r_t = torch.tensor([R], dtype=torch.int64, device=cdev)
         dist.broadcast(r_t, 0)
         R = int(r_t.item())
+    if strong:
+        # the job is what ONE GPU would run for --min-seconds (K x R launch batches); N ranks split it
+        R = max(1, -(-R // world))
     for i in range(W):
         leg.run(i * R, R)
     leg.sync()
@@ -711,27 +838,34 @@ def main():
     t0 = time.perf_counter()
     for i in range(K):
         profiled += leg.run(i * R, R, solo_every)
-    if len(engs) > 1:
-        leg.sync()
-    elif args.profile_kernels > 0:
+    leg.sync()
+    if len(engs) == 1 and args.profile_kernels > 0:
         profiled = (K * R + args.profile_kernels - 1) // args.profile_kernels
+    t_compute = time.perf_counter()
     # K7 + C1: compact detected records, gather them to rank 0 (the only collective)
-    n_kept = eng.compact_device(leg.rec.data_ptr(), total * T, kept.data_ptr())
+    n_kept = eng.compact_device(leg.rec.data_ptr(), total * T, kept.data_ptr())     # (synchronises)
+    t_compact = time.perf_counter()
     gathered = (parallel.gather_records(kept[:n_kept].to(cdev), world, rank, cdev, force=use_dist)
                 if use_dist else kept[:n_kept])
     torch.cuda.synchronize()
+    t_gather = time.perf_counter()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof = leg.read_profile()
-    per_rank = [int(n_kept)]
+    # (after the clock stopped, reporting only) every rank's own times: a sub-linear curve can be
+    # attributed to a slow rank's kernels, the compaction or the gather
+    mine = {"n_kept": int(n_kept), "compute_s": t_compute - t0, "compact_ms": (t_compact - t_compute) * 1e3,
+            "gather_ms": (t_gather - t_compact) * 1e3, "total_s": dt}
+    ranks = [mine]
     if use_dist:
-        per_rank = [None] * world
-        dist.all_gather_object(per_rank, int(n_kept))      # (after the clock stopped: reporting only)
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
         tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    per_rank = [r["n_kept"] for r in ranks]
     # ---- one handle alone (what the roofline's solo kernel times belong to), a short leg
     one_dt, one_n = None, 0
     if len(engs) > 1 and args.min_seconds > 0:
@@ -741,12 +875,13 @@ def main():
     if rank == 0:
         blocks_total = world * K * R * B
         value = blocks_total / dt
-        metric = ("IQ blocks/sec (16384-sample, 1024-chip template)" if n == 16384
+        metric = ("IQ blocks/sec (16384-sample, 1024-chip template)" if n == 16384 and args.config == "c2"
                   else "IQ blocks/sec (%d-sample, %d-sample template)" % (n, leg.wlen))
+        roof, rdetail = leg.roofline(prof, profiled, dt / (K * R) * 1e3, value / world)
         line = {
             "metric": metric,
             "value": value, "unit": "blocks/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": leg.workload_text(),
                        "name": args.config,
@@ -757,21 +892,32 @@ def main():
                        "parallelism": "block-shard x%d" % world,
                        "dist_backend": ((("gloo (rehearsal: every rank on cuda:0)" if gloo else "nccl (RCCL)"))
                                         if use_dist else None),
+                       "gather_method": gather_method,
+                       "rank_env": env_applied,
                        "handles_per_gpu": len(engs),
                        "detections_gathered": int(gathered.shape[0]),
-                       "detections_per_rank": per_rank},
+                       "detections_per_rank": per_rank,
+                       # per rank: seconds until its kernels were done, compaction, gather (ms)
+                       "per_rank_seconds": [round(r["compute_s"], 6) for r in ranks],
+                       "per_rank_compact_ms": [round(r["compact_ms"], 3) for r in ranks],
+                       "per_rank_gather_ms": [round(r["gather_ms"], 3) for r in ranks]},
+            # rank 0's own compaction and gather inside the timed region
+            "compact_ms": ranks[0]["compact_ms"], "gather_ms": ranks[0]["gather_ms"],
             # the sustained-rate protocol (wall clock over >= 1 M blocks after warm-up)
             "timed_region_s": dt, "blocks_timed": blocks_total,
             "value_first_1Mi": burst_rate if args.min_seconds > 0 else None,
-            "first_1Mi": {"blocks": burst_batches * B, "seconds": burst_dt,
-                          "note": "rank 0's first %d launch batches after a two-batch code-load warm-up (the "
-                                  "round-1/2 protocol), no gather" % burst_batches},
             "value_1stream": (one_n * B / one_dt) if one_dt else None,
-            "one_stream": ({"blocks": one_n * B, "seconds": one_dt, "note": "one engine handle alone on rank 0, "
-                            "straight after the timed region"} if one_dt else None),
-            "roofline": leg.roofline(prof, profiled, dt / (K * R) * 1e3),
-            "data_gen_s": leg.t_gen,
+            "roofline": roof,
         }
+        detail = {"main": {"workload": leg.workload_text(), "roofline_detail": rdetail, "data_gen_s": leg.t_gen,
+                           "first_1Mi": {"blocks": burst_batches * B, "seconds": burst_dt,
+                                         "note": "rank 0's first %d launch batches after a two-batch code-load "
+                                                 "warm-up (the round-1/2 protocol), no gather" % burst_batches},
+                           "one_stream": ({"blocks": one_n * B, "seconds": one_dt,
+                                           "note": "one engine handle alone on rank 0, straight after the "
+                                                   "timed region"} if one_dt else None),
+                           "ranks": ranks},
+                  "configs": {}}
         legs = []
         if args.legs == "auto":
             legs = (list(LEGS) if (world == 1 and args.config == "c2" and T == 1 and not pnum
@@ -783,29 +929,45 @@ def main():
             ns = min(total, 16384 if n == 16384 else 2048)
             host_blocks = leg.data[:ns].cpu().numpy()
             gpu_rec = leg.host_records(ns)
+        summary = {args.config + ("_t%d" % T if T > 1 else "") + ("_sparse" if args.mix != "dense" else ""): value}
         if legs:
             leg.close()      # the main leg's 32 GiB go before the other configs' data arrive
             torch.cuda.empty_cache()
             line["configs"] = {}
             for key in legs:
-                line["configs"][key] = extra_leg(torch, F, synth, dev, local, key, args.leg_seconds,
-                                                 cpu_ok=args.cpu_seconds > 0)
+                line["configs"][key], detail["configs"][key] = extra_leg(
+                    torch, F, synth, dev, local, key, args.leg_seconds, cpu_ok=args.cpu_seconds > 0)
+                summary[key] = line["configs"][key]["value"]
                 torch.cuda.empty_cache()
         if host_blocks is not None:
-            line["cpu_baseline"] = cpu_baseline(n, h, host_blocks, np.arange(first, first + len(host_blocks)),
-                                                leg.tpls[0], args.cpu_seconds, gpu_rec, pnum, leg.cwin)
+            cb = cpu_baseline(n, h, host_blocks, np.arange(first, first + len(host_blocks)),
+                              leg.tpls[0], args.cpu_seconds, gpu_rec, pnum, leg.cwin)
+            line["cpu_baseline"] = cb
             procs, how = physical_cores()
             if args.cpu_procs >= 0:
                 procs, how = args.cpu_procs, "--cpu-procs"
             if procs > 0 and not pnum:
-                ac = cpu_all_cores(n, h, host_blocks, leg.tpls[0], procs, line["cpu_baseline"]["value"],
-                                   window=leg.cwin)
+                ac = cpu_all_cores(n, h, host_blocks, leg.tpls[0], procs, cb["value"], window=leg.cwin)
                 ac["procs_from"] = how
-                line["cpu_baseline"]["all_cores"] = ac
+                detail["cpu_all_cores"] = ac
+                # (flat: the driver's record keeps the scalars of this object)
+                cb["all_cores_value"], cb["all_cores_procs"] = ac["value"], ac["procs"]
             if args.card_blocks > 0 and args.config == "c2" and T == 1 and not pnum:
-                if leg.engs:     # free the benchmark's engines before the plumbing leg creates its own
+                if leg.engs:     # free the benchmark's engines before the plumbing legs create their own
                     leg.close()
-                line["cpu_baseline"]["card_to_toad"] = card_to_toad_leg(args.card_blocks)
+                ct = card_to_toad_leg(args.card_blocks)
+                detail["card_to_toad"] = ct
+                for k in ("cpu_blocks_per_s", "gpu_blocks_per_s", "gpu_blocks", "gpu_loop_blocks_per_s",
+                          "raw_gpu_blocks_per_s", "outputs_agree"):
+                    if k in ct:
+                        cb["card_to_toad_" + k] = ct[k]
+                summary["card_to_toad"] = ct["gpu_blocks_per_s"]
+                if "raw_gpu_blocks_per_s" in ct:
+                    summary["raw_to_toad"] = ct["raw_gpu_blocks_per_s"]
+        # flat, last: the one place where every leg's blocks/s stands side by side (the driver keeps
+        # the tail of stdout)
+        line["summary"] = {k: round(v) for k, v in summary.items()}
+        write_detail(detail, "%s_n%d" % (args.config, world))
         print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()

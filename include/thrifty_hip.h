@@ -33,13 +33,18 @@ extern "C" {
 /* 6: + thr_create_ex (explicit variant and kernel-path selection), thr_plan_sections,
  *    thr_host_register / thr_host_unregister, thr_input_window (additions only).
  *    No environment variable changes what a handle computes or how it schedules any more. */
-#define THR_ABI_VERSION 6
+/* 7: + thr_run_card / thr_run_stream (the whole file -> .toad loop in one call, text on a library
+ *    thread), thr_get_settings, thr_input_window_ex (populator threads / segment size), THR_ERR_INDEX
+ *    (additions only) */
+#define THR_ABI_VERSION 7
 
 /* status codes */
 #define THR_OK 0
 #define THR_ERR_ARG (-1)      /* bad argument / unsupported configuration      */
 #define THR_ERR_DEVICE (-2)   /* HIP runtime error (no GPU, OOM, launch failure) */
 #define THR_ERR_STATE (-3)    /* call sequence error                            */
+#define THR_ERR_INDEX (-4)    /* thr_run_*: a block on which the reference raises IndexError
+                                 (THR_FLAG_INDEX_ERROR) ended the run                */
 
 /* thr_record.flags */
 #define THR_FLAG_CARRIER 1u      /* carrier_detect verdict (carrier_detect.py:95)  */
@@ -221,7 +226,9 @@ int thr_detect(thr_handle* h, const void* samples, int format, const int64_t* bl
  * characters.  Frames at most `max_records` whole lines starting at `text`; a last line without
  * a newline counts only if `at_eof`.  Outputs per record: timestamp (correctly rounded, like
  * Python's float()), block index, payload offset relative to `text`; `*consumed` = bytes
- * framed (the next call starts there).  No device involved.  Malformed line -> THR_ERR_ARG.
+ * framed (the next call starts there).  No device involved.  Malformed line -> THR_ERR_ARG -- from
+ * the call that STARTS at it: a call that meets it after whole records returns those first (the
+ * reference's per-line loop had processed them before it raised).
  */
 int thr_frame_card(const char* text, size_t text_len, int block_len, int at_eof, size_t max_records,
                    double* timestamps, int64_t* block_idx, int64_t* payload_off, size_t* n_records,
@@ -255,6 +262,14 @@ int thr_host_unregister(const void* p);
  * mapping must stay valid until the window is closed.
  */
 int thr_input_window(thr_handle* h, const void* p, size_t bytes);
+/*
+ * The same with its two resources stated: `populate_threads` (1 .. 16; 0 = the default, 3) threads
+ * map the pages of a segment ahead of the locking worker -- on a node whose CPUs are shared by
+ * several ranks a caller gives each rank its share (thrifty_amd.parallel.populate_threads: CPUs /
+ * world - 3, at least 1); `segment_bytes` (a power of two >= 64 KiB; 0 = the default, 128 MiB) is
+ * the locking granularity -- the tests shrink it to put segment boundaries where they want them.
+ */
+int thr_input_window_ex(thr_handle* h, const void* p, size_t bytes, int populate_threads, size_t segment_bytes);
 
 int thr_detect_card(thr_handle* h, const char* text, size_t text_len, const int64_t* payload_off,
                     const int64_t* block_idx, size_t n_blocks, thr_record* out);
@@ -354,6 +369,68 @@ int thr_format_toad(const thr_record* recs, const double* timestamps, size_t n, 
                     size_t out_capacity, size_t* out_len);
 
 /*
+ * The whole `thrifty detect <file> -o <toad>` loop in ONE call -- replaces the reference's per-block
+ * loop (detect.py:197-223: card_reader / block_reader -> Detector.detect -> `if detected:
+ * print(result.serialize())`; block_data.py:70-131) for an input that lies in memory (the mmap of
+ * the file, or a rank's shard of it).  Built on the entry points above and nothing else: the calling
+ * thread frames batches (thr_frame_card), keeps up to THR_MAX_IN_FLIGHT of them submitted
+ * (thr_submit_card / thr_submit_stream) and collects them in order; a thread of the library keeps the
+ * DETECTED records of each collected batch, formats them (thr_format_toad) and write()s the text to
+ * `out_fd`, and / or appends the records -- each with its timestamp's bits in `reserved` -- to
+ * `rec_out` (what the ranks of a sharded run exchange).  No interpreter in the loop, no hand-over of
+ * a lock between the two threads.
+ *
+ * Semantics are those of the batched Python loop (thrifty_amd/detect.py), i.e. the reference's:
+ *  - output order = input order; only blocks whose correlation verdict is positive produce a line;
+ *  - a block flagged THR_FLAG_INDEX_ERROR (the reference raises IndexError there,
+ *    carrier_sync.py:187) ends the run: the detections before it are written, the call returns
+ *    THR_ERR_INDEX and `stats` names the block;
+ *  - a malformed .card line (THR_ERR_ARG from thr_frame_card) or an invalid base64 payload ends it
+ *    likewise, after everything before the offending batch has been written.
+ * thr_run_card: `text` = .card text (whole lines; the last one may lack its newline).
+ * thr_run_stream: `stream` = raw interleaved u8 I/Q whose first 2*block_len bytes are block
+ *   `first_block_idx` (overlap framing as thr_detect_stream; the caller sends the reference's
+ *   zero-history lead-in blocks through thr_detect as before and starts here behind them); every
+ *   block of a batch is stamped with the wall clock when the batch is framed (`timestamp` NaN) or
+ *   with `timestamp`.
+ * If the handle has an input window (thr_input_window) around the input, the copies are DMA from
+ * the page cache as usual.  The handle must have no open tickets.
+ */
+typedef struct thr_run_opts {
+    uint32_t struct_bytes;        /* sizeof(thr_run_opts) -- guards the layout                     */
+    int32_t batch_blocks;         /* blocks per submitted batch; 0 = the handle's max_batch          */
+    int32_t out_fd;               /* >= 0: the .toad text is written here; -1: no text               */
+    int32_t with_rxid;            /* the arguments of thr_format_toad ...                            */
+    int64_t rxid;
+    int32_t with_txid;
+    int32_t carrier_offset_mode;  /* ... its carrier_offset_f32                                      */
+    double timestamp;             /* thr_run_stream only, see above                                  */
+    thr_record* rec_out;          /* NULL, or room for rec_capacity detected records                 */
+    size_t rec_capacity;
+} thr_run_opts;
+typedef struct thr_run_stats {
+    uint64_t blocks;              /* blocks whose records were handed to the formatter               */
+    uint64_t detections;          /* lines written / records appended                                */
+    uint64_t batches;
+    uint64_t bytes_in;            /* input bytes framed                                              */
+    uint64_t text_bytes;          /* bytes written to out_fd                                         */
+    uint64_t index_error_at;      /* position (0-based, in this run) of the block that ended the run
+                                     with THR_ERR_INDEX; UINT64_MAX otherwise                        */
+    int64_t index_error_block;    /* its block index                                                 */
+    int32_t index_error_bin;      /* its carrier bin                                                 */
+    int32_t reserved_;
+    double total_s;               /* where the calling thread's time went: the whole call,           */
+    double frame_s, submit_s, wait_s;     /* framing, thr_submit*, waiting in thr_collect            */
+    double format_s, write_s;     /* the library thread: thr_format_toad, write()                    */
+} thr_run_stats;
+int thr_run_card(thr_handle* h, const char* text, size_t text_len, const thr_run_opts* opts,
+                 thr_run_stats* stats);
+int thr_run_stream(thr_handle* h, const uint8_t* stream, size_t n_bytes, int64_t first_block_idx,
+                   const thr_run_opts* opts, thr_run_stats* stats);
+/* The settings a handle was created with (`templates` is NULL: the array is not retained). */
+int thr_get_settings(const thr_handle* h, thr_settings* out);
+
+/*
  * K7: keep only records whose THR_FLAG_CORR is set, preserving order -- what
  * detector_cli's `if detected: print(result.serialize())` does (detect.py:217-219).
  * Device pointers (`d_in` and `d_out` must not overlap); `*n_kept` is written on the host
@@ -389,6 +466,10 @@ const char* thr_kernel_name(int slot);
  *   (detect.py:75-78): the frequency-shifted spectrum and the correlation
  *   (first corr_len lags) for template `template_id`; either output may be NULL.
  */
+/* thr_debug_window: the input window's state, in bytes from its (page-aligned) start:
+ *   out[0] = everything below this offset has been released by the chunk copies (may be unlocked),
+ *   out[1], out[2] = the range that is page-locked now, out[3] = the segment size (0: no window). */
+int thr_debug_window(thr_handle* h, size_t out[4]);
 int thr_debug_fft(thr_handle* h, const void* samples, int format, size_t n_blocks,
                   float* spectra_out /* [n_blocks][block_len][2] */);
 int thr_debug_stage(thr_handle* h, const void* samples, int format, size_t n_blocks,

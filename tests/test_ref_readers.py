@@ -86,10 +86,15 @@ def test_malformed_lines_are_refused_by_both(tmp_path, bad, code):
     path.write_text(good + line)
     ref, rc = ref_readers.read_blocks(str(path), n, 0, card=True)
     assert len(ref) == 1 and rc == code                 # card_reader.c:55-72
-    with open(path, "rb") as f:
-        cs = block_data.CardStream(f, n)
-        with pytest.raises(ValueError):
-            cs.next_batch(10)
+    # like the native reader: the line before the bad one is delivered, then the error
+    for force_py in (False, True):
+        with open(path, "rb") as f:
+            cs = block_data.CardStream(f, n)
+            nb = cs._next_batch_py if force_py else cs.next_batch
+            stamps, idxs, _, offs = nb(10)
+            assert list(idxs) == [1] and stamps[0] == 1.5 and len(offs) == 1
+            with pytest.raises(ValueError):
+                nb(10)
     # (the classic card_reader follows the PYTHON reference, block_data.py:120-131, which decodes
     # whatever the line holds and leaves the length check to Detector.detect's assert)
     with open(path, "r") as f:

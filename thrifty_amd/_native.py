@@ -20,7 +20,7 @@ FLAG_CORR = 2
 FLAG_INDEX_ERROR = 4
 N_KERNEL_SLOTS = 5
 
-ABI_VERSION = 6     # THR_ABI_VERSION of include/thrifty_hip.h
+ABI_VERSION = 7     # THR_ABI_VERSION of include/thrifty_hip.h
 
 EXPORTS = [
     "thr_abi_version", "thr_last_error", "thr_create", "thr_destroy", "thr_detect",
@@ -29,7 +29,9 @@ EXPORTS = [
     "thr_debug_stage", "thr_identify", "thr_frame_card",
     "thr_submit", "thr_submit_card", "thr_submit_stream", "thr_collect", "thr_inputs_consumed", "thr_poll",
     "thr_set_stream_default", "thr_format_toad",
+    "thr_run_card", "thr_run_stream", "thr_get_settings", "thr_input_window_ex", "thr_debug_window",
 ]
+ERR_ARG, ERR_DEVICE, ERR_STATE, ERR_INDEX = -1, -2, -3, -4       # THR_ERR_*
 VARIANT_DEFAULT, VARIANT_PRESHIFT, VARIANT_FASTDET = 0, 1, 2      # THR_VARIANT_*
 INTERPOLATORS = {"parabolic": 0, "none": 1, "gaussian": 2, "cosine": 3}      # THR_INTERP_*
 PATHS = {"auto": 0, "multipass": 1, "unsectioned": 2}             # THR_PATH_*
@@ -48,6 +50,28 @@ class ThrSettings(C.Structure):
     ]
 
 
+class ThrRunOpts(C.Structure):
+    _fields_ = [
+        ("struct_bytes", C.c_uint32), ("batch_blocks", C.c_int32), ("out_fd", C.c_int32),
+        ("with_rxid", C.c_int32), ("rxid", C.c_int64), ("with_txid", C.c_int32),
+        ("carrier_offset_mode", C.c_int32), ("timestamp", C.c_double),
+        ("rec_out", C.c_void_p), ("rec_capacity", C.c_size_t),
+    ]
+
+
+class ThrRunStats(C.Structure):
+    _fields_ = [
+        ("blocks", C.c_uint64), ("detections", C.c_uint64), ("batches", C.c_uint64),
+        ("bytes_in", C.c_uint64), ("text_bytes", C.c_uint64), ("index_error_at", C.c_uint64),
+        ("index_error_block", C.c_int64), ("index_error_bin", C.c_int32), ("reserved_", C.c_int32),
+        ("total_s", C.c_double), ("frame_s", C.c_double), ("submit_s", C.c_double), ("wait_s", C.c_double),
+        ("format_s", C.c_double), ("write_s", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved_"}
+
+
 # numpy mirror of thr_record (64 bytes)
 RECORD_DTYPE = np.dtype([
     ("block_idx", "<i8"), ("flags", "<u4"), ("template_id", "<i4"),
@@ -60,7 +84,14 @@ assert RECORD_DTYPE.itemsize == 64
 
 
 class NativeError(RuntimeError):
-    pass
+    """An error status of the library: args = (message[, status code[, thr_run_* statistics]])."""
+
+    def __str__(self):
+        return str(self.args[0]) if self.args else ""
+
+    @property
+    def code(self):
+        return self.args[1] if len(self.args) > 1 else None
 
 
 _lib = None
@@ -116,6 +147,10 @@ def load_library():
     lib.thr_create_preshift.argtypes = [C.POINTER(ThrSettings), C.c_int, C.POINTER(vp)]
     lib.thr_create_fastdet.argtypes = [C.POINTER(ThrSettings), C.POINTER(vp)]
     lib.thr_input_window.argtypes = [vp, vp, C.c_size_t]
+    lib.thr_input_window_ex.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_size_t]
+    lib.thr_run_card.argtypes = [vp, vp, C.c_size_t, C.POINTER(ThrRunOpts), C.POINTER(ThrRunStats)]
+    lib.thr_run_stream.argtypes = [vp, vp, C.c_size_t, C.c_int64, C.POINTER(ThrRunOpts), C.POINTER(ThrRunStats)]
+    lib.thr_get_settings.argtypes = [vp, C.POINTER(ThrSettings)]
     lib.thr_host_register.argtypes = [vp, C.c_size_t]
     lib.thr_host_unregister.argtypes = [vp]
     ip = C.POINTER(C.c_int)
@@ -447,18 +482,79 @@ class Engine(object):
         assert got.value == nb
         return Ticket(t.value, out, None)
 
-    def input_window(self, buf=None):
-        """thr_input_window: declare `buf` (bytes-like: the mmap of the input file, or a slice of
+    def input_window(self, buf=None, populate_threads=0, segment_bytes=0):
+        """thr_input_window[_ex]: declare `buf` (bytes-like: the mmap of the input file, or a slice of
         it) as the range the host entry points will read front to back -- a library thread
         page-locks it a bounded distance ahead of the copies, which then are asynchronous DMA.
-        None closes the window.  The caller keeps `buf` alive until then."""
+        None closes the window.  The caller keeps `buf` alive until then.  populate_threads: the
+        page-table populators ahead of the locking (0 = the library's default, 3; a rank of a sharded
+        run passes its share of the host, parallel.populate_threads); segment_bytes: the locking
+        granularity (0 = 128 MiB; tests)."""
         if buf is None:
             _check(self._lib, self._lib.thr_input_window(self._h, None, 0))
             self._window = None
             return
         arr = np.frombuffer(buf, dtype=np.uint8)
-        _check(self._lib, self._lib.thr_input_window(self._h, arr.ctypes.data, arr.size))
+        _check(self._lib, self._lib.thr_input_window_ex(self._h, arr.ctypes.data, arr.size,
+                                                        int(populate_threads), int(segment_bytes)))
         self._window = arr
+
+    # ---- the whole file -> .toad loop inside the library (thr_run_card / thr_run_stream) -------
+    def _run_opts(self, out_fd, rxid, with_txid, carrier_offset_mode, batch_blocks, rec_out, timestamp=None):
+        o = ThrRunOpts()
+        o.struct_bytes = C.sizeof(ThrRunOpts)
+        o.batch_blocks = int(batch_blocks or 0)
+        o.out_fd = -1 if out_fd is None else int(out_fd)
+        o.with_rxid, o.rxid = (0, 0) if rxid is None else (1, int(rxid))
+        o.with_txid = int(bool(with_txid))
+        o.carrier_offset_mode = int(carrier_offset_mode)
+        o.timestamp = float("nan") if timestamp is None else float(timestamp)
+        if rec_out is not None:
+            assert rec_out.dtype == RECORD_DTYPE and rec_out.flags.c_contiguous
+            o.rec_out, o.rec_capacity = rec_out.ctypes.data, rec_out.size
+        return o
+
+    def _run_done(self, rc, stats):
+        """-> stats dict; THR_ERR_INDEX is reported in it (`index_error`), everything else raises."""
+        out = stats.as_dict()
+        out["index_error"] = rc == ERR_INDEX
+        if rc != 0 and rc != ERR_INDEX:
+            raise NativeError("libthriftyhip: %s (code %d)" % (self._lib.thr_last_error().decode(), rc),
+                              rc, out)
+        return out
+
+    def run_card(self, text, out_fd=None, rxid=None, with_txid=False, carrier_offset_mode=0,
+                 batch_blocks=0, rec_out=None):
+        """thr_run_card: frame, detect and format the .card text `text` (bytes-like: the mapped
+        file) inside the library; the .toad text goes to the descriptor `out_fd`, the detected
+        records (timestamp bits in `reserved`) into `rec_out` (a RECORD_DTYPE array) if given.
+        -> stats dict (blocks, detections, seconds per stage, `index_error` ...)."""
+        buf = np.frombuffer(text, dtype=np.uint8)
+        o = self._run_opts(out_fd, rxid, with_txid, carrier_offset_mode, batch_blocks, rec_out)
+        st = ThrRunStats()
+        rc = self._lib.thr_run_card(self._h, buf.ctypes.data, buf.size, C.byref(o), C.byref(st))
+        del buf
+        return self._run_done(rc, st)
+
+    def run_stream(self, stream, first_block_idx=0, out_fd=None, rxid=None, with_txid=False,
+                   carrier_offset_mode=0, batch_blocks=0, rec_out=None, timestamp=None):
+        """thr_run_stream: the same for a raw u8 I/Q stream whose first 2 * block_len bytes are
+        block `first_block_idx` (overlap framing on the device)."""
+        buf = np.frombuffer(stream, dtype=np.uint8)
+        o = self._run_opts(out_fd, rxid, with_txid, carrier_offset_mode, batch_blocks, rec_out, timestamp)
+        st = ThrRunStats()
+        rc = self._lib.thr_run_stream(self._h, buf.ctypes.data, buf.size, int(first_block_idx), C.byref(o),
+                                      C.byref(st))
+        del buf
+        return self._run_done(rc, st)
+
+    def debug_window(self):
+        """thr_debug_window -> (released_below, locked_lo, locked_hi, segment_bytes), byte offsets
+        from the window's page-aligned start (test hook)."""
+        out = (C.c_size_t * 4)()
+        self._lib.thr_debug_window.argtypes = [C.c_void_p, C.c_size_t * 4]
+        _check(self._lib, self._lib.thr_debug_window(self._h, out))
+        return tuple(int(v) for v in out)
 
     def collect(self, ticket):
         """thr_collect: wait for the ticket's batch -> its records [B, n_templates]."""

@@ -259,6 +259,16 @@ class CardStream(object):
             return None
         return memoryview(self._buf)[self._pos:self._end]
 
+    def take_rest(self):
+        """Mapped file only: everything this reader has not handed out yet (its shard), as ONE
+        memoryview of .card text -- for a consumer that frames it itself (thr_run_card); the reader
+        is exhausted afterwards.  -> (view, upper bound on the number of records in it)."""
+        if not self.mapped:
+            raise ValueError("take_rest() needs a mapped regular file")
+        view = memoryview(self._buf)[self._pos:self._end]
+        self._pos = self._end
+        return view, len(view) // (self.payload_chars + 4) + 1
+
     def ready(self, release=None):
         """True if next_batch() would not have to WAIT for the source: a mapped file, the end of
         the stream, or a COMPLETE record in the buffer -- a partial line (a producer that does not
@@ -387,13 +397,26 @@ class CardStream(object):
                 continue
             sp1 = buf.find(b" ", start, stop)
             sp2 = buf.find(b" ", sp1 + 1, stop)
+            bad = sp1 < 0 or sp2 < 0 or stop - (sp2 + 1) != self.payload_chars
+            if bad and offs:
+                # the records before a bad line go out first (the reference's per-line loop had
+                # processed them); the next call starts at the bad line and raises
+                self._pos = start
+                break
             if sp1 < 0 or sp2 < 0:
                 raise ValueError("malformed .card line: %r" % bytes(buf[start:min(stop, start + 60)]))
             if stop - (sp2 + 1) != self.payload_chars:
                 raise ValueError("block %s: payload of %d base64 characters, expected %d (block_len %d)" % (
                     bytes(buf[sp1 + 1:sp2]).decode(), stop - (sp2 + 1), self.payload_chars, self.block_len))
-            stamps.append(float(buf[start:sp1]))
-            idxs.append(int(buf[sp1 + 1:sp2]))
+            try:
+                ts, bi = float(buf[start:sp1]), int(buf[sp1 + 1:sp2])
+            except ValueError:
+                if offs:
+                    self._pos = start
+                    break
+                raise ValueError("malformed .card header: %r" % bytes(buf[start:sp2]))
+            stamps.append(ts)
+            idxs.append(bi)
             offs.append(sp2 + 1)
         if not offs:
             return None
@@ -512,6 +535,29 @@ class RawStream(object):
             self._off = self._origin + lo * step
         self._stop_idx = hi
         return self
+
+    def take_rest(self):
+        """Mapped file only, after the zero-history lead-in (`in_lead_in` false): every block not
+        handed out yet as ONE u8 stream view whose first 2 * size bytes are block `first` -- for a
+        consumer that frames it itself (thr_run_stream).  -> (view, first, n_blocks); the reader is
+        exhausted afterwards."""
+        if self._map is None or self.in_lead_in:
+            raise ValueError("take_rest() needs a mapped regular file behind its lead-in blocks")
+        step, carry = 2 * self.new, 2 * self.history
+        n = (len(self._map) - self._off) // step
+        if self._stop_idx is not None:
+            n = min(n, self._stop_idx - self._next_idx)
+        n = max(0, n)
+        first = self._next_idx
+        view = memoryview(self._map)[self._off - carry:self._off + n * step] if n else memoryview(b"")
+        self._next_idx += n
+        self._off += n * step
+        return view, first, n
+
+    @property
+    def in_lead_in(self):
+        """The next block still contains part of the reference's all-zero initial history."""
+        return self._next_idx < self._n_lead
 
     def _read_upto(self, want_end, need_end=None):
         """Read until `need_end` valid bytes are buffered (default: want_end) or EOF, never

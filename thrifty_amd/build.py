@@ -12,8 +12,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libthriftyhip.so")
-SOURCES = ["api.hip", "detect16k.hip", "detect16k_carrier.hip", "detect16k_preshift.hip", "detect_seg.hip", "detect_long.hip", "detect_small.hip", "generic.hip", "card_ingest.hip", "identify.hip"]
+SOURCES = ["api.hip", "detect16k.hip", "detect16k_carrier.hip", "detect16k_preshift.hip", "detect_seg.hip", "detect_long.hip", "detect_small.hip", "generic.hip", "card_ingest.hip", "identify.hip", "run_file.hip"]
 HEADERS = ["correlate16k.hpp", "detect_common.hpp", "fft_regs.hpp", "kernel_util.hpp", "lmdif8.hpp", "passes_w8.hpp", os.path.join("..", "..", "include", "thrifty_hip.h")]
+HOST_ONLY = ("api.hip", "run_file.hip")     # no kernels: not part of csrc_hash()
 # per-file code-generation flags (measured on MI355X, see csrc/detect16k_carrier.hip)
 PER_FILE_FLAGS = {"detect16k_carrier.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
@@ -26,12 +27,12 @@ def _hipcc():
 
 
 def csrc_hash():
-    """sha256 (first 16 hex digits) over the kernel sources and headers (everything but api.hip,
-    the host side): profiles/hbm_traffic.json records the hash its counter passes were taken on,
+    """sha256 (first 16 hex digits) over the kernel sources and headers (everything but the host
+    side, HOST_ONLY): profiles/hbm_traffic.json records the hash its counter passes were taken on,
     bench.py flags a mismatch (`traffic_stale`)."""
     import hashlib
     h = hashlib.sha256()
-    for name in sorted([x for x in SOURCES if x != "api.hip"] + [x for x in HEADERS if not x.startswith("..")]):
+    for name in sorted([x for x in SOURCES if x not in HOST_ONLY] + [x for x in HEADERS if not x.startswith("..")]):
         h.update(name.encode())
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(f.read())
@@ -73,11 +74,13 @@ def build_native(force=False, verbose=False):
     except OSError:
         flags_then = None
     if flags_then != flags_now:
+        # objects of another flag set: none of them may survive, whatever interrupts this rebuild --
+        # the library and every object go first, the stamp is written LAST (after the link), so an
+        # interrupted rebuild is still seen as "flags differ" by the next one
         force = True
-        if os.path.exists(LIB):
-            os.remove(LIB)           # a half-finished rebuild must not leave a mixed library behind
-        with open(stamp, "w") as f:
-            f.write(flags_now)
+        for stale in [LIB, stamp] + [os.path.join(CSRC, src.replace(".hip", ".o")) for src in SOURCES]:
+            if os.path.exists(stale):
+                os.remove(stale)
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(obj)
@@ -97,6 +100,8 @@ def build_native(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(flags_now)
     return LIB
 
 

@@ -106,8 +106,10 @@ struct EventPair {
 // the staging it replaces -- runs beside the caller instead of in front of it, and never more than
 // kAhead segments are locked whatever the size of the file.
 struct InputWindow {
-    static constexpr size_t kSeg = size_t(128) << 20;
-    static constexpr size_t kAhead = 8;       // segments the worker may run ahead of `consumed` (1 GiB)
+    static constexpr size_t kSegDefault = size_t(128) << 20;
+    static constexpr size_t kAheadBytes = size_t(1) << 30;   // the worker runs at most this far ahead of `consumed`
+    size_t kSeg = kSegDefault;                // bytes per segment (thr_input_window_ex: tests shrink it)
+    size_t kAhead = 8;                        // segments the worker may run ahead of `consumed` (1 GiB)
     uintptr_t base = 0, end = 0;              // page-aligned span; base == 0: no window
     size_t n_seg = 0;
     size_t reg_lo = 0, reg_hi = 0;            // segments [reg_lo, reg_hi) are locked now
@@ -120,8 +122,8 @@ struct InputWindow {
     // page-table population runs in front of the locking, on threads of its own: locking pages
     // that are already mapped goes at ~100 GB/s, faulting them in one by one inside
     // hipHostRegister at ~30 (measured), and the fabric copies run at 56
-    static constexpr int kPopulators = 3;
-    std::thread populators[kPopulators];
+    static constexpr int kPopulators = 3;      // default; thr_input_window_ex sizes it (ranks share the host's CPUs)
+    std::vector<std::thread> populators;
     std::vector<unsigned char> populated;      // per segment: its pages are mapped
     size_t pop_next = 0;                       // next segment a populator takes
 
@@ -200,9 +202,11 @@ struct InputWindow {
         reg_lo = reg_hi = 0;
     }
 
-    void open(const void* p, size_t bytes, int dev) {
+    void open(const void* p, size_t bytes, int dev, int n_populators = kPopulators, size_t seg_bytes = 0) {
         close();
         const uintptr_t page = 4096;
+        kSeg = seg_bytes ? seg_bytes : kSegDefault;
+        kAhead = std::max<size_t>(2, kAheadBytes / kSeg);
         base = reinterpret_cast<uintptr_t>(p) & ~(page - 1);
         end = (reinterpret_cast<uintptr_t>(p) + bytes + page - 1) & ~(page - 1);
         n_seg = size_t((end - base + kSeg - 1) / kSeg);
@@ -211,7 +215,8 @@ struct InputWindow {
         stop = failed = false;
         device = dev;
         worker = std::thread([this] { run(); });
-        for (auto& t : populators) t = std::thread([this] { populate_run(); });
+        populators.clear();
+        for (int i = 0; i < std::max(1, n_populators); ++i) populators.emplace_back([this] { populate_run(); });
     }
 
     void close() {
@@ -223,6 +228,7 @@ struct InputWindow {
         cv.notify_all();
         worker.join();
         for (auto& t : populators) t.join();
+        populators.clear();
         base = end = 0;
         n_seg = 0;
     }
@@ -307,10 +313,11 @@ struct thr_handle {
         thr_record* h_rec[kPipeDepth] = {};    // pinned: D2H never blocks the host
         unsigned char* d_text[kPipeDepth] = {};
         size_t text_bytes[kPipeDepth] = {};
-        long long* d_off[kPipeDepth] = {};
         int* d_bad[kPipeDepth] = {};
         int* h_bad = nullptr;                  // pinned int[kPipeDepth]
-        std::vector<long long> idx_host[kPipeDepth], off_host[kPipeDepth];
+        // a chunk's block indices and (.card) payload offsets, packed [idx[nb] | off[nb]]: pinned on the
+        // host, ONE asynchronous copy into d_idx[b] (2 * max_batch entries; the offsets follow the indices)
+        long long* h_meta[kPipeDepth] = {};
         // records of the chunk in buffer b still to be handed to the caller
         thr_record* pend_dst[kPipeDepth] = {};
         size_t pend_n[kPipeDepth] = {};
@@ -322,7 +329,11 @@ struct thr_handle {
         uint64_t slot_ticket[kPipeDepth] = {};
         uint64_t next_ticket = 1;
         int async_open = 0;
-        uintptr_t win_end[kPipeDepth] = {};    // input window: end of the chunk's source range (0: not windowed)
+        // input window: the chunk's source range [win_lo, win_end) (win_end 0: not windowed).  Chunks of a
+        // raw stream OVERLAP by the history: what may be unlocked behind a finished chunk ends where the
+        // earliest chunk still open begins, not where the finished one ended.
+        uintptr_t win_lo[kPipeDepth] = {};
+        uintptr_t win_end[kPipeDepth] = {};
     } hp;
     InputWindow win;
     // single-chunk staging of the test hooks (lazy)
@@ -565,7 +576,9 @@ int ensure_pipe(thr_handle* h) {
     for (int b = 0; b < thr_handle::kPipeDepth; ++b) {
         HIP_TRY(hipEventCreateWithFlags(&p.ev_h2d[b], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&p.ev_done[b], hipEventDisableTiming));
-        HIP_TRY(hipMalloc(&p.d_idx[b], mb * sizeof(long long)));
+        HIP_TRY(hipMalloc(&p.d_idx[b], 2 * mb * sizeof(long long)));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p.h_meta[b]), 2 * mb * sizeof(long long),
+                              hipHostMallocDefault));
         HIP_TRY(hipMalloc(&p.d_rec[b], mb * nt * sizeof(thr_record)));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p.h_rec[b]), mb * nt * sizeof(thr_record),
                               hipHostMallocDefault));
@@ -589,12 +602,13 @@ int pipe_h2d(thr_handle* h, int b, void* d_dst, const void* src, size_t bytes) {
         size_t done = 0;
         while (done < bytes) {
             const uintptr_t at = a + done;
-            const uintptr_t seg_end = h->win.base + (size_t((at - h->win.base) / InputWindow::kSeg) + 1) * InputWindow::kSeg;
+            const uintptr_t seg_end = h->win.base + (size_t((at - h->win.base) / h->win.kSeg) + 1) * h->win.kSeg;
             const size_t n = std::min<size_t>(bytes - done, size_t(seg_end - at));
             HIP_TRY(hipMemcpyAsync(static_cast<char*>(d_dst) + done, reinterpret_cast<const void*>(at), n,
                                    hipMemcpyHostToDevice, h->hp.copy));
             done += n;
         }
+        h->hp.win_lo[b] = a;
         h->hp.win_end[b] = a + bytes;
         return THR_OK;
     }
@@ -604,10 +618,15 @@ int pipe_h2d(thr_handle* h, int b, void* d_dst, const void* src, size_t bytes) {
 
 // buffer b's chunk has left host memory (its H2D event or its done event has been waited for)
 void pipe_inputs_done(thr_handle* h, int b) {
-    if (h->hp.win_end[b]) {
-        h->win.release_below(h->hp.win_end[b]);
-        h->hp.win_end[b] = 0;
-    }
+    auto& p = h->hp;
+    if (!p.win_end[b]) return;
+    uintptr_t upto = p.win_end[b];
+    p.win_end[b] = p.win_lo[b] = 0;
+    // nothing an open chunk still reads may be unlocked: a later chunk of a raw stream starts
+    // 2 * history bytes BEFORE the end of this one, possibly in the segment below
+    for (int o = 0; o < thr_handle::kPipeDepth; ++o)
+        if (p.win_end[o]) upto = std::min(upto, p.win_lo[o]);
+    h->win.release_below(upto);
 }
 
 // blocks per chunk of the host entry points: the staging buffers stay near 64 MiB each
@@ -1029,14 +1048,34 @@ int thr_host_unregister(const void* p) {
 }
 
 int thr_input_window(thr_handle* h, const void* p, size_t bytes) {
+    return thr_input_window_ex(h, p, bytes, 0, 0);
+}
+
+int thr_input_window_ex(thr_handle* h, const void* p, size_t bytes, int populate_threads, size_t segment_bytes) {
     if (!h) return fail(THR_ERR_ARG, "thr_input_window: null handle");
+    if (populate_threads < 0 || populate_threads > 16)
+        return fail(THR_ERR_ARG, "thr_input_window_ex: populate_threads %d out of range [0, 16]", populate_threads);
+    if (segment_bytes && (segment_bytes < (size_t(1) << 16) || (segment_bytes & (segment_bytes - 1))))
+        return fail(THR_ERR_ARG, "thr_input_window_ex: segment_bytes %zu is not a power of two >= 64 KiB", segment_bytes);
     if (hipSetDevice(h->device) != hipSuccess) return fail(THR_ERR_DEVICE, "hipSetDevice(%d) failed", h->device);
     if (h->hp.async_open != 0)
         return fail(THR_ERR_STATE, "thr_input_window: %d submitted batch(es) not collected yet", h->hp.async_open);
     if (h->hp.copy) (void)hipStreamSynchronize(h->hp.copy);     // no copy may still read the old window
     h->win.close();
     for (auto& e : h->hp.win_end) e = 0;
-    if (p && bytes) h->win.open(p, bytes, h->device);
+    for (auto& e : h->hp.win_lo) e = 0;
+    if (p && bytes)
+        h->win.open(p, bytes, h->device, populate_threads ? populate_threads : InputWindow::kPopulators, segment_bytes);
+    return THR_OK;
+}
+
+int thr_debug_window(thr_handle* h, size_t out[4]) {
+    if (!h || !out) return fail(THR_ERR_ARG, "thr_debug_window: null argument");
+    std::lock_guard<std::mutex> lk(h->win.mu);
+    out[0] = h->win.base ? h->win.consumed * h->win.kSeg : 0;
+    out[1] = h->win.reg_lo * h->win.kSeg;
+    out[2] = h->win.reg_hi * h->win.kSeg;
+    out[3] = h->win.base ? h->win.kSeg : 0;
     return THR_OK;
 }
 
@@ -1277,9 +1316,9 @@ void thr_destroy(thr_handle* h) {
             if (p.ev_h2d[b]) (void)hipEventDestroy(p.ev_h2d[b]);
             if (p.ev_done[b]) (void)hipEventDestroy(p.ev_done[b]);
             if (p.h_rec[b]) (void)hipHostFree(p.h_rec[b]);
+            if (p.h_meta[b]) (void)hipHostFree(p.h_meta[b]);
             for (void* q : {p.d_in[b], static_cast<void*>(p.d_idx[b]), static_cast<void*>(p.d_rec[b]),
-                            static_cast<void*>(p.d_text[b]), static_cast<void*>(p.d_off[b]),
-                            static_cast<void*>(p.d_bad[b])})
+                            static_cast<void*>(p.d_text[b]), static_cast<void*>(p.d_bad[b])})
                 if (q) (void)hipFree(q);
         }
     }
@@ -1295,6 +1334,13 @@ void thr_destroy(thr_handle* h) {
         if (b) (void)hipFree(b);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
+}
+
+int thr_get_settings(const thr_handle* h, thr_settings* out) {
+    if (!h || !out) return fail(THR_ERR_ARG, "thr_get_settings: null argument");
+    *out = h->cfg;
+    out->templates = nullptr;
+    return THR_OK;
 }
 
 int thr_set_stream(thr_handle* h, void* hip_stream) {
@@ -1370,11 +1416,9 @@ static int chunk_samples(thr_handle* h, int b, const void* src, int format, size
     int rc;
     if ((rc = pipe_grow(&p.d_in[b], &p.in_bytes[b], bytes)) != THR_OK) return rc;
     if ((rc = pipe_h2d(h, b, p.d_in[b], src, bytes)) != THR_OK) return rc;
-    p.idx_host[b].resize(nb);
     for (size_t i = 0; i < nb; ++i)
-        p.idx_host[b][i] = block_idx ? (long long)block_idx[i] : (long long)(first_idx + int64_t(i));
-    HIP_TRY(hipMemcpyAsync(p.d_idx[b], p.idx_host[b].data(), nb * sizeof(long long),
-                           hipMemcpyHostToDevice, p.copy));
+        p.h_meta[b][i] = block_idx ? (long long)block_idx[i] : (long long)(first_idx + int64_t(i));
+    HIP_TRY(hipMemcpyAsync(p.d_idx[b], p.h_meta[b], nb * sizeof(long long), hipMemcpyHostToDevice, p.copy));
     if ((rc = pipe_inputs_enqueued(h, b)) != THR_OK) return rc;
     rc = run_batch(h, p.d_in[b], format, p.d_idx[b], int(nb), p.d_rec[b], nullptr, nullptr, nullptr, 0,
                    false, stride);
@@ -1401,22 +1445,17 @@ static int chunk_card(thr_handle* h, int b, const char* text, size_t text_len, c
     int rc;
     if ((rc = pipe_grow(reinterpret_cast<void**>(&p.d_text[b]), &p.text_bytes[b], span)) != THR_OK) return rc;
     if ((rc = pipe_grow(&p.d_in[b], &p.in_bytes[b], nb * out_bytes)) != THR_OK) return rc;
-    if (!p.d_off[b]) HIP_TRY(hipMalloc(&p.d_off[b], size_t(h->cfg.max_batch) * sizeof(long long)));
     if (!p.d_bad[b]) HIP_TRY(hipMalloc(&p.d_bad[b], sizeof(int)));
-    p.off_host[b].resize(nb);
-    p.idx_host[b].resize(nb);
+    long long* meta = p.h_meta[b];
     for (size_t i = 0; i < nb; ++i) {
-        p.off_host[b][i] = payload_off[first + i] - lo;
-        p.idx_host[b][i] = block_idx ? (long long)block_idx[first + i] : (long long)(first + i);
+        meta[i] = block_idx ? (long long)block_idx[first + i] : (long long)(first + i);
+        meta[nb + i] = payload_off[first + i] - lo;
     }
     if ((rc = pipe_h2d(h, b, p.d_text[b], text + lo, span)) != THR_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(p.d_off[b], p.off_host[b].data(), nb * sizeof(long long),
-                           hipMemcpyHostToDevice, p.copy));
-    HIP_TRY(hipMemcpyAsync(p.d_idx[b], p.idx_host[b].data(), nb * sizeof(long long),
-                           hipMemcpyHostToDevice, p.copy));
+    HIP_TRY(hipMemcpyAsync(p.d_idx[b], meta, 2 * nb * sizeof(long long), hipMemcpyHostToDevice, p.copy));
     HIP_TRY(hipMemsetAsync(p.d_bad[b], 0, sizeof(int), p.copy));
     if ((rc = pipe_inputs_enqueued(h, b)) != THR_OK) return rc;
-    HIP_TRY(thr::launch_b64_decode(p.d_text[b], p.d_off[b], int(nb), int(out_bytes),
+    HIP_TRY(thr::launch_b64_decode(p.d_text[b], p.d_idx[b] + nb, int(nb), int(out_bytes),
                                    static_cast<unsigned char*>(p.d_in[b]), p.d_bad[b], h->stream));
     rc = run_batch(h, p.d_in[b], THR_IN_U8, p.d_idx[b], int(nb), p.d_rec[b], nullptr, nullptr, nullptr,
                    0, false);
@@ -1533,11 +1572,18 @@ int thr_frame_card(const char* text, size_t text_len, int block_len, int at_eof,
             }
             sp1 = static_cast<const char*>(memchr(line, ' ', end));
             sp2 = sp1 ? static_cast<const char*>(memchr(sp1 + 1, ' ', size_t(line + end - sp1 - 1))) : nullptr;
-            if (!sp1 || !sp2)
+            // a bad line ends the call: the records framed BEFORE it are handed out first (the
+            // reference's per-line loop had processed them) and the next call, which starts at the
+            // bad line, reports it
+            if (!sp1 || !sp2) {
+                if (n) break;
                 return fail(THR_ERR_ARG, "malformed .card line at byte %zu: %.60s", pos, std::string(line, std::min<size_t>(end, 60)).c_str());
-            if (size_t(line + end - (sp2 + 1)) != chars)
+            }
+            if (size_t(line + end - (sp2 + 1)) != chars) {
+                if (n) break;
                 return fail(THR_ERR_ARG, "block %.*s: payload of %zu base64 characters, expected %zu (block_len %d)",
                             int(sp2 - sp1 - 1), sp1 + 1, size_t(line + end - (sp2 + 1)), chars, block_len);
+            }
         } else if (end == left && !at_eof) {
             break;   // the payload is complete but its newline has not arrived: wait (the next read brings it)
         }
@@ -1545,9 +1591,11 @@ int thr_frame_card(const char* text, size_t text_len, int block_len, int at_eof,
         long long idx = 0;
         const auto r1 = std::from_chars(line, sp1, ts);
         const auto r2 = std::from_chars(sp1 + 1, sp2, idx);
-        if (r1.ec != std::errc() || r1.ptr != sp1 || r2.ec != std::errc() || r2.ptr != sp2)
+        if (r1.ec != std::errc() || r1.ptr != sp1 || r2.ec != std::errc() || r2.ptr != sp2) {
+            if (n) break;
             return fail(THR_ERR_ARG, "malformed .card header at byte %zu: %.40s", pos,
                         std::string(line, size_t(sp2 - line)).c_str());
+        }
         timestamps[n] = ts;
         block_idx[n] = idx;
         payload_off[n] = (long long)(pos + size_t(sp2 + 1 - line));

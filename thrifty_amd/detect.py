@@ -145,7 +145,7 @@ class Detector(object):
 
     def __init__(self, settings, blocks=None, rxid=-1, yield_data=False, batch_size=None,
                  device_id=0, _preshift_num=0, _fastdet=False, max_wait=None, max_fill=None,
-                 pin_input=True, _interpolator="parabolic", _path="auto"):
+                 pin_input=True, _interpolator="parabolic", _path="auto", populate_threads=0):
         """Batching a classic `(timestamp, idx, block)` iterator must not hold results back the way
         the reference's per-block loop never did.  What ends the batch being filled (what has
         arrived is processed instead of waiting for a full batch) depends on what the source says
@@ -160,12 +160,16 @@ class Detector(object):
             (host decode, gzip) still gets batches of hundreds of blocks, a live one a latency of
             50 ms instead of batch_size blocks' worth of waiting.
         `max_wait` / `max_fill` given explicitly apply to any source.  `pin_input`: page-lock a
-        mapped input file ahead of the copies while it is read (thr_input_window; best effort)."""
+        mapped input file ahead of the copies while it is read (thr_input_window; best effort);
+        `populate_threads`: the library threads that map its pages ahead of the locking (0 = the
+        library's default; a rank of a sharded run passes parallel.populate_threads(world))."""
         if batch_size is None:      # ~64 MiB of u8 samples per engine batch (the staging chunk size)
             batch_size = max(64, min(65536, (64 << 20) // (2 * int(settings.block_len))))
             if yield_data:          # every block of a batch holds two N-point stage dumps in _ready
                 batch_size = min(batch_size, _YIELD_DATA_BATCH)
         live = getattr(blocks, "live", None)
+        if live is None and isinstance(blocks, (list, tuple, np.ndarray)):
+            live = False            # an in-memory sequence never has to be waited for
         self._known_not_live = live is not None and not live
         if max_wait is None:
             max_wait = _SLOW_SOURCE_S if live else float("inf")
@@ -199,7 +203,7 @@ class Detector(object):
         reader = self._card if self._card is not None else self._raw
         span = reader.mapped_span() if reader is not None else None
         if pin_input and span is not None and len(span):
-            self._engine.input_window(span)
+            self._engine.input_window(span, populate_threads=populate_threads)
             self._pin = True
         self._ready = deque()
         self._exhausted = False
@@ -425,6 +429,12 @@ class Detector(object):
             pending = self._ahead.popleft()
             if not self.yield_data:
                 self._engine.collect(pending[2])
+        # nothing of the input is read any more: an error the read-ahead had parked belongs to
+        # blocks behind the one that ended the iteration, and the input's pages can be unlocked
+        self._read_error = None
+        if getattr(self, "_pin", False):
+            self._engine.input_window(None)
+            self._pin = False
 
     def _may_read_ahead(self, prev=None):
         """Reading the NEXT batch before handing out this one must not delay it: fine on files and
@@ -488,6 +498,126 @@ class Detector(object):
                 self._exhausted = True
                 self._drop_ahead()
                 self._result(stamps[stop], int(idxs[stop]), recs[stop])   # raises
+
+    # ---------------------------------------------------- the loop inside the library
+    def _library_loop_ready(self):
+        """True if the REST of the input can be handed to thr_run_card / thr_run_stream in one call:
+        a mapped file behind a batch reader, nothing in flight or handed out yet."""
+        reader = self._card if self._card is not None else self._raw
+        return (reader is not None and reader.mapped and not self.yield_data and not self._ahead
+                and not self._ready and not self._exhausted and self._read_error is None)
+
+    def _index_error(self, carrier_bin):
+        n = self.settings.block_len
+        return IndexError("index {} is out of bounds for axis 0 with size {}".format(
+            max(int(carrier_bin) + self._fit_reach, n), n))
+
+    def _run_library_loop(self, out_fd=None, want_records=False, partial=None):
+        """The rest of a mapped input through thr_run_card / thr_run_stream (framing, submission,
+        collection on this thread inside the library; .toad text formatted and written by a library
+        thread -- no Python per batch).  -> (stats, records or None).  The reference's IndexError
+        block (carrier_sync.py:187) raises IndexError here after the detections before it are out
+        (`partial`: a list that receives the record chunks as they complete, so a caller that
+        catches the error still holds the records before the block)."""
+        eng, mode = self._engine, _offset_mode(self._offset_type)
+        n_t = eng.n_templates
+        stats_all, recs_all = [], ([] if partial is None else partial)
+
+        def run(call, cap, **kw):
+            rec = np.zeros(cap * n_t, dtype=_native.RECORD_DTYPE) if want_records else None
+            try:
+                st = call(out_fd=out_fd, rxid=self.rxid, with_txid=self._multi, carrier_offset_mode=mode,
+                          batch_blocks=self.batch_size, rec_out=rec, **kw)
+            except _native.NativeError as exc:
+                self._finish_library_loop()
+                if rec is not None and len(exc.args) > 2:
+                    recs_all.append(rec[:exc.args[2]["detections"]])
+                if exc.code == _native.ERR_ARG and "base64" not in str(exc):
+                    raise ValueError(str(exc))        # (a malformed line: what CardStream raises)
+                raise
+            stats_all.append(st)
+            if rec is not None:
+                recs_all.append(rec[:st["detections"]])
+            if st["index_error"]:
+                self._finish_library_loop()
+                raise self._index_error(st["index_error_bin"])
+
+        if self._card is not None:
+            view, cap = self._card.take_rest()
+            run(lambda **kw: eng.run_card(view, **kw), cap)
+        else:
+            raw = self._raw
+            while raw.in_lead_in:               # the zero-history lead-in blocks (complex64, one batch)
+                batch = raw.next_batch(self.batch_size)
+                if batch is None:
+                    break
+                _, stamps, idxs, data = batch
+                recs = eng.detect(data, idxs).reshape(-1)
+                ts = np.repeat(np.asarray(stamps, dtype=np.float64), n_t)
+                bad = np.flatnonzero(recs["flags"] & _native.FLAG_INDEX_ERROR)
+                stop = int(bad[0]) if len(bad) else len(recs)
+                keep = np.flatnonzero(recs["flags"][:stop] & _native.FLAG_CORR)
+                if len(keep) and out_fd is not None:
+                    _write_fd(out_fd, _native.format_toad(recs[keep], ts[keep], self.new_len, rxid=self.rxid,
+                                                          with_txid=self._multi, carrier_offset_f32=mode))
+                if len(keep) and want_records:
+                    r = recs[keep].copy()
+                    r["reserved"] = ts[keep].view(np.uint64)
+                    recs_all.append(r)
+                stats_all.append({"blocks": len(idxs), "detections": len(keep), "lead_in": True})
+                if len(bad):
+                    self._finish_library_loop()
+                    raise self._index_error(recs["carrier_bin"][stop])
+            if not raw.in_lead_in:
+                view, first, n = raw.take_rest()
+                if n:
+                    run(lambda **kw: eng.run_stream(view, first_block_idx=first, **kw), n)
+        self._finish_library_loop()
+        total = {"blocks": sum(s["blocks"] for s in stats_all),
+                 "detections": sum(s["detections"] for s in stats_all), "calls": stats_all}
+        recs = None
+        if want_records:
+            recs = np.concatenate(recs_all) if recs_all else np.zeros(0, dtype=_native.RECORD_DTYPE)
+        return total, recs
+
+    def _finish_library_loop(self):
+        self._exhausted = True
+        self._more()            # (closes the input window)
+
+    def write_toad(self, output_file):
+        """Write the `.toad` lines of every remaining detection to `output_file` (what `thrifty
+        detect --quiet -o` does, reference detect.py:217-219).  For a mapped `.card` / raw file the
+        whole loop runs inside the library (thr_run_card / thr_run_stream: no Python per batch,
+        text written straight to the file's descriptor); any other source takes iter_toad_text().
+        -> statistics of the library loop, or None."""
+        fd = None
+        if self.blocks is not None and self._library_loop_ready():
+            try:
+                output_file.flush()
+                fd = output_file.fileno()
+            except (AttributeError, OSError, ValueError):
+                fd = None
+        if fd is not None:
+            stats, _ = self._run_library_loop(out_fd=fd)
+            return stats
+        binary = "b" in getattr(output_file, "mode", "") or not hasattr(output_file, "encoding")
+        for text in self.iter_toad_text():
+            output_file.write(text if binary else text.decode("ascii"))
+        output_file.flush()
+        return None
+
+    def detected_records(self):
+        """Every remaining DETECTED record, in input order, each with its timestamp's bits in
+        `reserved` -- what the ranks of a sharded run send to rank 0 (parallel.run_sharded).  A
+        mapped file runs inside the library like write_toad()."""
+        if self.blocks is not None and self._library_loop_ready():
+            return self._run_library_loop(want_records=True)[1]
+        chunks = []
+        for stamps, recs in self.iter_detected_records():
+            recs = recs.copy()
+            recs["reserved"] = np.ascontiguousarray(stamps, dtype=np.float64).view(np.uint64)
+            chunks.append(recs)
+        return np.concatenate(chunks) if chunks else np.zeros(0, dtype=_native.RECORD_DTYPE)
 
     def iter_toad_text(self):
         """Batches of `.toad` text (bytes: '\\n'-terminated lines) for the detected blocks,
@@ -596,6 +726,13 @@ class MultiTemplateDetector(Detector):
         return self.detect_batch([(timestamp, block_idx, block)])[0]
 
 
+def _write_fd(fd, data):
+    import os
+    view = memoryview(data)
+    while len(view):
+        view = view[os.write(fd, view):]
+
+
 def _carrier_freq(carrier_info, block_len, sample_rate):
     bin_freq = sample_rate / block_len
     return (util.fft_bin(carrier_info.bin, block_len) + carrier_info.offset) * bin_freq
@@ -655,6 +792,7 @@ def detector_cli(detector_class, parser=None, extra_args=None, argv=None):
     order.  The per-block summary lines are a console aid of the
     single-process loop and are not printed in that mode."""
     from thrifty_amd import parallel
+    parallel.rank_env()     # (before the HIP runtime initialises: the same on every launch route)
     argv = list(sys.argv[1:] if argv is None else argv)
     gpus = parallel.peek_gpus(argv)
     # a rank of a sharded run is a process that THIS CLI re-launched, or that torchrun started
@@ -722,6 +860,8 @@ def detector_cli(detector_class, parser=None, extra_args=None, argv=None):
         if args.gpus != world:
             raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
         blocks.shard(rank, world)
+        if "populate_threads" not in kwargs and detector_class in (Detector, MultiTemplateDetector):
+            kwargs["populate_threads"] = parallel.populate_threads(world)   # the ranks share the host's CPUs
         detections = detector_class(settings, blocks, rxid=config.rxid, device_id=local, **kwargs)
         if not hasattr(detections, "iter_detected_records"):
             raise SystemExit("--gpus: %s does not expose iter_detected_records() (the records that "
@@ -731,8 +871,12 @@ def detector_cli(detector_class, parser=None, extra_args=None, argv=None):
     detections = detector_class(settings, blocks, rxid=config.rxid, **kwargs)
     if args.quiet and hasattr(detections, "only_detections"):
         detections.only_detections = True   # nothing is printed for the other blocks anyway
+    if args.quiet and output_file is not None and hasattr(detections, "write_toad"):
+        # nothing per block is needed: a mapped input runs entirely inside the library
+        # (thr_run_card / thr_run_stream), anything else a batch of text at a time
+        detections.write_toad(output_file)
+        return
     if args.quiet and output_file is not None and hasattr(detections, "iter_toad_text"):
-        # nothing per block is needed: the library formats the detections of a batch at once
         for text in detections.iter_toad_text():
             output_file.write(text.decode("ascii"))
         output_file.flush()

@@ -27,18 +27,64 @@ def shard_range(n_blocks, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_records(local, world, rank, device=None, group=None, force=False):
+# What a rank's environment must hold before torch / the HIP runtime initialise, whichever way the
+# rank was started (the driver's `python -m torch.distributed.run ... bench.py --gpus N`, our own
+# relaunch_under_torchrun(), a user's torchrun): the host driver of these boxes only supports
+# dmabuf IPC, and without this RCCL's cross-process buffer sharing fails with
+# `hipIpcGetMemHandle: invalid argument`.
+RANK_ENV = {"HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+
+
+def rank_env(environ=None):
+    """Apply RANK_ENV (defaults: a value the caller exported wins) to `environ` (default: this
+    process) and return what is in effect.  Call it before `import torch` / the first HIP call."""
+    env = os.environ if environ is None else environ
+    for key, val in RANK_ENV.items():
+        env.setdefault(key, val)
+    return {key: env.get(key) for key in RANK_ENV}
+
+
+def cpu_budget():
+    """CPUs this process may keep busy: its affinity mask, capped by the cgroup-v2 quota
+    (`cpu.max`) of the container -- a box that shows 256 logical CPUs may grant 16."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def populate_threads(world):
+    """Page-table populator threads of a rank's input window (thr_input_window_ex): the CPUs of the
+    box divided among the ranks, minus the rank's own host thread, its text formatter and the
+    page-locking worker; between 1 and 3 (three is as good as any on an otherwise idle host,
+    DESIGN.md section 6; eight ranks on a 16-CPU cgroup get one each)."""
+    return max(1, min(3, cpu_budget() // max(1, int(world)) - 3))
+
+
+_gather_method = "gather"      # or "all_gather": chosen by gather_selftest() on the real backend
+
+
+def gather_records(local, world, rank, device=None, group=None, force=False, method=None):
     """Gather variable-length uint8 [n_i, 64] record tensors to rank 0, in rank order.
 
     Returns the concatenation on rank 0 and an empty [0, 64] tensor elsewhere.
     Because each rank owns an increasing block range and its records are in
     block order, the result is globally ordered by block index.
-    """
+
+    method "gather" (default): counts by all_gather, then ONE padded `dist.gather` to rank 0;
+    "all_gather": the padded buffers go to every rank and the others drop them -- the same bytes
+    over the most exercised collective, what gather_selftest() falls back to if the backend's
+    gather does not work."""
     import torch
     import torch.distributed as dist
 
     if world == 1 and not force:
         return local
+    method = method or _gather_method
     dev = local.device if device is None else device
     n = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
     counts = [torch.zeros_like(n) for _ in range(world)]
@@ -47,12 +93,73 @@ def gather_records(local, world, rank, device=None, group=None, force=False):
     m = max(max(counts), 1)
     padded = torch.zeros((m, RECORD_BYTES), dtype=torch.uint8, device=dev)
     padded[:local.shape[0]] = local
+    if method == "all_gather":
+        bufs = [torch.empty_like(padded) for _ in range(world)]
+        dist.all_gather(bufs, padded, group=group)
+        if rank != 0:
+            return padded[:0]
+        return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
     if rank == 0:
         bufs = [torch.empty_like(padded) for _ in range(world)]
         dist.gather(padded, bufs, dst=0, group=group)
         return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
     dist.gather(padded, None, dst=0, group=group)
     return padded[:0]
+
+
+def selftest_counts(world):
+    """Record counts of the pre-flight gather: uneven, and one rank with nothing (world > 1)."""
+    return [0 if (world > 1 and r == world - 1) else 3 + 2 * (r % 3) for r in range(world)]
+
+
+def gather_selftest(world, rank, device, group=None):
+    """One tiny gather_records() round on the REAL backend, before anything is timed: every rank
+    sends selftest_counts()[rank] records stamped (rank, position); rank 0 checks count, order and
+    bytes.  If the backend's `gather` raises on any rank or delivers something else, every rank
+    switches to the all_gather form (decided collectively, re-checked); if that fails too the run
+    ends here with a sentence instead of inside the timed region.  -> the method in use."""
+    import torch
+    import torch.distributed as dist
+    global _gather_method
+
+    counts = selftest_counts(world)
+
+    def payload(r):
+        a = np.zeros((counts[r], RECORD_BYTES), dtype=np.uint8)
+        a[:, 0] = r & 0xFF
+        a[:, 1] = np.arange(counts[r]) & 0xFF
+        a[:, 2:] = (np.arange(2, RECORD_BYTES) * (r + 1)) & 0xFF
+        return a
+
+    def one_round(method):
+        bad, why = 0, ""
+        try:
+            got = gather_records(torch.from_numpy(payload(rank)).to(device), world, rank, device, group=group,
+                                 force=True, method=method)
+            if rank == 0:
+                want = np.concatenate([payload(r) for r in range(world)])
+                if got.shape != tuple(want.shape) or not np.array_equal(got.cpu().numpy(), want):
+                    bad, why = 1, "rank 0 received %s records, expected %s" % (tuple(got.shape), want.shape)
+            elif got.shape[0] != 0:
+                bad, why = 1, "rank %d kept %d records" % (rank, got.shape[0])
+        except Exception as exc:      # (a backend without gather, a refused buffer: say so and fall back)
+            bad, why = 1, "%s: %s" % (type(exc).__name__, exc)
+        flag = torch.tensor([bad], dtype=torch.int64, device=device)
+        dist.all_reduce(flag, group=group)
+        return int(flag.item()), why
+
+    failed, why = one_round("gather")
+    if failed:
+        print("pre-flight: gather over %s failed on %d rank(s)%s; falling back to all_gather"
+              % (dist.get_backend(group), failed, " (rank %d: %s)" % (rank, why) if why else ""), file=sys.stderr)
+        failed2, why2 = one_round("all_gather")
+        if failed2:
+            raise SystemExit("pre-flight: neither gather nor all_gather over %s delivers the ranks' records "
+                             "(rank %d: %s)" % (dist.get_backend(group), rank, why2 or why))
+        _gather_method = "all_gather"
+    else:
+        _gather_method = "gather"
+    return _gather_method
 
 
 # ---------------------------------------------------------------------------------------------
@@ -111,7 +218,7 @@ def relaunch_under_torchrun(gpus, argv):
     spec = getattr(__main__, "__spec__", None)
     target = ["-m", spec.name] if spec is not None and spec.name else [os.path.abspath(sys.argv[0])]
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes)
+    rank_env(env)                                       # dmabuf IPC (RCCL across processes)
     env["THRIFTY_SHARDED"] = "1"                        # marks the children as ranks of THIS CLI
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + target + list(argv)
@@ -140,15 +247,29 @@ def run_sharded(detections, rank, world, local, output_file, backend="nccl"):
         dev = torch.device("cpu")
         if not dist.is_initialized():
             dist.init_process_group(backend)
-    chunks, error = [], None
-    try:
-        for stamps, recs in detections.iter_detected_records():
-            recs = recs.copy()
-            recs["reserved"] = np.ascontiguousarray(stamps, dtype=np.float64).view(np.uint64)
-            chunks.append(recs)
-    except IndexError as exc:
-        error = exc
-    mine = (np.concatenate(chunks) if chunks else np.zeros(0, dtype=_native.RECORD_DTYPE))
+    # before any work: the record gather must run on this backend with uneven and empty ranks
+    # (falls back to the all_gather form, or ends the run with a sentence)
+    gather_selftest(world, rank, dev)
+    # this rank's detected records, each with its timestamp in `reserved` (a mapped shard runs
+    # inside the library: thr_run_card / thr_run_stream with a record sink)
+    error, mine = None, np.zeros(0, dtype=_native.RECORD_DTYPE)
+    if hasattr(detections, "detected_records") and getattr(detections, "_library_loop_ready", lambda: False)():
+        sink = []
+        try:
+            mine = detections._run_library_loop(want_records=True, partial=sink)[1]
+        except IndexError as exc:
+            error = exc
+            mine = np.concatenate(sink) if sink else mine
+    else:
+        chunks = []
+        try:
+            for stamps, recs in detections.iter_detected_records():
+                recs = recs.copy()
+                recs["reserved"] = np.ascontiguousarray(stamps, dtype=np.float64).view(np.uint64)
+                chunks.append(recs)
+        except IndexError as exc:
+            error = exc
+        mine = np.concatenate(chunks) if chunks else mine
     failed = torch.tensor([1 if error is not None else 0], dtype=torch.int64, device=dev)
     flags = [torch.zeros_like(failed) for _ in range(world)]
     dist.all_gather(flags, failed)
