@@ -815,6 +815,7 @@ def main():
         r_t = torch.tensor([R], dtype=torch.int64, device=cdev)
         dist.broadcast(r_t, 0)
         R = int(r_t.item())
+    R_one_gpu = R
     if strong:
         # the job is what ONE GPU would run for --min-seconds (K x R launch batches); N ranks split it
         R = max(1, -(-R // world))
@@ -887,6 +888,8 @@ def main():
                        "name": args.config,
                        "variant": args.variant if not pnum else "preshift(num=%d)" % pnum,
                        "blocks_per_step_per_gpu": R * B, "launch_batches_per_step": R,
+                       # (the calibrated step of ONE GPU's job; --scaling strong splits it over the ranks)
+                       "launch_batches_per_step_one_gpu": R_one_gpu,
                        "blocks_per_launch_batch": B, "templates": T,
                        "carrier_window": list(leg.cwin), "thresholds": "15*snr",
                        "parallelism": "block-shard x%d" % world,

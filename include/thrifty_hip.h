@@ -161,6 +161,11 @@ int thr_create_fastdet(const thr_settings* settings, thr_handle** out);
  *                         overlap-save sections of 16384 points (detect_seg.hip).  AUTO falls back
  *                         to it by itself for templates longer than 9361 samples (at 65536) and for
  *                         thr_debug_stage dumps.
+ *   THR_PATH_GENERIC_ROWS AUTO, except that the correlate kernel of block_len 16384 (and of the
+ *                         sections of longer blocks) is the generic one, with the unique-window test
+ *                         in all 16 rows of lags, instead of the window-row specialisation the
+ *                         geometry selects (csrc/correlate16k_geom.hpp): same arithmetic, so the
+ *                         records are equal byte for byte -- which is what the tests use it for.
  * All paths implement the same reference semantics and agree to rounding (tests/test_gpu_*.py).
  */
 #define THR_VARIANT_DEFAULT 0
@@ -173,6 +178,7 @@ int thr_create_fastdet(const thr_settings* settings, thr_handle** out);
 #define THR_PATH_AUTO 0
 #define THR_PATH_MULTIPASS 1
 #define THR_PATH_UNSECTIONED 2
+#define THR_PATH_GENERIC_ROWS 3
 int thr_create_ex(const thr_settings* settings, int variant, int variant_arg, int path, thr_handle** out);
 /*
  * The overlap-save plan THR_PATH_AUTO uses for the correlate stage of a long block (host-only, no
@@ -466,10 +472,21 @@ const char* thr_kernel_name(int slot);
  *   (detect.py:75-78): the frequency-shifted spectrum and the correlation
  *   (first corr_len lags) for template `template_id`; either output may be NULL.
  */
+/* thr_debug_correlate_geom: which window-row specialisation of the correlate kernel this handle's
+ *   launches take (csrc/correlate16k_geom.hpp): *rows_lo / *rows_hi = rows of 1024 lags compiled out
+ *   below / above the unique window, or -1, -1 for the generic kernel (a window outside the table,
+ *   a stddev threshold term, another block length or variant).  Decided by the same function the
+ *   launcher calls. */
+int thr_debug_correlate_geom(thr_handle* h, int* rows_lo, int* rows_hi);
 /* thr_debug_window: the input window's state, in bytes from its (page-aligned) start:
  *   out[0] = everything below this offset has been released by the chunk copies (may be unlocked),
  *   out[1], out[2] = the range that is page-locked now, out[3] = the segment size (0: no window). */
 int thr_debug_window(thr_handle* h, size_t out[4]);
+/* thr_debug_window_times: seconds the window's threads have spent since it was opened -- out[0]
+ *   populating page tables (summed over the populator threads), out[1] in hipHostRegister, out[2] in
+ *   hipHostUnregister, out[3] the CALLER waiting in front of a copy for its segments to be locked;
+ *   out[4] = number of such waits, out[5] = chunk copies that went out as pageable memory instead. */
+int thr_debug_window_times(thr_handle* h, double out[6]);
 int thr_debug_fft(thr_handle* h, const void* samples, int format, size_t n_blocks,
                   float* spectra_out /* [n_blocks][block_len][2] */);
 int thr_debug_stage(thr_handle* h, const void* samples, int format, size_t n_blocks,

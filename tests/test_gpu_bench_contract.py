@@ -153,8 +153,11 @@ def test_strong_scaling_splits_one_gpus_job_over_the_ranks():
     one, two = lines[1], lines[2]
     # per-rank residency halves, and so does the per-rank step (to within the rounding of R)
     assert "32768 blocks/GPU" in two["config"]["workload"] and "65536 blocks/GPU" in one["config"]["workload"]
-    r1, r2 = one["config"]["launch_batches_per_step"], two["config"]["launch_batches_per_step"]
-    assert r2 == -(-r1 // 2) or abs(r2 - r1 / 2) <= max(1, 0.35 * r1 / 2)     # (calibrated per run)
+    # (the one-GPU step is calibrated per run -- and the rehearsal's two ranks share GPU 0 --, so each
+    # line is checked against its own calibration)
+    for world, d in lines.items():
+        c = d["config"]
+        assert c["launch_batches_per_step"] == -(-c["launch_batches_per_step_one_gpu"] // world)
     assert two["blocks_timed"] == 2 * two["steps"] * two["config"]["blocks_per_step_per_gpu"]
 
 

@@ -23,7 +23,8 @@ pytestmark = pytest.mark.gpu
 
 
 def data_lines(text):
-    return [ln for ln in text.strip().split("\n") if ln and not ln.startswith("#")]
+    return [ln for ln in text.strip().split("\n")
+            if ln.strip() and not ln.startswith(("#", "Using Volk machine:", "linux;"))]
 
 
 def python_loop_text(settings, reader, cls=Detector, **kw):

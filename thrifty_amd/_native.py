@@ -29,12 +29,12 @@ EXPORTS = [
     "thr_debug_stage", "thr_identify", "thr_frame_card",
     "thr_submit", "thr_submit_card", "thr_submit_stream", "thr_collect", "thr_inputs_consumed", "thr_poll",
     "thr_set_stream_default", "thr_format_toad",
-    "thr_run_card", "thr_run_stream", "thr_get_settings", "thr_input_window_ex", "thr_debug_window",
+    "thr_run_card", "thr_run_stream", "thr_get_settings", "thr_input_window_ex", "thr_debug_window", "thr_debug_window_times", "thr_debug_correlate_geom",
 ]
 ERR_ARG, ERR_DEVICE, ERR_STATE, ERR_INDEX = -1, -2, -3, -4       # THR_ERR_*
 VARIANT_DEFAULT, VARIANT_PRESHIFT, VARIANT_FASTDET = 0, 1, 2      # THR_VARIANT_*
 INTERPOLATORS = {"parabolic": 0, "none": 1, "gaussian": 2, "cosine": 3}      # THR_INTERP_*
-PATHS = {"auto": 0, "multipass": 1, "unsectioned": 2}             # THR_PATH_*
+PATHS = {"auto": 0, "multipass": 1, "unsectioned": 2, "generic_rows": 3}      # THR_PATH_*
 MAX_IN_FLIGHT = 3       # THR_MAX_IN_FLIGHT
 TOAD_LINE_MAX = 384     # THR_TOAD_LINE_MAX
 
@@ -555,6 +555,22 @@ class Engine(object):
         self._lib.thr_debug_window.argtypes = [C.c_void_p, C.c_size_t * 4]
         _check(self._lib, self._lib.thr_debug_window(self._h, out))
         return tuple(int(v) for v in out)
+
+    def correlate_geom(self):
+        """thr_debug_correlate_geom -> (rows_lo, rows_hi) of the window-row specialisation this
+        handle's correlate launches take, or (-1, -1): the generic kernel."""
+        lo, hi = C.c_int(-1), C.c_int(-1)
+        self._lib.thr_debug_correlate_geom.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        _check(self._lib, self._lib.thr_debug_correlate_geom(self._h, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def debug_window_times(self):
+        """thr_debug_window_times -> dict of seconds per activity of the input window's threads."""
+        out = (C.c_double * 6)()
+        self._lib.thr_debug_window_times.argtypes = [C.c_void_p, C.c_double * 6]
+        _check(self._lib, self._lib.thr_debug_window_times(self._h, out))
+        keys = ("populate_s", "register_s", "unregister_s", "acquire_wait_s", "acquire_waits", "pageable_copies")
+        return dict(zip(keys, (float(v) for v in out)))
 
     def collect(self, ticket):
         """thr_collect: wait for the ticket's batch -> its records [B, n_templates]."""

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <charconv>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -116,7 +117,7 @@ struct InputWindow {
     size_t consumed = 0;                      // segments below this one are not needed any more
     bool stop = false, failed = false;
     int device = 0;
-    std::thread worker;
+    std::thread worker, unlocker;
     std::mutex mu;
     std::condition_variable cv;
     // page-table population runs in front of the locking, on threads of its own: locking pages
@@ -126,6 +127,12 @@ struct InputWindow {
     std::vector<std::thread> populators;
     std::vector<unsigned char> populated;      // per segment: its pages are mapped
     size_t pop_next = 0;                       // next segment a populator takes
+    // where the window's threads spend their time (thr_debug_window_times; seconds, under `mu`)
+    double t_populate = 0, t_register = 0, t_unregister = 0, t_acquire = 0;
+    size_t n_acquire_waits = 0, n_pageable = 0;
+    static double now_s() {
+        return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    }
 
     void populate_run() {
         std::unique_lock<std::mutex> lk(mu);
@@ -135,6 +142,7 @@ struct InputWindow {
                 const size_t sgm = pop_next++;
                 lk.unlock();
                 void* at = reinterpret_cast<void*>(seg_lo(sgm));
+                const double t0 = now_s();
 #ifdef MADV_POPULATE_READ
                 int rc = madvise(at, seg_len(sgm), MADV_POPULATE_READ);
 #else
@@ -147,6 +155,7 @@ struct InputWindow {
                     (void)acc;
                 }
                 lk.lock();
+                t_populate += now_s() - t0;
                 populated[sgm] = 1;
                 cv.notify_all();
                 continue;
@@ -158,21 +167,19 @@ struct InputWindow {
     uintptr_t seg_lo(size_t s) const { return base + s * kSeg; }
     size_t seg_len(size_t s) const { return size_t(std::min<uintptr_t>(end, seg_lo(s) + kSeg) - seg_lo(s)); }
 
+    // the locking worker: page-locks segment reg_hi while it lies less than kAhead segments ahead of
+    // `consumed` and its pages are mapped
     void run() {
         (void)hipSetDevice(device);
         std::unique_lock<std::mutex> lk(mu);
         while (!stop) {
-            if (reg_lo < std::min(consumed, reg_hi)) {
-                const size_t sgm = reg_lo;
-                lk.unlock();
-                (void)hipHostUnregister(reinterpret_cast<void*>(seg_lo(sgm)));
-                lk.lock();
-                ++reg_lo;
-                continue;
-            }
-            if (!failed && reg_hi < n_seg && reg_hi < consumed + kAhead) {
+            // (never more than 2 x kAhead segments locked, however far the unlocker lags behind)
+            if (!failed && reg_hi < n_seg && reg_hi < consumed + kAhead && reg_hi < reg_lo + 2 * kAhead) {
                 if (reg_hi < consumed) {      // the reader skipped ahead: nothing in between is wanted
-                    reg_lo = reg_hi = consumed;
+                    if (reg_lo == reg_hi)     // (once the unlocker has let go of what was locked below)
+                        reg_lo = reg_hi = consumed;
+                    else
+                        cv.wait(lk);
                     continue;
                 }
                 const size_t sgm = reg_hi;
@@ -181,10 +188,12 @@ struct InputWindow {
                     continue;
                 }
                 lk.unlock();
+                const double t0 = now_s();
                 const hipError_t rc = hipHostRegister(reinterpret_cast<void*>(seg_lo(sgm)), seg_len(sgm),
                                                       hipHostRegisterDefault);
                 if (rc != hipSuccess) (void)hipGetLastError();
                 lk.lock();
+                t_register += now_s() - t0;
                 if (rc == hipSuccess)
                     ++reg_hi;
                 else
@@ -194,12 +203,29 @@ struct InputWindow {
             }
             cv.wait(lk);
         }
-        for (size_t sgm = reg_lo; sgm < reg_hi; ++sgm) {
-            lk.unlock();
-            (void)hipHostUnregister(reinterpret_cast<void*>(seg_lo(sgm)));
-            lk.lock();
+    }
+
+    // the unlocking worker, a thread of its own: hipHostUnregister costs three times what
+    // hipHostRegister costs on mapped pages (measured: 47 against 15 ms per 2.9 GB), and on ONE
+    // thread the two together filled the whole run -- the caller waited for locks that were queued
+    // behind unlocks of segments nobody needed any more
+    void unlock_run() {
+        (void)hipSetDevice(device);
+        std::unique_lock<std::mutex> lk(mu);
+        while (!stop) {
+            if (reg_lo < std::min(consumed, reg_hi)) {
+                const size_t sgm = reg_lo;
+                lk.unlock();
+                const double t0 = now_s();
+                (void)hipHostUnregister(reinterpret_cast<void*>(seg_lo(sgm)));
+                lk.lock();
+                t_unregister += now_s() - t0;
+                ++reg_lo;
+                cv.notify_all();
+                continue;
+            }
+            cv.wait(lk);
         }
-        reg_lo = reg_hi = 0;
     }
 
     void open(const void* p, size_t bytes, int dev, int n_populators = kPopulators, size_t seg_bytes = 0) {
@@ -211,10 +237,13 @@ struct InputWindow {
         end = (reinterpret_cast<uintptr_t>(p) + bytes + page - 1) & ~(page - 1);
         n_seg = size_t((end - base + kSeg - 1) / kSeg);
         reg_lo = reg_hi = consumed = pop_next = 0;
+        t_populate = t_register = t_unregister = t_acquire = 0;
+        n_acquire_waits = n_pageable = 0;
         populated.assign(n_seg, 0);
         stop = failed = false;
         device = dev;
         worker = std::thread([this] { run(); });
+        unlocker = std::thread([this] { unlock_run(); });
         populators.clear();
         for (int i = 0; i < std::max(1, n_populators); ++i) populators.emplace_back([this] { populate_run(); });
     }
@@ -227,8 +256,12 @@ struct InputWindow {
         }
         cv.notify_all();
         worker.join();
+        unlocker.join();
         for (auto& t : populators) t.join();
         populators.clear();
+        for (size_t sgm = reg_lo; sgm < reg_hi; ++sgm)      // what is still locked
+            (void)hipHostUnregister(reinterpret_cast<void*>(seg_lo(sgm)));
+        reg_lo = reg_hi = 0;
         base = end = 0;
         n_seg = 0;
     }
@@ -240,8 +273,16 @@ struct InputWindow {
         if (base == 0 || bytes == 0 || a < base || a + bytes > end) return false;
         const size_t s0 = size_t((a - base) / kSeg), s1 = size_t((a + bytes - 1 - base) / kSeg);
         std::unique_lock<std::mutex> lk(mu);
-        if (failed || s0 < reg_lo || s1 >= consumed + kAhead) return false;
-        cv.wait(lk, [&] { return failed || reg_hi > s1; });
+        if (failed || s0 < reg_lo || s1 >= consumed + kAhead) {
+            ++n_pageable;
+            return false;
+        }
+        if (!(failed || reg_hi > s1)) {
+            const double t0 = now_s();
+            cv.wait(lk, [&] { return failed || reg_hi > s1; });
+            t_acquire += now_s() - t0;
+            ++n_acquire_waits;
+        }
         return !failed && s0 >= reg_lo;
     }
 
@@ -1079,6 +1120,34 @@ int thr_debug_window(thr_handle* h, size_t out[4]) {
     return THR_OK;
 }
 
+int thr_debug_correlate_geom(thr_handle* h, int* rows_lo, int* rows_hi) {
+    if (!h || !rows_lo || !rows_hi) return fail(THR_ERR_ARG, "thr_debug_correlate_geom: null argument");
+    *rows_lo = *rows_hi = -1;
+    int lo = -1, hi = -1;
+    bool got = false;
+    if (h->fast && !h->preshift_num)
+        got = thr::correlate_geom_16k(h->dev, &lo, &hi);
+    else if (h->seg)
+        got = thr::correlate_geom_seg(h->dev, &lo, &hi);
+    if (got) {
+        *rows_lo = lo;
+        *rows_hi = hi;
+    }
+    return THR_OK;
+}
+
+int thr_debug_window_times(thr_handle* h, double out[6]) {
+    if (!h || !out) return fail(THR_ERR_ARG, "thr_debug_window_times: null argument");
+    std::lock_guard<std::mutex> lk(h->win.mu);
+    out[0] = h->win.t_populate;
+    out[1] = h->win.t_register;
+    out[2] = h->win.t_unregister;
+    out[3] = h->win.t_acquire;
+    out[4] = double(h->win.n_acquire_waits);
+    out[5] = double(h->win.n_pageable);
+    return THR_OK;
+}
+
 int thr_plan_sections(int block_len, int history_len, int template_len, int* n_sections, int* start,
                       int* win_lo, int* win_hi, int* sum_lo, int* sum_hi) {
     if (!n_sections || !start || !win_lo || !win_hi || !sum_lo || !sum_hi)
@@ -1106,7 +1175,8 @@ int thr_plan_sections(int block_len, int history_len, int template_len, int* n_s
 }
 
 int thr_create_ex(const thr_settings* s, int variant, int variant_arg, int path, thr_handle** out) {
-    if (path != THR_PATH_AUTO && path != THR_PATH_MULTIPASS && path != THR_PATH_UNSECTIONED)
+    if (path != THR_PATH_AUTO && path != THR_PATH_MULTIPASS && path != THR_PATH_UNSECTIONED &&
+        path != THR_PATH_GENERIC_ROWS)
         return fail(THR_ERR_ARG, "thr_create_ex: unknown path %d", path);
     switch (variant) {
         case THR_VARIANT_DEFAULT: return create_impl(s, 0, out, -1, path);
@@ -1213,6 +1283,7 @@ static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out
                 d.car_prune = 2;  // any narrow window: pre-shift by win_lo - 3
         }
         d.cor_want_std = s->corr_thresh[2] != 0.0;
+        d.no_row_geom = path == THR_PATH_GENERIC_ROWS;
         h->small = thr::small_supported(n) && !multipass && !preshift_num;
         // long blocks: the correlate stage in overlap-save sections wherever the template allows
         h->seg = h->lng && path != THR_PATH_UNSECTIONED && plan_sections(d, s->template_len);

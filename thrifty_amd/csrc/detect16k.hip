@@ -20,7 +20,7 @@
 // holds its block_len = 16384 instantiations and their launcher.
 #include <hip/hip_runtime.h>
 
-#include "correlate16k.hpp"
+#include "correlate16k_geom.hpp"
 
 namespace thr {
 
@@ -50,30 +50,23 @@ correlate_fn correlate_variant(int fmt, bool want_std, bool multi, bool dump) {
 }
 #endif
 
-// window geometries with a specialised peak search (no stddev term, no dumps)
-struct RowGeom {
-    int lo, hi;
-};
-constexpr RowGeom kRowGeoms[] = {{1, 2}, {0, 4}};
-constexpr int kNumRowGeoms = int(sizeof(kRowGeoms) / sizeof(kRowGeoms[0]));
-
-template <int FMT, bool MULTI>
-correlate_fn geom_pick(int g) {
-    return g == 0 ? &k_correlate<FMT, false, MULTI, false, kRowGeoms[0].lo, kRowGeoms[0].hi>
-                  : &k_correlate<FMT, false, MULTI, false, kRowGeoms[1].lo, kRowGeoms[1].hi>;
-}
-correlate_fn geom_variant(int fmt, int g, bool multi) {
+// the window-row specialisation for this geometry (no stddev term, no dumps), or nullptr
+correlate_fn geom_variant(int fmt, int lo, int hi, bool multi) {
 #ifdef THR_DEV_MINIMAL
     (void)fmt;
-    (void)g;
+    (void)lo;
+    (void)hi;
     (void)multi;
     return nullptr;
 #else
-    if (fmt == THR_IN_U8) return multi ? geom_pick<THR_IN_U8, true>(g) : geom_pick<THR_IN_U8, false>(g);
-    return multi ? geom_pick<THR_IN_C64, true>(g) : geom_pick<THR_IN_C64, false>(g);
+    switch (lo) {
+        case 0: return geom_variant_lo0(fmt, multi, hi);
+        case 1: return geom_variant_lo1(fmt, multi, hi);
+        case 2: return geom_variant_lo2(fmt, multi, hi);
+    }
+    return nullptr;
 #endif
 }
-static_assert(kNumRowGeoms == 2, "geom_variant() enumerates the geometries by hand");
 }  // namespace
 
 hipError_t prepare_16k_carrier();   // detect16k_carrier.hip
@@ -91,16 +84,19 @@ hipError_t prepare_16k() {
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
                     if (e != hipSuccess) return e;
                 }
-    for (int fmt = 0; fmt < 2; ++fmt)
-        for (int g = 0; g < kNumRowGeoms; ++g)
-            for (int m = 0; m < 2; ++m) {
-                correlate_fn fn = geom_variant(fmt, g, m != 0);
-                if (fn == nullptr) continue;
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-                if (e != hipSuccess) return e;
-            }
+#ifndef THR_DEV_MINIMAL
+    if ((e = prepare_geom_lo0()) != hipSuccess) return e;
+    if ((e = prepare_geom_lo1()) != hipSuccess) return e;
+    if ((e = prepare_geom_lo2()) != hipSuccess) return e;
+#endif
     return hipSuccess;
+}
+
+// which window-row specialisation launch_correlate_16k takes for this configuration (false: the
+// generic kernel) -- the launcher and thr_debug_correlate_geom share this one decision
+bool correlate_geom_16k(const DevCfg& cfg, int* lo, int* hi) {
+    if (cfg.cor_want_std != 0 || cfg.no_row_geom) return false;
+    return pick_row_geom(&cfg.corr_lo, &cfg.corr_hi, 1, kGeomLoMax, lo, hi);
 }
 
 hipError_t launch_correlate_16k(int fmt, const void* samples, const DevCfg& cfg,
@@ -111,13 +107,11 @@ hipError_t launch_correlate_16k(int fmt, const void* samples, const DevCfg& cfg,
                                 hipStream_t stream) {
     const bool dump = dump_xhat != nullptr || dump_corr != nullptr;
     correlate_fn fn = correlate_variant(fmt, cfg.cor_want_std != 0, cfg.n_templates > 1, dump);
-    if (!dump && cfg.cor_want_std == 0)
-        for (int g = 0; g < kNumRowGeoms; ++g)
-            if (row_geom_applies(kRowGeoms[g].lo, kRowGeoms[g].hi, cfg.corr_lo, cfg.corr_hi) &&
-                geom_variant(fmt, g, cfg.n_templates > 1) != nullptr) {
-                fn = geom_variant(fmt, g, cfg.n_templates > 1);
-                break;
-            }
+    int lo = -1, hi = -1;
+    if (!dump && correlate_geom_16k(cfg, &lo, &hi)) {
+        correlate_fn g = geom_variant(fmt, lo, hi, cfg.n_templates > 1);
+        if (g != nullptr) fn = g;
+    }
     hipLaunchKernelGGL(fn, dim3(grid), dim3(NT), LDS_BYTES, stream, samples, cfg,
                        reinterpret_cast<const cpx*>(tables), reinterpret_cast<const cpx*>(twn),
                        reinterpret_cast<const f4*>(tspec), shifts, work_list, work_count,

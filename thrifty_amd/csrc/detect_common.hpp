@@ -41,6 +41,7 @@ struct DevCfg {
     // coordinates (lag - seg_start[g]): it owns the window lags [seg_lo[g], seg_hi[g]) and, for the
     // stddev term, sums the lags [seg_sum_lo[g], seg_sum_hi[g]); the owned ranges tile the block's
     // [corr_lo, corr_hi) resp. [0, corr_len) exactly once (plan_sections, api.hip).
+    int no_row_geom;   // THR_PATH_GENERIC_ROWS: the correlate launches take the generic kernel (cross-checks)
     int n_seg;
     int seg_start[kMaxSections];
     int seg_lo[kMaxSections], seg_hi[kMaxSections];
@@ -108,6 +109,10 @@ hipError_t launch_correlate_16k(int fmt, const void* samples, const DevCfg& cfg,
                                 const int* work_count, CorrStats* corr_stats,
                                 float2* dump_xhat, float2* dump_corr, int dump_template, int grid,
                                 hipStream_t stream);
+// the window-row specialisation (correlate16k_geom.hpp) the correlate launch of this configuration
+// takes; false: the generic kernel
+bool correlate_geom_16k(const DevCfg& cfg, int* lo, int* hi);
+bool correlate_geom_seg(const DevCfg& cfg, int* lo, int* hi);
 // seg_stats (or null): the sectioned correlate stage's [record][section] results, merged here
 hipError_t launch_finish(int n_records, const DevCfg& cfg, const CorrStats* corr_stats,
                          thr_record* records, int* work_count, hipStream_t stream,

@@ -15,17 +15,13 @@
 // lowest lag, and the owned lag ranges ascend with the section index).
 #include <hip/hip_runtime.h>
 
-#include "correlate16k.hpp"
+#include "correlate16k_geom.hpp"
 
 namespace thr {
 
 using namespace k16;
 
 namespace {
-// the section geometry with a specialised peak search: window lags [1, 12289) of every section --
-// BASELINE's 65536-sample blocks with the 4094-sample template and history 4096
-constexpr int kSegRowLo = 0, kSegRowHi = 3;
-
 template <int FMT, bool STD>
 correlate_fn seg_pick(bool multi) {
     return multi ? &k_correlate<FMT, STD, true, false, -1, -1, true>
@@ -35,30 +31,27 @@ correlate_fn seg_variant(int fmt, bool want_std, bool multi) {
     if (fmt == THR_IN_U8) return want_std ? seg_pick<THR_IN_U8, true>(multi) : seg_pick<THR_IN_U8, false>(multi);
     return want_std ? seg_pick<THR_IN_C64, true>(multi) : seg_pick<THR_IN_C64, false>(multi);
 }
-template <int FMT>
-correlate_fn seg_geom_pick(bool multi) {
-    return multi ? &k_correlate<FMT, false, true, false, kSegRowLo, kSegRowHi, true>
-                 : &k_correlate<FMT, false, false, false, kSegRowLo, kSegRowHi, true>;
-}
-correlate_fn seg_geom_variant(int fmt, bool multi) {
-    return fmt == THR_IN_U8 ? seg_geom_pick<THR_IN_U8>(multi) : seg_geom_pick<THR_IN_C64>(multi);
-}
 }  // namespace
 
 hipError_t prepare_seg() {
     for (int fmt = 0; fmt < 2; ++fmt)
-        for (int m = 0; m < 2; ++m) {
+        for (int m = 0; m < 2; ++m)
             for (int st = 0; st < 2; ++st) {
                 hipError_t e = hipFuncSetAttribute(
                     reinterpret_cast<const void*>(seg_variant(fmt, st != 0, m != 0)),
                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
                 if (e != hipSuccess) return e;
             }
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(seg_geom_variant(fmt, m != 0)),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-            if (e != hipSuccess) return e;
-        }
-    return hipSuccess;
+    // the window-row specialisations of the sections (correlate16k_geom.hpp): owned lags start at
+    // 0 or 1, so RLO = 0; RHI = 0 .. 4 by the template length (BASELINE's 4094 samples: 3)
+    return prepare_geom_row<0, true>();
+}
+
+// which specialisation launch_correlate_seg takes: one pair must fit the window of EVERY section
+// (the launch is one kernel over all (block, section) items)
+bool correlate_geom_seg(const DevCfg& cfg, int* lo, int* hi) {
+    if (cfg.cor_want_std != 0 || cfg.n_seg <= 0 || cfg.no_row_geom) return false;
+    return pick_row_geom(cfg.seg_lo, cfg.seg_hi, cfg.n_seg, 0, lo, hi);
 }
 
 // seg_stats: [block of the sub-batch][template][section]
@@ -68,12 +61,8 @@ hipError_t launch_correlate_seg(int fmt, const void* samples, const DevCfg& cfg,
                                 int grid, hipStream_t stream) {
     const bool multi = cfg.n_templates > 1;
     correlate_fn fn = seg_variant(fmt, cfg.cor_want_std != 0, multi);
-    if (cfg.cor_want_std == 0) {
-        bool all = true;
-        for (int g = 0; g < cfg.n_seg; ++g)
-            all = all && row_geom_applies(kSegRowLo, kSegRowHi, cfg.seg_lo[g], cfg.seg_hi[g]);
-        if (all) fn = seg_geom_variant(fmt, multi);
-    }
+    int lo = -1, hi = -1;
+    if (correlate_geom_seg(cfg, &lo, &hi)) fn = geom_row<0, true>(fmt, multi, hi);
     hipLaunchKernelGGL(fn, dim3(grid), dim3(NT), LDS_BYTES, stream, samples, cfg,
                        reinterpret_cast<const cpx*>(tables), reinterpret_cast<const cpx*>(twn),
                        reinterpret_cast<const f4*>(tspec16k), shifts, work_list, work_count, seg_stats,

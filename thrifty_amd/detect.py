@@ -673,11 +673,12 @@ class MultiTemplateDetector(Detector):
     _multi = True
 
     def __init__(self, settings, blocks=None, rxid=-1, yield_data=False, batch_size=None,
-                 device_id=0, max_wait=None):
+                 device_id=0, max_wait=None, populate_threads=0):
         if yield_data:
             raise TypeError("stage dumps (yield_data) are a single-template facility")
         super(MultiTemplateDetector, self).__init__(settings, blocks, rxid=rxid, batch_size=batch_size,
-                                                    device_id=device_id, max_wait=max_wait)
+                                                    device_id=device_id, max_wait=max_wait,
+                                                    populate_threads=populate_threads)
         self.n_templates = int(np.asarray(settings.template).shape[0])
 
     def _flat(self, stamps, idxs, recs):
