@@ -276,6 +276,16 @@ int thr_input_window(thr_handle* h, const void* p, size_t bytes);
  * the locking granularity -- the tests shrink it to put segment boundaries where they want them.
  */
 int thr_input_window_ex(thr_handle* h, const void* p, size_t bytes, int populate_threads, size_t segment_bytes);
+/*
+ * "The input has been read": no further copy will come out of the window.  Returns at once; what is
+ * still page-locked (the segments of the last chunks) is unlocked by the window's own thread in the
+ * background -- a few milliseconds of hipHostUnregister that a caller writing its last output line
+ * need not wait for.  Source ranges inside the window are copied as pageable memory from here on.
+ * The mapping must STILL stay valid until thr_input_window(h, NULL, 0), the next
+ * thr_input_window[_ex] on this handle or thr_destroy has returned: those wait for the unlocking.
+ * Not while tickets are open (THR_ERR_STATE).
+ */
+int thr_input_window_release(thr_handle* h);
 
 int thr_detect_card(thr_handle* h, const char* text, size_t text_len, const int64_t* payload_off,
                     const int64_t* block_idx, size_t n_blocks, thr_record* out);
@@ -487,6 +497,12 @@ int thr_debug_window(thr_handle* h, size_t out[4]);
  *   hipHostUnregister, out[3] the CALLER waiting in front of a copy for its segments to be locked;
  *   out[4] = number of such waits, out[5] = chunk copies that went out as pageable memory instead. */
 int thr_debug_window_times(thr_handle* h, double out[6]);
+/* thr_debug_pipe_times: seconds the calling thread has spent inside the chunks of the host entry
+ *   points since the last call (reads and resets): out[0] growing staging buffers, out[1] the input's
+ *   host-to-device copy calls, out[2] block indices / offsets, out[3] kernel launches, out[4] the
+ *   records' device-to-host calls; out[5] = chunks; out[6] event record / wait between the copy and
+ *   the main stream, out[7] filling the index array (sample chunks). */
+int thr_debug_pipe_times(thr_handle* h, double out[8]);
 int thr_debug_fft(thr_handle* h, const void* samples, int format, size_t n_blocks,
                   float* spectra_out /* [n_blocks][block_len][2] */);
 int thr_debug_stage(thr_handle* h, const void* samples, int format, size_t n_blocks,

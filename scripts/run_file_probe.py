@@ -44,7 +44,9 @@ out_fd = os.open(os.devnull, os.O_WRONLY)
 
 
 def run(batch, pop, seg, window=True):
+    t_c = time.perf_counter()
     eng = F.Engine(n, h, tpl, thr, win, tuple(float(v) for v in g["corr_thresh"]), max_batch=batch)
+    t_c = time.perf_counter() - t_c
     with open(tmp.name, "rb") as f:
         mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
         view = memoryview(mm)
@@ -57,28 +59,31 @@ def run(batch, pop, seg, window=True):
             st = eng.run_stream(view, first_block_idx=0, out_fd=out_fd, rxid=0, batch_blocks=batch)
         dt = time.perf_counter() - t0
         wt = eng.debug_window_times() if window else {}
+        pt = eng.debug_pipe_times()
         eng.input_window(None)
         view.release()
         mm.close()
     eng.close()
     per = 1e3 / max(1, st["batches"])
+    print("create %.1f ms; " % (t_c * 1e3), end="")
     print("batch %5d pop %d seg %4d MiB%s: %.3f M blocks/s (%.1f GB/s) | per batch ms: frame %.2f submit %.2f wait %.2f "
           "| text thread: format %.2f write %.2f | window s: populate %.3f lock %.3f unlock %.3f caller-waited %.3f "
-          "(%d waits, %d pageable)" % (
+          "(%d waits, %d pageable) | submit phases ms/batch: grow %.3f h2d %.3f meta %.3f launch %.3f d2h %.3f event %.3f fill %.3f" % (
               batch, pop, seg >> 20, "" if window else " NO WINDOW", st["blocks"] / dt / 1e6, size / dt / 1e9,
               st["frame_s"] * per, st["submit_s"] * per, st["wait_s"] * per, st["format_s"] * per, st["write_s"] * per,
               wt.get("populate_s", 0), wt.get("register_s", 0), wt.get("unregister_s", 0), wt.get("acquire_wait_s", 0),
-              wt.get("acquire_waits", 0), wt.get("pageable_copies", 0)))
+              wt.get("acquire_waits", 0), wt.get("pageable_copies", 0),
+              *[pt[k] * 1e3 / max(1, pt["chunks"]) for k in ("grow_s", "h2d_s", "meta_s", "launch_s", "d2h_s", "event_s", "fill_s")]))
 
 
 run(2048, 3, 128 << 20)     # warm-up (code objects, staging pools)
-for rep in range(2):
+for rep in range(3):
     run(2048, 3, 128 << 20)
-for pop in (1, 2, 4, 6):
+run(1024, 3, 128 << 20)
+for pop in (1, 2):
     run(2048, pop, 128 << 20)
-for seg in (32 << 20, 64 << 20, 256 << 20):
+for seg in (32 << 20, 256 << 20):
     run(2048, 3, seg)
-for batch in (1024, 4096):
-    run(batch, 3, 128 << 20)
+run(4096, 3, 128 << 20)
 run(2048, 3, 128 << 20, window=False)
 os.unlink(tmp.name)

@@ -118,7 +118,7 @@ def test_index_error_block_ends_the_run_where_the_reference_raises(golden, tmp_p
             det = Detector(st, CardStream(f, 16384), rxid=0, batch_size=batch)
             with pytest.raises(IndexError) as exc:
                 det.write_toad(o)
-            assert str(exc.value) == str(one.value) and not det._pin
+                assert str(exc.value) == str(one.value) and not det._pin
         want = b""
         try:
             for text in Detector(st, CardStream(io.BytesIO(card_text(g).encode()), 16384), rxid=0,
@@ -225,17 +225,23 @@ def test_window_is_never_released_past_the_start_of_an_open_chunk():
     the oldest must not release (let the worker unlock) input-window segments that the next chunk's
     copy still reads: the released mark stays at or below the start of every open chunk, also when a
     segment boundary falls inside the overlap (64 KiB segments put one into nearly every overlap)."""
-    n, h = 4096, 1024
+    # (history 3/4 of the block: consecutive 10-block chunks start 20 KiB apart and share 6 KiB, so a
+    # 64 KiB boundary falls into the shared bytes of about every third pair of chunks)
+    n, h = 4096, 3072
     tpl = synth.gold_template(9, 2, 1.0)
-    nblk = 120
+    nblk = 2000
     raw, _ = burst_stream(np.random.default_rng(11), n, h, tpl, nblk, (20.5, 44.1, 63.7, 91.2, 33.0, 50.5))
-    stream = np.ascontiguousarray(raw)
+    room = np.empty(len(raw) + 4096, dtype=np.uint8)        # a page-aligned copy: the same segment grid every run
+    off = -room.ctypes.data % 4096
+    stream = room[off:off + len(raw)]
+    stream[:] = raw
     step, blk = 2 * (n - h), 2 * n
     eng = F.Engine(n, h, tpl, (0, 15, 0), (7, 110), (0, 15, 0), max_batch=10)
-    want = eng.detect_stream(stream[step - 2 * h:], first_block_idx=1)           # no window: pageable copies
+    lead = -(-h // (n - h))                       # blocks that still reach before the stream's first byte
+    tail = stream[lead * step - 2 * h:]           # blocks lead .. : block i starts (i - lead) * step into `tail`
+    want = eng.detect_stream(tail, first_block_idx=lead)                          # no window: pageable copies
     eng.input_window(stream, segment_bytes=1 << 16)
     base = stream.ctypes.data & ~4095
-    tail = stream[step - 2 * h:]                  # blocks 1 .. : block i starts (i - 1) * step into `tail`
     total = (len(tail) - blk) // step + 1
     chunks = [(s, min(10, total - s)) for s in range(0, total, 10)]
     open_, got, inside = [], [], 0
@@ -244,15 +250,15 @@ def test_window_is_never_released_past_the_start_of_an_open_chunk():
         while pending and len(open_) < F.MAX_IN_FLIGHT:
             s, nb = pending.pop(0)
             view = tail[s * step:(s + nb - 1) * step + blk]
-            open_.append((eng.submit_stream(view, first_block_idx=1 + s), view.ctypes.data - base, len(view)))
+            open_.append((eng.submit_stream(view, first_block_idx=lead + s), view.ctypes.data - base, len(view)))
         ticket, start, size = open_.pop(0)
         got.append(eng.collect(ticket))
         released = eng.debug_window()[0]
         for _, o_start, _ in open_:
             assert released <= o_start, (released, o_start)
             # (the case the rule exists for: the next chunk starts in the segment BELOW this one's end)
-            inside += (o_start >> 16) < ((start + size) >> 16)
+            inside += (o_start >> 16) < ((start + size - 1) >> 16)
     eng.input_window(None)
     got = np.concatenate(got)
-    assert inside >= 3
+    assert inside >= 10
     assert got.tobytes() == want.tobytes() and len(got) == total

@@ -29,7 +29,7 @@ EXPORTS = [
     "thr_debug_stage", "thr_identify", "thr_frame_card",
     "thr_submit", "thr_submit_card", "thr_submit_stream", "thr_collect", "thr_inputs_consumed", "thr_poll",
     "thr_set_stream_default", "thr_format_toad",
-    "thr_run_card", "thr_run_stream", "thr_get_settings", "thr_input_window_ex", "thr_debug_window", "thr_debug_window_times", "thr_debug_correlate_geom",
+    "thr_run_card", "thr_run_stream", "thr_get_settings", "thr_input_window_ex", "thr_input_window_release", "thr_debug_window", "thr_debug_window_times", "thr_debug_correlate_geom", "thr_debug_pipe_times",
 ]
 ERR_ARG, ERR_DEVICE, ERR_STATE, ERR_INDEX = -1, -2, -3, -4       # THR_ERR_*
 VARIANT_DEFAULT, VARIANT_PRESHIFT, VARIANT_FASTDET = 0, 1, 2      # THR_VARIANT_*
@@ -494,10 +494,20 @@ class Engine(object):
             _check(self._lib, self._lib.thr_input_window(self._h, None, 0))
             self._window = None
             return
+        if getattr(self, "_window", None) is not None:     # (waits for a released window's unlocking)
+            _check(self._lib, self._lib.thr_input_window(self._h, None, 0))
+            self._window = None
         arr = np.frombuffer(buf, dtype=np.uint8)
         _check(self._lib, self._lib.thr_input_window_ex(self._h, arr.ctypes.data, arr.size,
                                                         int(populate_threads), int(segment_bytes)))
         self._window = arr
+
+    def input_window_release(self):
+        """thr_input_window_release: the input has been read -- stop locking, unlock what is still
+        locked in the background, return at once.  This object keeps the buffer alive until the
+        window is really closed (input_window(None), a new window, or close())."""
+        self._lib.thr_input_window_release.argtypes = [C.c_void_p]
+        _check(self._lib, self._lib.thr_input_window_release(self._h))
 
     # ---- the whole file -> .toad loop inside the library (thr_run_card / thr_run_stream) -------
     def _run_opts(self, out_fd, rxid, with_txid, carrier_offset_mode, batch_blocks, rec_out, timestamp=None):
@@ -563,6 +573,14 @@ class Engine(object):
         self._lib.thr_debug_correlate_geom.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         _check(self._lib, self._lib.thr_debug_correlate_geom(self._h, C.byref(lo), C.byref(hi)))
         return lo.value, hi.value
+
+    def debug_pipe_times(self):
+        """thr_debug_pipe_times -> seconds per phase of the host entry points' chunks (reads and resets)."""
+        out = (C.c_double * 8)()
+        self._lib.thr_debug_pipe_times.argtypes = [C.c_void_p, C.c_double * 8]
+        _check(self._lib, self._lib.thr_debug_pipe_times(self._h, out))
+        return dict(zip(("grow_s", "h2d_s", "meta_s", "launch_s", "d2h_s", "chunks", "event_s", "fill_s"),
+                        (float(v) for v in out)))
 
     def debug_window_times(self):
         """thr_debug_window_times -> dict of seconds per activity of the input window's threads."""

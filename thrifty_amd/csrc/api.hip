@@ -116,6 +116,7 @@ struct InputWindow {
     size_t reg_lo = 0, reg_hi = 0;            // segments [reg_lo, reg_hi) are locked now
     size_t consumed = 0;                      // segments below this one are not needed any more
     bool stop = false, failed = false;
+    bool draining = false;                    // release_all(): nothing more is locked, everything locked is let go
     int device = 0;
     std::thread worker, unlocker;
     std::mutex mu;
@@ -138,7 +139,7 @@ struct InputWindow {
         std::unique_lock<std::mutex> lk(mu);
         while (!stop) {
             if (pop_next < consumed) pop_next = consumed;
-            if (pop_next < n_seg && pop_next < consumed + kAhead) {
+            if (!draining && pop_next < n_seg && pop_next < consumed + kAhead) {
                 const size_t sgm = pop_next++;
                 lk.unlock();
                 void* at = reinterpret_cast<void*>(seg_lo(sgm));
@@ -174,7 +175,7 @@ struct InputWindow {
         std::unique_lock<std::mutex> lk(mu);
         while (!stop) {
             // (never more than 2 x kAhead segments locked, however far the unlocker lags behind)
-            if (!failed && reg_hi < n_seg && reg_hi < consumed + kAhead && reg_hi < reg_lo + 2 * kAhead) {
+            if (!failed && !draining && reg_hi < n_seg && reg_hi < consumed + kAhead && reg_hi < reg_lo + 2 * kAhead) {
                 if (reg_hi < consumed) {      // the reader skipped ahead: nothing in between is wanted
                     if (reg_lo == reg_hi)     // (once the unlocker has let go of what was locked below)
                         reg_lo = reg_hi = consumed;
@@ -213,7 +214,11 @@ struct InputWindow {
         (void)hipSetDevice(device);
         std::unique_lock<std::mutex> lk(mu);
         while (!stop) {
+#ifdef THR_DEV_NO_UNLOCK   // dev A/B only: nothing is unlocked before the window closes
+            if (false) {
+#else
             if (reg_lo < std::min(consumed, reg_hi)) {
+#endif
                 const size_t sgm = reg_lo;
                 lk.unlock();
                 const double t0 = now_s();
@@ -240,7 +245,7 @@ struct InputWindow {
         t_populate = t_register = t_unregister = t_acquire = 0;
         n_acquire_waits = n_pageable = 0;
         populated.assign(n_seg, 0);
-        stop = failed = false;
+        stop = failed = draining = false;
         device = dev;
         worker = std::thread([this] { run(); });
         unlocker = std::thread([this] { unlock_run(); });
@@ -266,6 +271,18 @@ struct InputWindow {
         n_seg = 0;
     }
 
+    // The reader is done with the window: nothing more is locked, and the unlocking worker lets go of
+    // everything that still is -- in the background; close() (or the next open()) waits for it.
+    void release_all() {
+        if (!worker.joinable()) return;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            draining = true;
+            consumed = n_seg;
+        }
+        cv.notify_all();
+    }
+
     // [src, src + bytes) is about to be copied: wait until its segments are locked.  False: copy
     // it as pageable memory (outside the window, behind it, too far ahead, or locking failed).
     bool acquire(const void* src, size_t bytes) {
@@ -273,7 +290,7 @@ struct InputWindow {
         if (base == 0 || bytes == 0 || a < base || a + bytes > end) return false;
         const size_t s0 = size_t((a - base) / kSeg), s1 = size_t((a + bytes - 1 - base) / kSeg);
         std::unique_lock<std::mutex> lk(mu);
-        if (failed || s0 < reg_lo || s1 >= consumed + kAhead) {
+        if (failed || draining || s0 < reg_lo || s1 >= consumed + kAhead) {
             ++n_pageable;
             return false;
         }
@@ -377,6 +394,10 @@ struct thr_handle {
         uintptr_t win_end[kPipeDepth] = {};
     } hp;
     InputWindow win;
+    // seconds the calling thread spent per phase of the host entry points' chunks
+    // (thr_debug_pipe_times): grow staging, H2D calls, metadata, launches, D2H calls, chunks
+    double t_pipe[8] = {};
+
     // single-chunk staging of the test hooks (lazy)
     void* d_in = nullptr;
     size_t d_in_bytes = 0;
@@ -641,6 +662,7 @@ int pipe_h2d(thr_handle* h, int b, void* d_dst, const void* src, size_t bytes) {
     if (h->win.acquire(src, bytes)) {
         const uintptr_t a = reinterpret_cast<uintptr_t>(src);
         size_t done = 0;
+
         while (done < bytes) {
             const uintptr_t at = a + done;
             const uintptr_t seg_end = h->win.base + (size_t((at - h->win.base) / h->win.kSeg) + 1) * h->win.kSeg;
@@ -716,6 +738,7 @@ int pipe_records_enqueued(thr_handle* h, int b, thr_record* dst, size_t n_rec, s
                            h->stream));
     if (card)
         HIP_TRY(hipMemcpyAsync(p.h_bad + b, p.d_bad[b], sizeof(int), hipMemcpyDeviceToHost, h->stream));
+
     HIP_TRY(hipEventRecord(p.ev_done[b], h->stream));
     p.pend_dst[b] = dst;
     p.pend_n[b] = n_rec;
@@ -1136,6 +1159,15 @@ int thr_debug_correlate_geom(thr_handle* h, int* rows_lo, int* rows_hi) {
     return THR_OK;
 }
 
+int thr_debug_pipe_times(thr_handle* h, double out[8]) {
+    if (!h || !out) return fail(THR_ERR_ARG, "thr_debug_pipe_times: null argument");
+    for (int i = 0; i < 8; ++i) {
+        out[i] = h->t_pipe[i];
+        h->t_pipe[i] = 0;
+    }
+    return THR_OK;
+}
+
 int thr_debug_window_times(thr_handle* h, double out[6]) {
     if (!h || !out) return fail(THR_ERR_ARG, "thr_debug_window_times: null argument");
     std::lock_guard<std::mutex> lk(h->win.mu);
@@ -1145,6 +1177,19 @@ int thr_debug_window_times(thr_handle* h, double out[6]) {
     out[3] = h->win.t_acquire;
     out[4] = double(h->win.n_acquire_waits);
     out[5] = double(h->win.n_pageable);
+    return THR_OK;
+}
+
+int thr_input_window_release(thr_handle* h) {
+    if (!h) return fail(THR_ERR_ARG, "thr_input_window_release: null handle");
+    if (hipSetDevice(h->device) != hipSuccess) return fail(THR_ERR_DEVICE, "hipSetDevice(%d) failed", h->device);
+    if (h->hp.async_open != 0)
+        return fail(THR_ERR_STATE, "thr_input_window_release: %d submitted batch(es) not collected yet",
+                    h->hp.async_open);
+    if (h->hp.copy) (void)hipStreamSynchronize(h->hp.copy);     // no copy reads the window any more
+    for (auto& e : h->hp.win_end) e = 0;
+    for (auto& e : h->hp.win_lo) e = 0;
+    h->win.release_all();
     return THR_OK;
 }
 
@@ -1485,16 +1530,34 @@ static int chunk_samples(thr_handle* h, int b, const void* src, int format, size
     // dense blocks: nb * blk_bytes; raw stream: (nb - 1) strides + one whole block
     const size_t bytes = stride ? (nb - 1) * stride + blk_bytes : nb * blk_bytes;
     int rc;
+    double t0 = InputWindow::now_s(), t1;
+    auto lap = [&](int k) {
+        t1 = InputWindow::now_s();
+        h->t_pipe[k] += t1 - t0;
+        t0 = t1;
+    };
     if ((rc = pipe_grow(&p.d_in[b], &p.in_bytes[b], bytes)) != THR_OK) return rc;
+    lap(0);
     if ((rc = pipe_h2d(h, b, p.d_in[b], src, bytes)) != THR_OK) return rc;
+    lap(1);
     for (size_t i = 0; i < nb; ++i)
         p.h_meta[b][i] = block_idx ? (long long)block_idx[i] : (long long)(first_idx + int64_t(i));
+    lap(7);
     HIP_TRY(hipMemcpyAsync(p.d_idx[b], p.h_meta[b], nb * sizeof(long long), hipMemcpyHostToDevice, p.copy));
+    lap(2);
+    // (raw streams: hipStreamWaitEvent in here is where this thread meets the device's pace -- it
+    // returns ~0.45 ms late per 2048-block chunk whatever precedes it on either stream, whatever
+    // engine does the copy; profiles/README.md, round 5)
     if ((rc = pipe_inputs_enqueued(h, b)) != THR_OK) return rc;
+    lap(6);
     rc = run_batch(h, p.d_in[b], format, p.d_idx[b], int(nb), p.d_rec[b], nullptr, nullptr, nullptr, 0,
                    false, stride);
     if (rc != THR_OK) return rc;
-    return pipe_records_enqueued(h, b, dst, nb * size_t(h->cfg.n_templates), first, false);
+    lap(3);
+    rc = pipe_records_enqueued(h, b, dst, nb * size_t(h->cfg.n_templates), first, false);
+    lap(4);
+    h->t_pipe[5] += 1;
+    return rc;
 }
 
 static int chunk_card(thr_handle* h, int b, const char* text, size_t text_len, const int64_t* payload_off,
@@ -1514,24 +1577,38 @@ static int chunk_card(thr_handle* h, int b, const char* text, size_t text_len, c
     }
     const size_t span = size_t(hi - lo) + chars;
     int rc;
+    double t0 = InputWindow::now_s(), t1;
+    auto lap = [&](int k) {
+        t1 = InputWindow::now_s();
+        h->t_pipe[k] += t1 - t0;
+        t0 = t1;
+    };
     if ((rc = pipe_grow(reinterpret_cast<void**>(&p.d_text[b]), &p.text_bytes[b], span)) != THR_OK) return rc;
     if ((rc = pipe_grow(&p.d_in[b], &p.in_bytes[b], nb * out_bytes)) != THR_OK) return rc;
     if (!p.d_bad[b]) HIP_TRY(hipMalloc(&p.d_bad[b], sizeof(int)));
+    lap(0);
     long long* meta = p.h_meta[b];
     for (size_t i = 0; i < nb; ++i) {
         meta[i] = block_idx ? (long long)block_idx[first + i] : (long long)(first + i);
         meta[nb + i] = payload_off[first + i] - lo;
     }
+    lap(2);
     if ((rc = pipe_h2d(h, b, p.d_text[b], text + lo, span)) != THR_OK) return rc;
+    lap(1);
     HIP_TRY(hipMemcpyAsync(p.d_idx[b], meta, 2 * nb * sizeof(long long), hipMemcpyHostToDevice, p.copy));
     HIP_TRY(hipMemsetAsync(p.d_bad[b], 0, sizeof(int), p.copy));
     if ((rc = pipe_inputs_enqueued(h, b)) != THR_OK) return rc;
+    lap(2);
     HIP_TRY(thr::launch_b64_decode(p.d_text[b], p.d_idx[b] + nb, int(nb), int(out_bytes),
                                    static_cast<unsigned char*>(p.d_in[b]), p.d_bad[b], h->stream));
     rc = run_batch(h, p.d_in[b], THR_IN_U8, p.d_idx[b], int(nb), p.d_rec[b], nullptr, nullptr, nullptr,
                    0, false);
     if (rc != THR_OK) return rc;
-    return pipe_records_enqueued(h, b, dst, nb * size_t(h->cfg.n_templates), first, true);
+    lap(3);
+    rc = pipe_records_enqueued(h, b, dst, nb * size_t(h->cfg.n_templates), first, true);
+    lap(4);
+    h->t_pipe[5] += 1;
+    return rc;
 }
 
 // entry checks shared by the synchronous host entry points: device, staging, no open tickets

@@ -532,7 +532,7 @@ class Detector(object):
                 self._finish_library_loop()
                 if rec is not None and len(exc.args) > 2:
                     recs_all.append(rec[:exc.args[2]["detections"]])
-                if exc.code == _native.ERR_ARG and "base64" not in str(exc):
+                if exc.code == _native.ERR_ARG and "not valid base64" not in str(exc):
                     raise ValueError(str(exc))        # (a malformed line: what CardStream raises)
                 raise
             stats_all.append(st)
@@ -581,8 +581,12 @@ class Detector(object):
         return total, recs
 
     def _finish_library_loop(self):
+        """Nothing more is read: the window's last locked pages are let go in the background (the
+        engine keeps the mapping alive until it is closed), the output is complete NOW."""
         self._exhausted = True
-        self._more()            # (closes the input window)
+        if self._pin:
+            self._engine.input_window_release()
+            self._pin = False
 
     def write_toad(self, output_file):
         """Write the `.toad` lines of every remaining detection to `output_file` (what `thrifty
