@@ -331,8 +331,15 @@ def card_to_toad_leg(n_card):
            "cpu_blocks_per_s": n_cpu / t_cpu, "cpu_blocks": n_cpu, "cpu_cores": 1}
     with tempfile.TemporaryDirectory() as tmpd:
         card, warm, toad = (os.path.join(tmpd, x) for x in ("rx.card", "warm.card", "rx.toad"))
+        def settle(f):
+            """The file as a capture written long ago is: its pages clean in the page cache (locking
+            pages that are still under write-back is slower, and says nothing about the detector)."""
+            f.flush()
+            os.fsync(f.fileno())
+
         with open(card, "wb") as f:      # a regular file, as `thrifty detect rx.card`
             f.write(text)
+            settle(f)
         # warm-up, not timed: the first 8192 lines through the same path (a regular file: mapped,
         # input window, full-size batches), as W warm-up steps precede the timed steps of the main
         # leg -- code objects loaded, staging buffers of full size in the runtime's pool
@@ -347,7 +354,7 @@ def card_to_toad_leg(n_card):
                     # the library loop alone (thr_run_card's own clock: no Detector construction)
                     "gpu_loop_blocks_per_s": (loop["blocks"] / loop["total_s"]) if loop.get("total_s") else None,
                     "gpu_loop_stats": {k: loop.get(k) for k in ("batches", "total_s", "frame_s", "submit_s", "wait_s",
-                                                                "format_s", "write_s")},
+                                                                "format_s", "write_s", "window", "submit_phases")},
                     "gpu_includes": "a %.1f GB file in the page cache, after an untimed pass over its first 8192 "
                                     "lines; Detector construction, thr_run_card (host framing, H2D of the base64 "
                                     "text out of the page-locked input window, device decode, detection, D2H, "
@@ -368,9 +375,13 @@ def card_to_toad_leg(n_card):
             chunk = np.concatenate([seed_blocks[j][-step:] for j in range(64)]).tobytes()
             for _ in range(n_raw // 64):
                 f.write(chunk)
+            settle(f)
         run_file(rawp, lambda f: block_data.RawStream(f, n, h), os.path.join(tmpd, "warm2.toad"))
         t_raw, rstats = run_file(rawp, lambda f: block_data.RawStream(f, n, h), os.path.join(tmpd, "raw.toad"))
-        out.update({"raw_gpu_blocks_per_s": (rstats or {}).get("blocks", 0) / t_raw,
+        rloop = (rstats or {}).get("calls", [{}])[-1]
+        out.update({"raw_gpu_loop_stats": {k: rloop.get(k) for k in ("batches", "total_s", "frame_s", "submit_s", "wait_s",
+                                                                     "format_s", "write_s", "window", "submit_phases")},
+                    "raw_gpu_blocks_per_s": (rstats or {}).get("blocks", 0) / t_raw,
                     "raw_gpu_blocks": (rstats or {}).get("blocks", 0),
                     "raw_detections_gpu": (rstats or {}).get("detections", 0)})
     return out

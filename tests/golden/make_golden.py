@@ -34,6 +34,14 @@ from thrifty_amd import synth  # noqa: E402  (input generator only)
 
 SEED0 = 20260928
 
+# what save() writes into every fixture (tests/test_oracle_golden.py checks the committed files
+# against this list; `small` adds the .card round trip)
+KEYS = ["block_len", "history_len", "carrier_thresh", "carrier_window", "corr_thresh", "template", "rxid",
+        "blocks", "block_idx", "toad", "versions",
+        "carrier_det", "det", "cbin", "coff", "cenergy", "cnoise", "sample", "soff", "energy", "noise", "soa",
+        "sum_mag2", "nbhd", "xhat_energy", "corr3", "index_error"]
+EXTRA_KEYS = {"small": ["card_text", "card_toad"]}
+
 
 def run_reference(settings, blocks_u8, block_idx, rxid=0):
     det = Detector(settings, None, rxid=rxid, yield_data=True)
@@ -100,6 +108,7 @@ def save(name, settings, blocks_u8, block_idx, extra=None, rxid=0):
     meta.update(out)
     if extra:
         meta.update(extra)
+    assert sorted(meta) == sorted(KEYS + EXTRA_KEYS.get(name, [])), sorted(meta)
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **meta)
     print("%-18s blocks=%d carrier=%d det=%d  %.0f KiB" % (

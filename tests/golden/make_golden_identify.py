@@ -73,6 +73,12 @@ def as_objects(rows):
     return out
 
 
+# what save() writes (tests/test_oracle_golden.py): the columns, plus the automatic windows or the map
+KEYS = ["rxid", "timestamp", "block", "carrier_bin", "carrier_offset", "energy", "txid", "dup_mask", "kept_order"]
+KEYS_AUTO = ["edge_rx", "edge_ptr", "edges"]
+KEYS_MAP = ["map_rx", "map_tx", "map_lo", "map_hi"]
+
+
 def save(name, rows, freqmap):
     dets = as_objects(rows)
     out = {}
@@ -97,6 +103,7 @@ def save(name, rows, freqmap):
     kept = identify.filter_duplicates(dets)
     index_of = {id(d): i for i, d in enumerate(dets)}
     cols = np.array(rows, dtype=float)
+    assert sorted(out) == sorted(KEYS_AUTO if freqmap is None else KEYS_MAP)
     np.savez_compressed(os.path.join(HERE, name + ".npz"),
                         rxid=cols[:, 0].astype(np.int64), timestamp=cols[:, 1],
                         block=cols[:, 2].astype(np.int64), carrier_bin=cols[:, 3].astype(np.int64),

@@ -26,6 +26,17 @@ from thrifty.experimental.detect_preshift import PreshiftDetector  # noqa: E402
 from thrifty.signal_utils import Signal  # noqa: E402
 
 
+# what run() writes (tests/test_oracle_golden.py checks the committed files against these lists):
+# every fixture KEYS; those of the default interpolator carry their input blocks, the others name
+# the fixture whose blocks they share
+KEYS = ["block_len", "history_len", "carrier_thresh", "carrier_window", "corr_thresh", "template", "rxid", "num",
+        "interpolator", "block_idx", "toad", "versions",
+        "carrier_det", "det", "cbin", "coff", "cenergy", "cnoise", "sample", "soff", "energy", "noise", "soa",
+        "frac_shift", "index_error"]
+KEYS_OWN_BLOCKS = ["blocks"]
+KEYS_SHARED_BLOCKS = ["src"]
+
+
 def run(src_name, out_name, num, take=None, interpolator="parabolic"):
     g = np.load(os.path.join(HERE, src_name + ".npz"))
     st = DetectorSettings(int(g["block_len"]), int(g["history_len"]), len(g["template"]),
@@ -82,6 +93,7 @@ def run(src_name, out_name, num, take=None, interpolator="parabolic"):
         assert take is None
         del meta["blocks"]
         meta["src"] = src_name
+    assert sorted(meta) == sorted(KEYS + (KEYS_OWN_BLOCKS if interpolator == "parabolic" else KEYS_SHARED_BLOCKS))
     path = os.path.join(HERE, out_name + ".npz")
     np.savez_compressed(path, **meta)
     print("%-22s blocks=%d carrier=%d det=%d index_error=%d  %.0f KiB" % (

@@ -6,6 +6,8 @@
     test_carrier_sync.py:12-65, test_soa_estimator.py:13-109,
     test_block_data.py:13-37, test_util.py:11-16).
 """
+import os
+
 import numpy as np
 import pytest
 import scipy.signal
@@ -233,3 +235,42 @@ def test_identify_oracle_matches_reference(golden, name):
     mask = onp.duplicate_mask(g["rxid"], txid, g["block"], g["timestamp"], g["energy"])
     assert np.array_equal(mask, g["dup_mask"])
     assert np.array_equal(onp.filter_order(mask, g["timestamp"]), g["kept_order"])
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _declared(generator, names):
+    """Module-level list / dict literals of a fixture generator, read with `ast` -- the generators
+    import the reference at import time, which exists in the build container only."""
+    import ast
+    tree = ast.parse(open(os.path.join(GOLDEN_DIR, generator)).read())
+    out = {}
+    for node in tree.body:
+        if isinstance(node, ast.Assign) and len(node.targets) == 1 and getattr(node.targets[0], "id", None) in names:
+            out[node.targets[0].id] = ast.literal_eval(node.value)
+    assert set(out) == set(names), (generator, sorted(out))
+    return out
+
+
+def test_every_fixture_holds_exactly_the_keys_its_generator_writes():
+    """A fixture that predates a change of its generator (a key added, renamed, dropped) would
+    still load -- and a test reading the new key would fail only where it runs.  Every committed
+    .npz must carry exactly the key set its generator declares (and asserts when it writes)."""
+    import glob
+    det = _declared("make_golden.py", ["KEYS", "EXTRA_KEYS"])
+    pre = _declared("make_golden_preshift.py", ["KEYS", "KEYS_OWN_BLOCKS", "KEYS_SHARED_BLOCKS"])
+    ide = _declared("make_golden_identify.py", ["KEYS", "KEYS_AUTO", "KEYS_MAP"])
+    seen = 0
+    for path in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))):
+        name = os.path.basename(path)[:-4]
+        have = sorted(np.load(path, allow_pickle=False).files)
+        if name.startswith("preshift_"):
+            shared = "src" in have
+            want = pre["KEYS"] + (pre["KEYS_SHARED_BLOCKS"] if shared else pre["KEYS_OWN_BLOCKS"])
+        elif name.startswith("identify_"):
+            want = ide["KEYS"] + (ide["KEYS_MAP"] if name == "identify_map" else ide["KEYS_AUTO"])
+        else:
+            want = det["KEYS"] + det["EXTRA_KEYS"].get(name, [])
+        assert have == sorted(want), (name, sorted(set(have) ^ set(want)))
+        seen += 1
+    assert seen >= 24

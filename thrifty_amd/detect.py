@@ -535,6 +535,8 @@ class Detector(object):
                 if exc.code == _native.ERR_ARG and "not valid base64" not in str(exc):
                     raise ValueError(str(exc))        # (a malformed line: what CardStream raises)
                 raise
+            # (where the input window's threads and the chunk submissions spent their time)
+            st["window"], st["submit_phases"] = eng.debug_window_times(), eng.debug_pipe_times()
             stats_all.append(st)
             if rec is not None:
                 recs_all.append(rec[:st["detections"]])
