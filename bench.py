@@ -118,7 +118,7 @@ def parse_args():
                          "0: skip the leg)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0,
                     help="wall budget of the single-core CPU baseline leg (0 disables every CPU leg)")
-    ap.add_argument("--card-blocks", type=int, default=65536,
+    ap.add_argument("--card-blocks", type=int, default=131072,
                     help="blocks of the config-#1 .card -> .toad plumbing leg (0 skips it)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl: RCCL, one GPU per rank (the real thing); gloo: every rank on cuda:0, "
@@ -300,11 +300,14 @@ def card_to_toad_leg(n_card):
     ook = (tpl - tpl.min()) / (tpl.max() - tpl.min()) * 2 - 1     # synth draws 0.3 * (t + 1) / 2
     seed_blocks, _ = synth.synth_blocks(rng, 64, n, ook, onp.unique_window(n, h, len(tpl)))
     payload = [block_data.card_line(0.0, 0, seed_blocks[j]).split(" ", 2)[2] for j in range(64)]
-    text = "".join("%.6f %d %s" % (1000.0 + 0.005 * i, i, payload[i % 64]) for i in range(n_card)).encode()
+
+    def card_lines(lo, hi):
+        return "".join("%.6f %d %s" % (1000.0 + 0.005 * i, i, payload[i % 64]) for i in range(lo, hi)).encode()
+
     # --- CPU: one core, the reference's per-line loop
     orc = onp.OracleDetector(n, h, tpl, cthr, cwin, xthr)
     n_cpu = min(n_card, 256)
-    lines = text.split(b"\n")[:n_cpu]
+    lines = card_lines(0, n_cpu).split(b"\n")[:n_cpu]
     t0 = time.perf_counter()
     cpu_out = []
     for ln in lines:
@@ -322,31 +325,37 @@ def card_to_toad_leg(n_card):
         with open(path, "rb") as f, open(out_path, "wb") as out:
             t0 = time.perf_counter()      # (opening the reader and the engine handle is part of the job)
             det = Detector(st, reader(f), rxid=0)
+            t1 = time.perf_counter()
             stats = det.write_toad(out)
             out.flush()
-            return time.perf_counter() - t0, stats
+            dt = time.perf_counter() - t0
+            det.close()     # (now, not at garbage collection: the next Detector reuses the runtime's pools)
+            if stats is not None:
+                stats["construct_s"], stats["write_toad_s"] = t1 - t0, dt - (t1 - t0)
+            return dt, stats
 
     out = {"config": "BASELINE configs[0]: example detector.cfg settings (block 16384, history %d, %d-sample "
                      "template, window bins %d..%d) on a synthetic .card stream" % (h, len(tpl), cwin[0], cwin[1]),
            "cpu_blocks_per_s": n_cpu / t_cpu, "cpu_blocks": n_cpu, "cpu_cores": 1}
     with tempfile.TemporaryDirectory() as tmpd:
-        card, warm, toad = (os.path.join(tmpd, x) for x in ("rx.card", "warm.card", "rx.toad"))
+        card, toad = (os.path.join(tmpd, x) for x in ("rx.card", "rx.toad"))
         def settle(f):
             """The file as a capture written long ago is: its pages clean in the page cache (locking
             pages that are still under write-back is slower, and says nothing about the detector)."""
             f.flush()
             os.fsync(f.fileno())
 
+        text_bytes = 0
         with open(card, "wb") as f:      # a regular file, as `thrifty detect rx.card`
-            f.write(text)
+            for lo in range(0, n_card, 4096):
+                text_bytes += f.write(card_lines(lo, min(n_card, lo + 4096)))
             settle(f)
-        # warm-up, not timed: the first 8192 lines through the same path (a regular file: mapped,
-        # input window, full-size batches), as W warm-up steps precede the timed steps of the main
-        # leg -- code objects loaded, staging buffers of full size in the runtime's pool
-        n_warm = min(8192, n_card)
-        with open(warm, "wb") as f:
-            f.write(b"\n".join(text.split(b"\n", n_warm)[:n_warm]) + b"\n")
-        run_file(warm, lambda f: block_data.CardStream(f, n), os.path.join(tmpd, "warm.toad"))
+        # warm-up, not timed: one pass of the same job, as W warm-up steps precede the timed steps of
+        # the main leg.  (A whole pass, not a few batches: the HIP runtime keeps growing its pools for
+        # the first ~30 batches of a process -- 8-15 ms stalls in the first copies of records out of
+        # each pipeline slot; a pass over a DIFFERENT, never-read file in a warm process runs at the
+        # rate of the second pass over this one, profiles/README.md round 5.)
+        run_file(card, lambda f: block_data.CardStream(f, n), os.path.join(tmpd, "warm.toad"))
         t_gpu, stats = run_file(card, lambda f: block_data.CardStream(f, n), toad)
         gpu_out = open(toad, "rb").read().decode("ascii").split("\n")[:-1]   # (for the check below, not timed)
         loop = (stats or {}).get("calls", [{}])[-1]
@@ -355,11 +364,12 @@ def card_to_toad_leg(n_card):
                     "gpu_loop_blocks_per_s": (loop["blocks"] / loop["total_s"]) if loop.get("total_s") else None,
                     "gpu_loop_stats": {k: loop.get(k) for k in ("batches", "total_s", "frame_s", "submit_s", "wait_s",
                                                                 "format_s", "write_s", "window", "submit_phases")},
-                    "gpu_includes": "a %.1f GB file in the page cache, after an untimed pass over its first 8192 "
-                                    "lines; Detector construction, thr_run_card (host framing, H2D of the base64 "
+                    "gpu_construct_s": (stats or {}).get("construct_s"),
+                    "gpu_includes": "a %.1f GB file in the page cache, after one untimed pass of the same job; "
+                                    "Detector construction, thr_run_card (host framing, H2D of the base64 "
                                     "text out of the page-locked input window, device decode, detection, D2H, "
                                     ".toad text formatted and written by a library thread), file on disk"
-                                    % (len(text) / 1e9),
+                                    % (text_bytes / 1e9),
                     "detections_cpu": len(cpu_out), "detections_gpu": len(gpu_out)})
         same = [a.split()[:3] + [a.split()[4], a.split()[8]] for a in gpu_out[:len(cpu_out)]] == \
                [b.split()[:3] + [b.split()[4], b.split()[8]] for b in cpu_out]
@@ -367,7 +377,6 @@ def card_to_toad_leg(n_card):
         # --- the raw form of the same stream (`thrifty detect --raw`): the blocks' NEW samples back to
         # back, overlap framing on the device (thr_run_stream); the reference's zero-history lead-in
         # goes through the complex64 path first
-        del text
         step = 2 * (n - h)
         rawp = os.path.join(tmpd, "rx.bin")
         n_raw = n_card

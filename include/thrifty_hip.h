@@ -501,8 +501,9 @@ int thr_debug_window_times(thr_handle* h, double out[6]);
  *   points since the last call (reads and resets): out[0] growing staging buffers, out[1] the input's
  *   host-to-device copy calls, out[2] block indices / offsets, out[3] kernel launches, out[4] the
  *   records' device-to-host calls; out[5] = chunks; out[6] event record / wait between the copy and
- *   the main stream, out[7] filling the index array (sample chunks). */
-int thr_debug_pipe_times(thr_handle* h, double out[8]);
+ *   the main stream, out[7] filling the index array (sample chunks); out[8 + k] = the longest single
+ *   occurrence of phase k. */
+int thr_debug_pipe_times(thr_handle* h, double out[16]);
 int thr_debug_fft(thr_handle* h, const void* samples, int format, size_t n_blocks,
                   float* spectra_out /* [n_blocks][block_len][2] */);
 int thr_debug_stage(thr_handle* h, const void* samples, int format, size_t n_blocks,

@@ -19,35 +19,49 @@ from thrifty_amd import block_data, synth
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 kind = sys.argv[2] if len(sys.argv) > 2 else "card"
+if len(sys.argv) > 3 and sys.argv[3] == "torch":      # the process bench.py's legs run in: torch owns streams too
+    import torch
+    x = torch.zeros(1 << 20, device="cuda")
+    torch.cuda.synchronize()
+    print("torch %s initialised on %s" % (torch.__version__, torch.cuda.get_device_name(0)))
 g = np.load(os.path.join(ROOT, "tests", "golden", "c1.npz"))
 n, h, tpl = int(g["block_len"]), int(g["history_len"]), g["template"]
 ook = (tpl - tpl.min()) / (tpl.max() - tpl.min()) * 2 - 1
 pad = h - len(tpl) + 1
 rng = np.random.default_rng(0)
 seed, _ = synth.synth_blocks(rng, 64, n, ook, (pad // 2, n - len(tpl) + 1 - (pad - pad // 2)))
-tmp = tempfile.NamedTemporaryFile(suffix="." + kind, delete=False)
-if kind == "card":
-    lines = [block_data.card_line(0.0, 0, seed[j]).split(" ", 2)[2] for j in range(64)]
-    for s in range(0, nb, 4096):
-        tmp.write("".join("%.6f %d %s" % (1000.0 + 0.005 * i, i, lines[i % 64]) for i in range(s, min(nb, s + 4096))).encode())
-else:
-    step = 2 * (n - h)
-    chunk = np.concatenate([seed[j][-step:] for j in range(64)]).tobytes()
-    for _ in range(nb // 64):
-        tmp.write(chunk)
-tmp.close()
-size = os.path.getsize(tmp.name)
-print("%s file: %d blocks, %.2f GB" % (kind, nb, size / 1e9))
+def make_file(count):
+    tmp = tempfile.NamedTemporaryFile(suffix="." + kind, delete=False)
+    if kind == "card":
+        lines = [block_data.card_line(0.0, 0, seed[j]).split(" ", 2)[2] for j in range(64)]
+        for s0 in range(0, count, 4096):
+            tmp.write("".join("%.6f %d %s" % (1000.0 + 0.005 * i, i, lines[i % 64])
+                              for i in range(s0, min(count, s0 + 4096))).encode())
+    else:
+        step = 2 * (n - h)
+        chunk = np.concatenate([seed[j][-step:] for j in range(64)]).tobytes()
+        for _ in range(count // 64):
+            tmp.write(chunk)
+    tmp.flush()
+    os.fsync(tmp.fileno())
+    tmp.close()
+    print("%s file %s: %d blocks, %.2f GB" % (kind, tmp.name, count, os.path.getsize(tmp.name) / 1e9))
+    return tmp.name
+
+
+file_a, file_b = make_file(nb), make_file(2 * nb)
 thr = tuple(float(v) for v in g["carrier_thresh"])
 win = tuple(int(v) for v in g["carrier_window"])
 out_fd = os.open(os.devnull, os.O_WRONLY)
 
 
-def run(batch, pop, seg, window=True):
+def run(batch, pop, seg, window=True, path=None):
+    path = path or file_a
+    size = os.path.getsize(path)
     t_c = time.perf_counter()
     eng = F.Engine(n, h, tpl, thr, win, tuple(float(v) for v in g["corr_thresh"]), max_batch=batch)
     t_c = time.perf_counter() - t_c
-    with open(tmp.name, "rb") as f:
+    with open(path, "rb") as f:
         mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
         view = memoryview(mm)
         t0 = time.perf_counter()
@@ -74,16 +88,14 @@ def run(batch, pop, seg, window=True):
               wt.get("populate_s", 0), wt.get("register_s", 0), wt.get("unregister_s", 0), wt.get("acquire_wait_s", 0),
               wt.get("acquire_waits", 0), wt.get("pageable_copies", 0),
               *[pt[k] * 1e3 / max(1, pt["chunks"]) for k in ("grow_s", "h2d_s", "meta_s", "launch_s", "d2h_s", "event_s", "fill_s")]))
+    print("      longest single call ms: " + " ".join("%s %.2f" % (k[4:-2], pt[k] * 1e3) for k in sorted(pt) if k.startswith("max_")))
 
 
-run(2048, 3, 128 << 20)     # warm-up (code objects, staging pools)
-for rep in range(3):
-    run(2048, 3, 128 << 20)
-run(1024, 3, 128 << 20)
-for pop in (1, 2):
-    run(2048, pop, 128 << 20)
-for seg in (32 << 20, 256 << 20):
-    run(2048, 3, seg)
-run(4096, 3, 128 << 20)
-run(2048, 3, 128 << 20, window=False)
-os.unlink(tmp.name)
+print("-- A, A, then B (twice as long, never read before), B, A")
+run(2048, 3, 128 << 20)
+run(2048, 3, 128 << 20)
+run(2048, 3, 128 << 20, path=file_b)
+run(2048, 3, 128 << 20, path=file_b)
+run(2048, 3, 128 << 20)
+os.unlink(file_a)
+os.unlink(file_b)

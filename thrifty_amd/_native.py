@@ -576,11 +576,13 @@ class Engine(object):
 
     def debug_pipe_times(self):
         """thr_debug_pipe_times -> seconds per phase of the host entry points' chunks (reads and resets)."""
-        out = (C.c_double * 8)()
-        self._lib.thr_debug_pipe_times.argtypes = [C.c_void_p, C.c_double * 8]
+        out = (C.c_double * 16)()
+        self._lib.thr_debug_pipe_times.argtypes = [C.c_void_p, C.c_double * 16]
         _check(self._lib, self._lib.thr_debug_pipe_times(self._h, out))
-        return dict(zip(("grow_s", "h2d_s", "meta_s", "launch_s", "d2h_s", "chunks", "event_s", "fill_s"),
-                        (float(v) for v in out)))
+        keys = ("grow_s", "h2d_s", "meta_s", "launch_s", "d2h_s", "chunks", "event_s", "fill_s")
+        res = dict(zip(keys, (float(v) for v in out[:8])))
+        res.update(("max_" + k, float(v)) for k, v in zip(keys, out[8:]) if k != "chunks")
+        return res
 
     def debug_window_times(self):
         """thr_debug_window_times -> dict of seconds per activity of the input window's threads."""

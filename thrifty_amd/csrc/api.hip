@@ -397,6 +397,7 @@ struct thr_handle {
     // seconds the calling thread spent per phase of the host entry points' chunks
     // (thr_debug_pipe_times): grow staging, H2D calls, metadata, launches, D2H calls, chunks
     double t_pipe[8] = {};
+    double t_pipe_max[8] = {};   // the longest single occurrence of each phase
 
     // single-chunk staging of the test hooks (lazy)
     void* d_in = nullptr;
@@ -1159,11 +1160,12 @@ int thr_debug_correlate_geom(thr_handle* h, int* rows_lo, int* rows_hi) {
     return THR_OK;
 }
 
-int thr_debug_pipe_times(thr_handle* h, double out[8]) {
+int thr_debug_pipe_times(thr_handle* h, double out[16]) {
     if (!h || !out) return fail(THR_ERR_ARG, "thr_debug_pipe_times: null argument");
     for (int i = 0; i < 8; ++i) {
         out[i] = h->t_pipe[i];
-        h->t_pipe[i] = 0;
+        out[8 + i] = h->t_pipe_max[i];
+        h->t_pipe[i] = h->t_pipe_max[i] = 0;
     }
     return THR_OK;
 }
@@ -1534,6 +1536,7 @@ static int chunk_samples(thr_handle* h, int b, const void* src, int format, size
     auto lap = [&](int k) {
         t1 = InputWindow::now_s();
         h->t_pipe[k] += t1 - t0;
+        h->t_pipe_max[k] = std::max(h->t_pipe_max[k], t1 - t0);
         t0 = t1;
     };
     if ((rc = pipe_grow(&p.d_in[b], &p.in_bytes[b], bytes)) != THR_OK) return rc;
@@ -1581,6 +1584,7 @@ static int chunk_card(thr_handle* h, int b, const char* text, size_t text_len, c
     auto lap = [&](int k) {
         t1 = InputWindow::now_s();
         h->t_pipe[k] += t1 - t0;
+        h->t_pipe_max[k] = std::max(h->t_pipe_max[k], t1 - t0);
         t0 = t1;
     };
     if ((rc = pipe_grow(reinterpret_cast<void**>(&p.d_text[b]), &p.text_bytes[b], span)) != THR_OK) return rc;

@@ -657,6 +657,21 @@ class Detector(object):
     def __call__(self, timestamp, block_idx, block):
         self.detect(timestamp, block_idx, block)
 
+    def close(self):
+        """Release the engine handle (device buffers, streams, the input window) now instead of at
+        garbage collection -- the detector's stage objects refer back to it, so plain reference
+        counting does not free it.  Also the exit of `with Detector(...) as det:`."""
+        self._drop_ahead()
+        self._exhausted = True
+        self._engine.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     def __iter__(self):
         return self
 
