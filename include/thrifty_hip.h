@@ -52,6 +52,10 @@ extern "C" {
 #define THR_FLAG_INDEX_ERROR 4u  /* reference raises IndexError here: carrier bin
                                     + 3 >= block_len (carrier_sync.py:187)         */
 
+#define THR_FLAG_INT_OFFSET 8u   /* PreshiftDetector, cosine interpolator: the reference returned the
+                                    Python int 0 (cos(omega) > 1, carrier_interpolators.py:87-88), so
+                                    carrier_offset is 0 and prints as "0", not "0.0"                  */
+
 /* input sample formats for thr_detect*() */
 #define THR_IN_U8 0   /* interleaved unsigned 8-bit I,Q (RTL-SDR; block_data.py:38-52) */
 #define THR_IN_C64 1  /* interleaved float32 re,im (a `Signal` already converted)     */
@@ -216,6 +220,24 @@ int thr_detect(thr_handle* h, const void* samples, int format, const int64_t* bl
                size_t n_blocks, thr_record* out);
 
 /*
+ * thr_detect() with the sub-bin carrier offsets GIVEN -- replaces `Synchronizer.sync` with a replaced
+ * `interpolator` (carrier_sync.py:52-76: `offset = self.interpolator(fft_mag, peak_idx)`, then the
+ * shift by -(peak_idx + offset)): what the reference's InterpolationDetector
+ * (thrifty/experimental/detect_carrier_interpol.py:17-40) does with any function of
+ * thrifty/experimental/carrier_interpolators.py:17-81.  The caller has run the carrier stage once
+ * (thr_detect + thr_debug_fft give it the peak bin and |FFT#1|), evaluated its interpolator on the
+ * host and hands the results back: block i is shifted by -(its carrier bin + carrier_offset[i])
+ * instead of by the Dirichlet fit; everything downstream (FFT#2, correlation, SoA) is unchanged and
+ * the record carries carrier_offset[i].  Entries of blocks without a carrier are ignored.  The
+ * reference's IndexError rule belongs to ITS interpolator (carrier_sync.py:187) and is not applied:
+ * THR_FLAG_INDEX_ERROR is never set here.  One batch (n_blocks <= max_batch), host pointers,
+ * synchronous, the default detector only.  A slow path by design (two passes over the block and a
+ * host round trip per batch) -- for analysis scripts, not for throughput.
+ */
+int thr_detect_offsets(thr_handle* h, const void* samples, int format, const int64_t* block_idx,
+                       size_t n_blocks, const double* carrier_offset, thr_record* out);
+
+/*
  * .card form (ingest on the device).  `text` holds .card records
  * "<timestamp> <block_idx> <base64 of 2*block_len bytes>" (block_data.py:120-131;
  * fastcard_cli.c:187-192); `payload_off[i]` is the byte offset of the i-th block's base64
@@ -376,7 +398,8 @@ int thr_poll(thr_handle* h, uint64_t ticket, int* done);
  * ids like serialize() does for values that are not None (txid = the record's template_id:
  * multi-template detection); carrier_offset_f32: 1 = round the carrier offset to float32 first
  * (PreshiftDetector's np.float32 offset), 2 = print it as an integer (its interpolator `none`
- * returns the int 0).  `out_capacity` must be >= n * THR_TOAD_LINE_MAX.
+ * returns the int 0); a record flagged THR_FLAG_INT_OFFSET prints it as an integer whatever the mode.
+ * `out_capacity` must be >= n * THR_TOAD_LINE_MAX.
  * Host only, no device, handle-free.
  */
 #define THR_TOAD_LINE_MAX 384

@@ -239,7 +239,12 @@ class OracleDetector(object):
     running the reference once per template yields)."""
 
     def __init__(self, block_len, history_len, templates, carrier_thresh,
-                 carrier_window, corr_thresh, carrier_len=None):
+                 carrier_window, corr_thresh, carrier_len=None, interpolator="dirichlet"):
+        """interpolator: "dirichlet" (the default Synchronizer's, carrier_sync.py:150-196), None (no
+        sub-bin estimate, carrier_sync.py:66-68) or a callable (mag, peak_idx) -> offset -- what the
+        reference's InterpolationDetector assigns to `sync.interpolator`
+        (experimental/detect_carrier_interpol.py:17-40)."""
+        self.interpolator = interpolator
         if isinstance(templates, np.ndarray) and templates.ndim == 1:
             templates = [templates]
         self.block_len = block_len
@@ -259,8 +264,13 @@ class OracleDetector(object):
         off = 0
         xhat = None
         if det:
-            _, off = dirichlet_fit(mag, idx, self.block_len, self.carrier_len)
-            xhat = shift_and_fft(x, -(idx + off))
+            if self.interpolator == "dirichlet":
+                _, off = dirichlet_fit(mag, idx, self.block_len, self.carrier_len)
+            elif self.interpolator is not None:
+                off = self.interpolator(mag, idx)
+            # (the reference's peak_idx is a NumPy int64 -- np.argmax + start, carrier_detect.py:138-154 --
+            # so a float32 offset is widened: int64 + float32 -> float64, carrier_sync.py:71)
+            xhat = shift_and_fft(x, -(np.int64(idx) + off))
         return CarrierStage(det, idx, off, peak, noise, thr), xhat, mag
 
     def detect_block(self, block_idx, x, want_data=False):
@@ -322,6 +332,33 @@ def cosine_offset(mag, peak_idx):
 
 CARRIER_INTERPOLATORS = {"parabolic": parabolic_offset, "none": no_offset,
                          "gaussian": gaussian_offset, "cosine": cosine_offset}
+
+
+def parabole_fit_offset(width):
+    """experimental/carrier_interpolators.py:61-70: vertex of the least-squares parabola through
+    the width + 1 magnitudes around the peak."""
+    def interpolate(mag, peak_idx):
+        x = np.arange(-(width // 2), width // 2 + 1)
+        coeffs = np.polyfit(x, mag[peak_idx + x], 2)
+        return -coeffs[1] / coeffs[0] / 2
+    return interpolate
+
+
+def corr_parabolic_offset(corr_width, block_len, carrier_len):
+    """experimental/carrier_interpolators.py:73-81: the three-point parabola on the magnitudes
+    correlated with the Dirichlet kernel (its own kernel: no absolute value, 1 at x = 0, :7-14)."""
+    rel = np.arange(-(corr_width // 2), corr_width // 2 + 1)
+    xr = np.array(rel, dtype=np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        kern = np.sin(np.pi * carrier_len * xr / block_len) / np.sin(np.pi * xr / block_len) / carrier_len
+        kern[np.isnan(kern)] = 1
+
+    def interpolate(mag, peak_idx):
+        a = np.sum(mag[peak_idx + rel - 1] * kern)
+        b = np.sum(mag[peak_idx + rel] * kern)
+        c = np.sum(mag[peak_idx + rel + 1] * kern)
+        return (c - a) / (4 * b - 2 * a - 2 * c)
+    return interpolate
 
 
 class PreshiftBank(object):

@@ -152,6 +152,60 @@ def test_detector_class_serialises_like_the_reference(golden, name):
         F.Engine(16384, 4096, np.ones((2, 100)), (0, 15, 0), (7, 110), (0, 15, 0), preshift_num=21)
 
 
+def test_cosine_interpolator_returns_the_int_zero_where_the_reference_does():
+    """carrier_interpolators.py:84-92: `if cos_omega > 1: return 0` -- an int, so that block's
+    carrier-offset column reads "0" (not "0.0") and CarrierSyncInfo.offset is the int 0.  It takes
+    a neighbour larger than the windowed peak: a carrier just BELOW the window's first bin puts the
+    window's maximum on that bin with the stronger bin outside."""
+    from thrifty_amd.experimental import carrier_interpolators
+    n, h = 16384, 4096
+    tpl = synth.gold_template(10, 2)
+    win = onp.unique_window(n, h, len(tpl))
+    rng = np.random.default_rng(77)
+    # a continuous carrier at bin 6.15 .. 6.32 under the burst, the window starting at 7: the window's
+    # maximum is bin 7 with |X[6]| well above it -- cos(omega) = 1.25 .. 3.4; at 6.41 / 6.45 it is
+    # 0.74 .. 0.87 and the formula applies.  (A burst alone has a main lobe 16 bins wide: its three
+    # magnitudes are nearly equal and cos(omega) sits within rounding of 1.)
+    cars = [6.15, 6.19, 6.24, 6.28, 6.32, 6.41, 6.45] * 2
+    blocks = []
+    for car in cars:
+        p = int(rng.integers(win[0], win[1]))
+        z = rng.normal(0, 0.02, n) + 1j * rng.normal(0, 0.02, n)
+        z += 0.08 * np.exp(2j * np.pi * car * np.arange(n) / n)
+        k = np.arange(len(tpl))
+        z[p:p + len(tpl)] += 0.3 * (tpl + 1) / 2 * np.exp(2j * np.pi * car * (k + p) / n)
+        blocks.append(synth.quantise_iq(z))
+    blocks = np.stack(blocks)
+    st = DetectorSettings(n, h, len(tpl), (0, 15, 0), (7, 110), tpl, (0, 15, 0))
+    items = [(1000.0 + i, i, blocks[i]) for i in range(len(blocks))]
+    det = PreshiftDetector(st, items, rxid=0, num=21, batch_size=5, interpolator=carrier_interpolators.cosine)
+    got = list(det)
+    orc = onp.OraclePreshiftDetector(n, h, tpl, (0, 15, 0), (7, 110), (0, 15, 0), num=21, interpolator="cosine")
+    ints = 0
+    for i, (detected, res) in enumerate(got):
+        want = orc.detect_u8(i, blocks[i])
+        assert res.carrier_info.bin == want.carrier.bin and (res.corr_info is not None) == want.carrier.detected
+        if not want.carrier.detected:
+            continue
+        if isinstance(want.carrier.offset, int):       # the reference's `return 0`
+            ints += 1
+            assert res.carrier_info.offset == 0 and isinstance(res.carrier_info.offset, int)
+            assert detected == want.detected
+            if detected:
+                assert res.serialize().split()[9] == "0" == onp.toad_line(0, 1000.0 + i, i, want).split()[9]
+        else:
+            assert isinstance(res.carrier_info.offset, np.floating)
+    assert ints == 10
+    # the library's own formatter (thr_format_toad) and the column formatter print the same text
+    det2 = PreshiftDetector(st, items, rxid=0, num=21, batch_size=5, interpolator="cosine")
+    lines = [ln for chunk in det2.iter_toad_lines() for ln in chunk]
+    assert lines == [res.serialize() for detected, res in got if detected]
+    from thrifty_amd import toads_data
+    det3 = PreshiftDetector(st, items, rxid=0, num=21, batch_size=50, interpolator="cosine")
+    for stamps, recs in det3.iter_detected_records():
+        assert toads_data.toad_lines(recs, stamps, n - h, rxid=0, carrier_offset_type=np.float32) == lines
+
+
 def test_index_error_is_raised_like_the_reference(golden):
     g = golden("preshift_c2_straddle")
     st = DetectorSettings(int(g["block_len"]), int(g["history_len"]), len(g["template"]),

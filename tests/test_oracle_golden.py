@@ -14,6 +14,8 @@ import scipy.signal
 
 from oracle import thrifty_np as onp
 
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
 FIXTURES = ["c2", "c2_negwin", "c2_straddle", "c2_stddev", "c2_fullwin",
             "c5_tx0", "c5_tx3", "c1", "c3", "small"]
 
@@ -236,7 +238,36 @@ def test_identify_oracle_matches_reference(golden, name):
     assert np.array_equal(mask, g["dup_mask"])
     assert np.array_equal(onp.filter_order(mask, g["timestamp"]), g["kept_order"])
 
-GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+INTERPOL = {"none": lambda n, w: onp.no_offset, "parabolic": lambda n, w: onp.parabolic_offset,
+            "gaussian": lambda n, w: onp.gaussian_offset, "cosine": lambda n, w: onp.cosine_offset,
+            "parabole_fit6": lambda n, w: onp.parabole_fit_offset(6),
+            "corr_parabolic4": lambda n, w: onp.corr_parabolic_offset(4, n, w)}
+
+
+@pytest.mark.parametrize("method", sorted(INTERPOL))
+def test_replaced_interpolator_reproduces_the_references_interpolation_detector(method):
+    """`sync.interpolator = fn` (reference experimental/detect_carrier_interpol.py:17-40): the oracle
+    with the same interpolator reproduces the reference's `.toad` text byte for byte, and the type
+    of the offset (none() and cosine's early return hand back the Python int 0)."""
+    g = np.load(os.path.join(GOLDEN_DIR, "interpol_c2_%s.npz" % method), allow_pickle=False)
+    src = np.load(os.path.join(GOLDEN_DIR, str(g["src"]) + ".npz"), allow_pickle=False)
+    n, w = int(src["block_len"]), len(src["template"])
+    orc = onp.OracleDetector(n, int(src["history_len"]), src["template"], tuple(src["carrier_thresh"]),
+                             tuple(int(v) for v in src["carrier_window"]), tuple(src["corr_thresh"]),
+                             interpolator=INTERPOL[method](n, w))
+    lines = []
+    for i, raw in enumerate(src["blocks"]):
+        (res,) = orc.detect_u8(int(src["block_idx"][i]), raw)
+        assert res.carrier.bin == g["cbin"][i] and res.carrier.detected == g["carrier_det"][i]
+        assert res.detected == g["det"][i]
+        if res.carrier.detected:
+            assert isinstance(res.carrier.offset, int) == bool(g["coff_is_int"][i])
+            assert res.carrier.offset == g["coff"][i] and res.corr.sample == g["sample"][i]
+        if res.detected:
+            lines.append(onp.toad_line(int(src["rxid"]), 1000.0 + i, int(src["block_idx"][i]), res))
+    assert "\n".join(lines) == str(g["toad"])
 
 
 def _declared(generator, names):
@@ -260,6 +291,7 @@ def test_every_fixture_holds_exactly_the_keys_its_generator_writes():
     det = _declared("make_golden.py", ["KEYS", "EXTRA_KEYS"])
     pre = _declared("make_golden_preshift.py", ["KEYS", "KEYS_OWN_BLOCKS", "KEYS_SHARED_BLOCKS"])
     ide = _declared("make_golden_identify.py", ["KEYS", "KEYS_AUTO", "KEYS_MAP"])
+    itp = _declared("make_golden_interpol.py", ["KEYS"])
     seen = 0
     for path in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))):
         name = os.path.basename(path)[:-4]
@@ -267,10 +299,12 @@ def test_every_fixture_holds_exactly_the_keys_its_generator_writes():
         if name.startswith("preshift_"):
             shared = "src" in have
             want = pre["KEYS"] + (pre["KEYS_SHARED_BLOCKS"] if shared else pre["KEYS_OWN_BLOCKS"])
+        elif name.startswith("interpol_"):
+            want = itp["KEYS"]
         elif name.startswith("identify_"):
             want = ide["KEYS"] + (ide["KEYS_MAP"] if name == "identify_map" else ide["KEYS_AUTO"])
         else:
             want = det["KEYS"] + det["EXTRA_KEYS"].get(name, [])
         assert have == sorted(want), (name, sorted(set(have) ^ set(want)))
         seen += 1
-    assert seen >= 24
+    assert seen >= 30

@@ -18,6 +18,7 @@ THR_IN_C64 = 1
 FLAG_CARRIER = 1
 FLAG_CORR = 2
 FLAG_INDEX_ERROR = 4
+FLAG_INT_OFFSET = 8
 N_KERNEL_SLOTS = 5
 
 ABI_VERSION = 7     # THR_ABI_VERSION of include/thrifty_hip.h
@@ -29,7 +30,7 @@ EXPORTS = [
     "thr_debug_stage", "thr_identify", "thr_frame_card",
     "thr_submit", "thr_submit_card", "thr_submit_stream", "thr_collect", "thr_inputs_consumed", "thr_poll",
     "thr_set_stream_default", "thr_format_toad",
-    "thr_run_card", "thr_run_stream", "thr_get_settings", "thr_input_window_ex", "thr_input_window_release", "thr_debug_window", "thr_debug_window_times", "thr_debug_correlate_geom", "thr_debug_pipe_times",
+    "thr_run_card", "thr_run_stream", "thr_get_settings", "thr_input_window_ex", "thr_input_window_release", "thr_detect_offsets", "thr_debug_window", "thr_debug_window_times", "thr_debug_correlate_geom", "thr_debug_pipe_times",
 ]
 ERR_ARG, ERR_DEVICE, ERR_STATE, ERR_INDEX = -1, -2, -3, -4       # THR_ERR_*
 VARIANT_DEFAULT, VARIANT_PRESHIFT, VARIANT_FASTDET = 0, 1, 2      # THR_VARIANT_*
@@ -160,6 +161,7 @@ def load_library():
     lib.thr_destroy.restype = None
     lib.thr_detect.argtypes = [vp, vp, C.c_int, vp, C.c_size_t, vp]
     lib.thr_detect_card.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_size_t, vp]
+    lib.thr_detect_offsets.argtypes = [vp, vp, C.c_int, vp, C.c_size_t, vp, vp]
     lib.thr_frame_card.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_size_t, vp, vp, vp,
                                    C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     lib.thr_detect_device.argtypes = [vp, vp, C.c_int, vp, C.c_size_t, vp]
@@ -402,6 +404,19 @@ class Engine(object):
             idx_p = idx.ctypes.data
         _check(self._lib, self._lib.thr_detect(self._h, a.ctypes.data, fmt, idx_p, nb,
                                                out.ctypes.data))
+        return out
+
+    def detect_offsets(self, blocks, carrier_offset, block_idx=None):
+        """thr_detect_offsets: detect() with the sub-bin carrier offset of every block given (float64
+        [B]) instead of fitted -- the slow path behind a replaced `Detector.sync.interpolator`."""
+        a, fmt = self._as_input(blocks)
+        nb = a.shape[0]
+        off = np.ascontiguousarray(np.asarray(carrier_offset, dtype=np.float64))
+        assert off.shape == (nb,)
+        out = np.zeros((nb, self.n_templates), dtype=RECORD_DTYPE)
+        idx, idx_p = self._idx_ptr(block_idx, nb)
+        _check(self._lib, self._lib.thr_detect_offsets(self._h, a.ctypes.data, fmt, idx_p, nb, off.ctypes.data,
+                                                       out.ctypes.data))
         return out
 
     def detect_card(self, text, payload_off, block_idx=None):

@@ -396,6 +396,10 @@ struct thr_handle {
     InputWindow win;
     // seconds the calling thread spent per phase of the host entry points' chunks
     // (thr_debug_pipe_times): grow staging, H2D calls, metadata, launches, D2H calls, chunks
+    // thr_detect_offsets: the caller's sub-bin carrier offsets for the batch in flight (device
+    // array; nullptr = the Dirichlet fit), and the staging behind it
+    const double* forced = nullptr;
+    double* d_forced = nullptr;
     double t_pipe[8] = {};
     double t_pipe_max[8] = {};   // the longest single occurrence of each phase
 
@@ -821,7 +825,8 @@ int run_batch_fast(thr_handle* h, const void* d_samples_all, int format,
         {
             ProfScope p(h, 1);
             HIP_TRY(thr::launch_fit(n_blocks, h->dev, h->d_stats, d_block_idx, h->d_shifts,
-                                    h->d_work_list, h->d_work_count, d_out, h->d_corr_stats, h->stream));
+                                    h->d_work_list, h->d_work_count, d_out, h->d_corr_stats, h->stream,
+                                    h->forced ? h->forced + off : nullptr));
         }
         {
             ProfScope p(h, 2);
@@ -888,7 +893,7 @@ int run_batch_generic(thr_handle* h, const void* d_samples, int format,
             ProfScope p(h, 1);
             HIP_TRY(thr::launch_fit(nb, h->dev, h->d_stats, d_block_idx ? d_block_idx + off : nullptr,
                                     h->d_shifts, h->d_work_list, h->d_work_count, out, nullptr,
-                                    h->stream));
+                                    h->stream, h->forced ? h->forced + off : nullptr));
         }
         float2 *xh = nullptr, *cc = nullptr;
         {
@@ -937,7 +942,8 @@ int run_batch_long(thr_handle* h, const void* d_samples, int format,
             ProfScope p(h, 1);
             HIP_TRY(thr::launch_fit(nb, h->dev, h->d_stats, d_block_idx ? d_block_idx + off : nullptr,
                                     h->d_shifts, h->d_work_list, h->d_work_count, out,
-                                    h->d_corr_stats, h->stream));   // (sub-batch-local indices)
+                                    h->d_corr_stats, h->stream,     // (sub-batch-local indices)
+                                    h->forced ? h->forced + off : nullptr));
         }
         // correlate stage: one fused launch (sub-transforms + combination per workgroup) does
         // every batch with at least one carrier-positive block per workgroup; smaller ones fall
@@ -1005,7 +1011,7 @@ int run_batch_small(thr_handle* h, const void* d_samples, int format,
     {
         ProfScope p(h, 1);
         HIP_TRY(thr::launch_fit(n_blocks, h->dev, h->d_stats, d_block_idx, h->d_shifts,
-                                h->d_work_list, h->d_work_count, d_out, h->d_corr_stats, h->stream));
+                                h->d_work_list, h->d_work_count, d_out, h->d_corr_stats, h->stream, h->forced));
     }
     {
         ProfScope p(h, 2);
@@ -1447,7 +1453,7 @@ void thr_destroy(thr_handle* h) {
         (void)hipEventDestroy(e.b);
     }
     void* bufs[] = {h->d_tables, h->d_twn, h->d_tspec, h->d_stats, h->d_shifts, h->d_corr_stats, h->d_gen_scratch, h->d_tspec_nat, h->d_bank, h->d_gtw, h->d_tspec16k, h->d_seg_stats, h->d_win_pow, h->d_partial, h->d_dsub, h->d_work_list,
-                    h->d_work_count, h->d_xhat_scratch, h->d_ncompact, h->d_compact_tiles, h->d_in, h->d_idx, h->d_rec};
+                    h->d_work_count, h->d_xhat_scratch, h->d_ncompact, h->d_compact_tiles, h->d_in, h->d_idx, h->d_rec, h->d_forced};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -2070,7 +2076,8 @@ int thr_format_toad(const thr_record* recs, const double* timestamps, size_t n, 
         *p++ = ' ';
         p = put_int(p, r.carrier_bin);
         *p++ = ' ';
-        if (carrier_offset_f32 == 2)      // an int-typed offset (interpolator `none`): Python prints "0"
+        if (carrier_offset_f32 == 2 || (r.flags & THR_FLAG_INT_OFFSET))   // an int-typed offset (interpolator
+                                                                          // `none`; cosine's `return 0`): "0"
             p = put_int(p, (long long)r.carrier_offset);
         else
             p = py_repr_double(p, carrier_offset_f32 ? double(float(r.carrier_offset)) : r.carrier_offset);
@@ -2175,6 +2182,51 @@ int thr_debug_fft(thr_handle* h, const void* samples, int format, size_t n_block
         }
     } while (0);
     (void)hipFree(d_dump);
+    return rc;
+}
+
+int thr_detect_offsets(thr_handle* h, const void* samples, int format, const int64_t* block_idx,
+                       size_t n_blocks, const double* carrier_offset, thr_record* out) {
+    if (!h || !samples || !carrier_offset || !out) return fail(THR_ERR_ARG, "thr_detect_offsets: null argument");
+    if (format != THR_IN_U8 && format != THR_IN_C64) return fail(THR_ERR_ARG, "bad format %d", format);
+    if (n_blocks > size_t(h->cfg.max_batch))
+        return fail(THR_ERR_ARG, "n_blocks %zu exceeds max_batch %d", n_blocks, h->cfg.max_batch);
+    if (h->preshift_num) return fail(THR_ERR_ARG, "thr_detect_offsets: the default detector only (this variant "
+                                                  "interpolates inside its fused kernel)");
+    if (n_blocks == 0) return THR_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->hp.async_open != 0)
+        return fail(THR_ERR_STATE, "thr_detect_offsets: %d submitted batch(es) not collected yet", h->hp.async_open);
+    int rc = ensure_staging(h, format);
+    if (rc != THR_OK) return rc;
+    if (!h->d_forced) HIP_TRY(hipMalloc(&h->d_forced, size_t(h->cfg.max_batch) * sizeof(double)));
+    const size_t blk_bytes = size_t(h->cfg.block_len) * (format == THR_IN_U8 ? 2 : 8);
+    const size_t nt = size_t(h->cfg.n_templates);
+    std::vector<long long> idx(n_blocks);
+    for (size_t i = 0; i < n_blocks; ++i) idx[i] = block_idx ? (long long)block_idx[i] : (long long)i;
+    rc = THR_OK;
+    do {
+        if (hipMemcpyAsync(h->d_in, samples, n_blocks * blk_bytes, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            hipMemcpyAsync(h->d_idx, idx.data(), n_blocks * sizeof(long long), hipMemcpyHostToDevice, h->stream) !=
+                hipSuccess ||
+            hipMemcpyAsync(h->d_forced, carrier_offset, n_blocks * sizeof(double), hipMemcpyHostToDevice,
+                           h->stream) != hipSuccess) {
+            rc = fail(THR_ERR_DEVICE, "staging failed: %s", hipGetErrorString(hipGetLastError()));
+            break;
+        }
+        h->forced = h->d_forced;
+        rc = run_batch(h, h->d_in, format, h->d_idx, int(n_blocks), h->d_rec, nullptr, nullptr, nullptr, 0, false);
+        h->forced = nullptr;
+        if (rc != THR_OK) break;
+        if (hipMemcpyAsync(out, h->d_rec, n_blocks * nt * sizeof(thr_record), hipMemcpyDeviceToHost, h->stream) !=
+                hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) {
+            rc = fail(THR_ERR_DEVICE, "D2H copy failed: %s", hipGetErrorString(hipGetLastError()));
+            break;
+        }
+    } while (0);
+    h->forced = nullptr;
+    if (rc != THR_OK) (void)hipStreamSynchronize(h->stream);
     return rc;
 }
 

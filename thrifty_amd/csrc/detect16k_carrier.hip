@@ -300,7 +300,8 @@ __global__ __launch_bounds__(64) void k_fit(int n_blocks, DevCfg cfg,
                                             int* __restrict__ work_list,
                                             int* __restrict__ work_count,
                                             thr_record* __restrict__ records,
-                                            CorrStats* __restrict__ corr_stats) {
+                                            CorrStats* __restrict__ corr_stats,
+                                            const double* __restrict__ forced_offset) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = gid & 7;
     int b = gid >> 3;
@@ -325,15 +326,21 @@ __global__ __launch_bounds__(64) void k_fit(int n_blocks, DevCfg cfg,
     bool detected = peak_mag > thr;
     unsigned flags = 0;
     double offset = 0.0;
-    if (detected && peak_idx + 3 >= n) {
+    // (forced_offset: thr_detect_offsets -- the caller's own interpolator has produced the sub-bin
+    // offset, Synchronizer.sync with a replaced `interpolator`, carrier_sync.py:52-76; what that
+    // interpolator reads of the spectrum, and where it raises, is its business)
+    if (detected && forced_offset == nullptr && peak_idx + 3 >= n) {
         flags |= THR_FLAG_INDEX_ERROR;  // carrier_sync.py:187 raises here
         detected = false;
     }
     // the fit is group-uniform only if `detected` is; it is (same inputs in all 8 lanes)
     if (detected) {
         flags |= THR_FLAG_CARRIER;
-        offset = lmdif_dirichlet8(st->nb[j < 7 ? j : 6], st->nb[3], j, double(n),
-                                  double(cfg.carrier_len));
+        if (forced_offset != nullptr)
+            offset = forced_offset[b];
+        else
+            offset = lmdif_dirichlet8(st->nb[j < 7 ? j : 6], st->nb[3], j, double(n),
+                                      double(cfg.carrier_len));
 #ifdef THR_DEBUG_FIT
         {
             double lo = offset, hi = offset;
@@ -680,9 +687,9 @@ hipError_t launch_carrier_16k(int fmt, const void* samples, int n_blocks, const 
 hipError_t launch_fit(int n_blocks, const DevCfg& cfg, const CarStats* stats,
                       const long long* block_idx, ShiftParams* shifts, int* work_list,
                       int* work_count, thr_record* records, CorrStats* corr_stats,
-                      hipStream_t stream) {
+                      hipStream_t stream, const double* forced_offset) {
     hipLaunchKernelGGL(k_fit, dim3((n_blocks * 8 + 63) / 64), dim3(64), 0, stream, n_blocks, cfg,
-                       stats, block_idx, shifts, work_list, work_count, records, corr_stats);
+                       stats, block_idx, shifts, work_list, work_count, records, corr_stats, forced_offset);
     return hipGetLastError();
 }
 

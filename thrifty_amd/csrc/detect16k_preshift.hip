@@ -44,6 +44,7 @@ namespace {
 // NumPy >= 2), and nothing may be contracted into an fma: NumPy rounds every operation.
 struct PreshiftVerdict {
     bool carrier, index_error;
+    bool int_offset = false;   // the interpolator returned the Python int 0 (cosine, cos(omega) > 1)
     float peak_mag, noise_rms, offset;
     double offset_f64;   // what goes into the record (fastdet keeps the double parabola)
     int s_mod;   // int_shift mod N, in [0, N)
@@ -127,6 +128,8 @@ __device__ __forceinline__ PreshiftVerdict preshift_verdict(const DevCfg& cfg, f
                 const float omega = acosf(cos_omega);
                 const float theta = atanf((a - c) / ((2.0f * b) * sinf(omega)));
                 v.offset = -theta / omega;
+            } else {
+                v.int_offset = true;   // `return 0` (:87-88): an int, and the .toad column reads "0"
             }
         }
     }
@@ -148,7 +151,8 @@ __device__ __forceinline__ thr_record preshift_record(const PreshiftVerdict& vd,
                                                       int peak_idx) {
     thr_record r;
     r.block_idx = block_idx;
-    r.flags = (vd.carrier ? THR_FLAG_CARRIER : 0u) | (vd.index_error ? THR_FLAG_INDEX_ERROR : 0u);
+    r.flags = (vd.carrier ? THR_FLAG_CARRIER : 0u) | (vd.index_error ? THR_FLAG_INDEX_ERROR : 0u) |
+              (vd.carrier && vd.int_offset ? THR_FLAG_INT_OFFSET : 0u);
     r.template_id = 0;
     r.carrier_bin = peak_idx;
     r.corr_sample = -1;

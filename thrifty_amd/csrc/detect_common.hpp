@@ -102,7 +102,8 @@ hipError_t launch_carrier_16k(int fmt, const void* samples, int n_blocks, const 
 hipError_t launch_fit(int n_blocks, const DevCfg& cfg, const CarStats* stats,
                       const long long* block_idx, ShiftParams* shifts, int* work_list,
                       int* work_count, thr_record* records, CorrStats* corr_stats_x2,
-                      hipStream_t stream);   // corr_stats_x2: where to park sum |X|^2 (or null)
+                      hipStream_t stream,    // corr_stats_x2: where to park sum |X|^2 (or null)
+                      const double* forced_offset = nullptr);   // [n_blocks] sub-bin offsets instead of the fit
 hipError_t launch_correlate_16k(int fmt, const void* samples, const DevCfg& cfg,
                                 const float2* tables, const float2* twn, const float4* tspec,
                                 const ShiftParams* shifts, const int* work_list,

@@ -60,9 +60,15 @@ class _SyncStage(object):
     (carrier_sync.py:30-118) -- the attributes `thresh_coeffs`, `window`, `weights` and the call
     `sync(signal) -> (shifted_fft or None, CarrierSyncInfo)` -- evaluated by the engine for ONE
     block (carrier stage, Dirichlet fit, frequency shift, FFT#2; `thr_debug_stage` returns the
-    shifted spectrum in natural order).  Read-only: `detector` / `interpolator` / `shifter` are
-    stages of fused kernels and cannot be replaced (the reference's own subclasses that do so
-    are separate detectors here: `PreshiftDetector`, `FastDetector`)."""
+    shifted spectrum in natural order).  `detector` and `shifter` are stages of fused kernels and
+    cannot be replaced (the reference's own subclasses that do so are separate detectors here:
+    `PreshiftDetector`, `FastDetector`).  `interpolator` CAN be assigned, as the reference's
+    InterpolationDetector does (experimental/detect_carrier_interpol.py:17-40): any callable
+    `(fft_mag, peak_idx) -> offset` -- or None for no sub-bin estimate, carrier_sync.py:66-68 --
+    then runs on the HOST between two engine passes (carrier stage + |FFT#1| out, offsets back in:
+    thr_detect_offsets), a slow path for analysis scripts."""
+
+    _DEVICE_FIT = object()      # `interpolator` not assigned: the engine's own Dirichlet fit (k_fit)
 
     def __init__(self, det, settings):
         self._det = det
@@ -70,9 +76,26 @@ class _SyncStage(object):
         self.window = settings.carrier_window
         self.weights = None
         self._last = None       # (id of the shifted_fft handed out, record, corr) of the latest block
+        self._interpolator = self._DEVICE_FIT
+
+    @property
+    def interpolator(self):
+        return self._device_interpolator if self._interpolator is self._DEVICE_FIT else self._interpolator
+
+    @interpolator.setter
+    def interpolator(self, fn):
+        if fn is not None and not callable(fn):
+            raise TypeError("sync.interpolator takes a callable (fft_mag, peak_idx) -> offset, or None")
+        self._interpolator = fn
+        self._det._use_host_interpolator()
 
     def sync(self, signal):
         det = self._det
+        if self._interpolator is not self._DEVICE_FIT:
+            # (the stage dump is the engine's OWN pipeline, Dirichlet fit included: it cannot show
+            # the spectrum shifted by somebody else's offset)
+            raise NotImplementedError("sync(block) evaluates the engine's own stages; with a replaced "
+                                      "interpolator use Detector.detect(timestamp, block_idx, block)")
         arr = det._stack([signal])
         rec = det._run(arr, np.zeros(1, dtype=np.int64))[0, 0]
         _, result = det._result(0.0, 0, rec)
@@ -93,8 +116,9 @@ class _SyncStage(object):
 
     detector = detect
 
-    def interpolator(self, fft_mag, peak_idx):
-        raise NotImplementedError("the Dirichlet fit runs inside the engine (k_fit): call sync(block)")
+    def _device_interpolator(self, fft_mag, peak_idx):
+        raise NotImplementedError("the Dirichlet fit runs inside the engine (k_fit): call sync(block) -- or "
+                                  "assign sync.interpolator a host callable (slow path)")
 
     def shifter(self, signal, shift):
         raise NotImplementedError("the frequency shift is fused into the correlate kernel: call sync(block)")
@@ -142,6 +166,7 @@ class Detector(object):
     _fit_reach = 3            # the carrier interpolator reads fft_mag[peak + 3] (carrier_sync.py:187)
     _offset_type = float      # CarrierSyncInfo.offset as the reference types it
     _multi = False            # MultiTemplateDetector: settings.template is [n_templates, len]
+    _host_interp = False      # `sync.interpolator` has been assigned: the two-pass slow path
 
     def __init__(self, settings, blocks=None, rxid=-1, yield_data=False, batch_size=None,
                  device_id=0, _preshift_num=0, _fastdet=False, max_wait=None, max_fill=None,
@@ -219,6 +244,7 @@ class Detector(object):
         corr_len = settings.block_len - template.shape[-1] + 1
         # twins of the reference's sub-objects (detect.py:46-58): the same attributes, and CALLABLE
         # like them -- evaluated by the engine, one block at a time (_SyncStage / _SoaStage below)
+        self._host_interp = False   # sync.interpolator has been assigned: the slow path below
         self.sync = _SyncStage(self, settings)
         self.soa_estimate = _SoaStage(self, settings, template, corr_len)
 
@@ -243,7 +269,8 @@ class Detector(object):
                 max(int(rec["carrier_bin"]) + self._fit_reach, n), n))
         has_carrier = bool(flags & _native.FLAG_CARRIER)
         carrier = toads_data.CarrierSyncInfo(
-            int(rec["carrier_bin"]), self._offset_type(rec["carrier_offset"]) if has_carrier else 0,
+            int(rec["carrier_bin"]),
+            (0 if flags & _native.FLAG_INT_OFFSET else self._offset_type(rec["carrier_offset"])) if has_carrier else 0,
             np.float32(rec["carrier_energy"]), np.float32(rec["carrier_noise"]))
         if not has_carrier:
             return False, toads_data.DetectionResult(timestamp, block_idx, None, carrier, None,
@@ -275,6 +302,8 @@ class Detector(object):
         cbin = recs["carrier_bin"].tolist()
         coff = (recs["carrier_offset"].tolist() if self._offset_type is float
                 else recs["carrier_offset"].astype(self._offset_type))
+        if np.any(flags & _native.FLAG_INT_OFFSET):       # (the reference's interpolator returned the int 0)
+            coff = [0 if f & _native.FLAG_INT_OFFSET else v for f, v in zip(fl, coff)]
         cen, cno = recs["carrier_energy"], recs["carrier_noise"]     # stay np.float32
         samp = recs["corr_sample"].tolist()
         soff = recs["corr_offset"].tolist()
@@ -298,16 +327,70 @@ class Detector(object):
         in flight the synchronous entry point would refuse to run (thr_detect waits for open
         tickets to be collected), so a direct detect() between two next() calls rides the
         ticket interface too."""
-        if not self._ahead or self.yield_data:
+        if not self._ahead or self.yield_data or self._host_interp:
             return self._engine.detect(arr, idx)
         step = self.batch_size
         return np.concatenate([self._engine.collect(self._engine.submit(arr[s:s + step], idx[s:s + step]))
                                for s in range(0, len(arr), step)])
 
+    # --------------------------------------------- a replaced carrier interpolator (slow path)
+    def _use_host_interpolator(self):
+        """`sync.interpolator = fn` was assigned (reference experimental/detect_carrier_interpol.py:
+        17-40): from here on every batch makes two engine passes with the callable in between, one
+        batch at a time, blocks pulled through the classic per-block iterator."""
+        if self._engine.preshift_num or self._multi or self.yield_data:
+            raise NotImplementedError("a replaced interpolator is offered by the default single-template "
+                                      "Detector (this variant interpolates inside its fused kernel)")
+        if self._ahead or self._ready:
+            raise RuntimeError("assign sync.interpolator before iterating")
+        self._host_interp = True
+        self._card = self._raw = None          # (the readers also iterate as (timestamp, idx, block))
+        if self._pin:
+            self._engine.input_window(None)
+            self._pin = False
+        self.batch_size = min(self.batch_size, _YIELD_DATA_BATCH)   # a batch drags its spectra along
+
+    def _detect_batch_host(self, items):
+        """Reference Synchronizer.sync with `interpolator` replaced (carrier_sync.py:52-76), for a batch:
+        engine pass 1 -> verdict, peak bin and |FFT#1| of every block; the callable on the host for the
+        blocks that carry a carrier; engine pass 2 with those offsets (thr_detect_offsets).  An
+        exception of the callable (IndexError at the spectrum's end, like the reference's own
+        interpolators) belongs to its block: the results before it still come out, then it is raised."""
+        fn = self.sync._interpolator
+        arr = self._stack([it[2] for it in items])
+        idx = np.array([int(it[1]) for it in items], dtype=np.int64)
+        first = self._engine.detect(arr, idx)[:, 0]
+        has = (first["flags"] & (_native.FLAG_CARRIER | _native.FLAG_INDEX_ERROR)) != 0
+        spectra = self._engine.debug_fft(arr) if has.any() and fn is not None else None
+        vals, error, n_ok = [0] * len(items), None, len(items)
+        for i in np.flatnonzero(has).tolist():
+            if fn is None:
+                continue                        # `if self.interpolator is not None` (carrier_sync.py:66)
+            try:
+                vals[i] = fn(np.abs(spectra[i]), int(first["carrier_bin"][i]))
+            except Exception as exc:            # noqa: BLE001 -- whatever the callable raises is the block's
+                error, n_ok = exc, i
+                break
+        out = []
+        if n_ok:
+            recs = self._engine.detect_offsets(arr[:n_ok], np.array([float(v) for v in vals[:n_ok]]), idx[:n_ok])[:, 0]
+            out = self._results([it[0] for it in items[:n_ok]], idx[:n_ok], recs)
+            for (detected, res), v in zip(out, vals):
+                if res.corr_info is not None:   # the offset as the callable returned it (none() -> the int 0)
+                    res.carrier_info = res.carrier_info._replace(offset=v)
+        if error is not None:
+            out.append(_Deferred(error))
+        return out
+
     def detect_batch(self, items):
         """[(timestamp, block_idx, block), ...] -> [(detected, DetectionResult), ...]."""
         if not items:
             return []
+        if self._host_interp:
+            out = self._detect_batch_host(items)
+            if out and isinstance(out[-1], _Deferred):
+                raise out[-1].exc
+            return out
         arr = self._stack([it[2] for it in items])
         idx = np.array([int(it[1]) for it in items], dtype=np.int64)
         recs = self._run(arr, idx)[:, 0]
@@ -380,7 +463,7 @@ class Detector(object):
                 break
         if not items:
             return None
-        if self.yield_data:
+        if self.yield_data or self._host_interp:
             return items
         arr = self._stack([it[2] for it in items])
         idx = np.array([int(it[1]) for it in items], dtype=np.int64)
@@ -399,7 +482,7 @@ class Detector(object):
             if first is None:
                 return None
             self._ahead.append(first)
-        if self.yield_data:
+        if self.yield_data or self._host_interp:
             return self._ahead.popleft()
         while (len(self._ahead) <= self._depth and not self._exhausted and self._read_error is None
                and self._may_read_ahead(self._ahead[-1][2])):
@@ -427,7 +510,7 @@ class Detector(object):
         """The iteration ends here (the reference's loop died on this block): never leave a ticket open."""
         while self._ahead:
             pending = self._ahead.popleft()
-            if not self.yield_data:
+            if not (self.yield_data or self._host_interp):
                 self._engine.collect(pending[2])
         # nothing of the input is read any more: an error the read-ahead had parked belongs to
         # blocks behind the one that ended the iteration, and the input's pages can be unlocked
@@ -460,6 +543,9 @@ class Detector(object):
         if self.yield_data:
             self._ready.extend(self.detect(*it) for it in got)
             return
+        if self._host_interp:
+            self._ready.extend(self._detect_batch_host(got))
+            return
         stamps, idxs, recs = got
         groups = None
         if self.only_detections:
@@ -482,8 +568,9 @@ class Detector(object):
         that error after the detections before it have been yielded."""
         if self.blocks is None:
             raise TypeError("Detector was constructed without a block source")
-        if self.yield_data:
-            raise TypeError("record iteration is not available with yield_data")
+        if self.yield_data or self._host_interp:
+            raise TypeError("record iteration is not available with yield_data / a replaced interpolator: "
+                            "iterate the detector")
         while self._more():
             got = self._next_records()
             if got is None:
@@ -893,12 +980,14 @@ def detector_cli(detector_class, parser=None, extra_args=None, argv=None):
     detections = detector_class(settings, blocks, rxid=config.rxid, **kwargs)
     if args.quiet and hasattr(detections, "only_detections"):
         detections.only_detections = True   # nothing is printed for the other blocks anyway
-    if args.quiet and output_file is not None and hasattr(detections, "write_toad"):
+    if (args.quiet and output_file is not None and hasattr(detections, "write_toad")
+            and not getattr(detections, "_host_interp", False)):
         # nothing per block is needed: a mapped input runs entirely inside the library
         # (thr_run_card / thr_run_stream), anything else a batch of text at a time
         detections.write_toad(output_file)
         return
-    if args.quiet and output_file is not None and hasattr(detections, "iter_toad_text"):
+    if (args.quiet and output_file is not None and hasattr(detections, "iter_toad_text")
+            and not getattr(detections, "_host_interp", False)):
         for text in detections.iter_toad_text():
             output_file.write(text.decode("ascii"))
         output_file.flush()

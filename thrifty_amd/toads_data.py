@@ -88,6 +88,10 @@ def toad_lines(recs, timestamps, new_len, rxid=None, txid=None, carrier_offset_t
         list(map(repr, recs["carrier_energy"].astype(np.float64).tolist())),
         list(map(repr, recs["carrier_noise"].astype(np.float64).tolist())),
     ]
+    # THR_FLAG_INT_OFFSET (8): the reference's interpolator returned the Python int 0 for this block
+    # (cosine, cos(omega) > 1, carrier_interpolators.py:87-88) -- the column reads "0"
+    for i in np.flatnonzero(recs["flags"] & 8).tolist():
+        cols[8][i] = "0"
     ids = [str(v) for v in (rxid, txid) if v is not None]
     head = " ".join(ids) + " " if ids else ""
     return [head + " ".join(row) for row in zip(*cols)]
