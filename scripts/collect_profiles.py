@@ -3,7 +3,7 @@
 profiles/ (tracked) and rebuild profiles/hbm_traffic.json, which bench.py reads for
 `roofline.traffic`:  {config key: {kernel: {fetch_kib_raw, write_kib, bytes_per_launch}}}.
 
-    python scripts/collect_profiles.py r03_c2=c2 r03_t4=c2_t4 r03_c3=c3 r03_sparse=c2_sparse
+    python scripts/collect_profiles.py r05_c2=c2 r05_t4=c2_t4 r05_c3=c3 r05_sparse=c2_sparse r05_c1=c1 ...
 """
 import json
 import os
@@ -17,7 +17,7 @@ if os.path.exists(path):
     try:
         old = json.load(open(path))
         out = {k: v for k, v in old.items() if isinstance(v, dict) and all(isinstance(x, dict) for x in v.values())
-               and k in ("c2", "c2_t4", "c3", "c3_t4", "c2_preshift", "c2_sparse", "c2_fullwin")}
+               and k in ("c2", "c2_t4", "c3", "c3_t4", "c2_preshift", "c2_sparse", "c2_fullwin", "c1", "c1_sparse")}
     except Exception:
         out = {}
 for arg in sys.argv[1:]:
