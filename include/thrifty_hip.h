@@ -118,7 +118,7 @@ int thr_create(const thr_settings* settings, thr_handle** out);
 /*
  * PreshiftDetector variant -- replaces `PreshiftDetector.__init__` + `TemplateShifts`
  * (thrifty/experimental/detect_preshift.py:24-60; defaults num=21, parabolic carrier
- * interpolator experimental/carrier_interpolators.py:44-49, corr_shift off): the
+ * interpolator experimental/carrier_interpolators.py:40-45, corr_shift off): the
  * carrier offset is a 3-point parabola on |FFT#1|, FFT#1 is rolled by the rounded shift
  * (freq_shift_integer, carrier_sync.py:241-245) and correlated against the nearest of
  * `num_shifts` template spectra pre-shifted by -0.5 .. +0.5 bin.  Every other entry
@@ -152,8 +152,8 @@ int thr_create_fastdet(const thr_settings* settings, thr_handle** out);
  * The three constructors above in one call, plus an explicit choice of kernel path.  `variant`:
  * THR_VARIANT_DEFAULT (thr_create), THR_VARIANT_PRESHIFT (thr_create_preshift; variant_arg =
  * num_shifts | THR_INTERP_* << 16: the bank size and the carrier interpolator, one of the reference's
- * thrifty/experimental/carrier_interpolators.py -- parabolic (:44-49, what thr_create_preshift uses
- * and the reference's default), none (:17), gaussian (:52-58), cosine (:92-100); float32 like the
+ * thrifty/experimental/carrier_interpolators.py -- parabolic (:40-45, what thr_create_preshift uses
+ * and the reference's default), none (:17-18), gaussian (:48-54), cosine (:84-92); float32 like the
  * magnitudes they are given) or THR_VARIANT_FASTDET (thr_create_fastdet).  `path`:
  *   THR_PATH_AUTO         what the other constructors use: the fastest kernels for the block
  *                         length (LDS-resident for 1024 ... 65536, multi-pass otherwise);

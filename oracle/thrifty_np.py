@@ -296,7 +296,7 @@ class OracleDetector(object):
 # 8(f) rank 2: PreshiftDetector              (experimental/detect_preshift.py)
 # --------------------------------------------------------------------------
 def parabolic_offset(mag, peak_idx):
-    """3-point parabola on the FFT magnitudes (experimental/carrier_interpolators.py:44-49).
+    """3-point parabola on the FFT magnitudes (experimental/carrier_interpolators.py:40-45).
     `mag` is float32, so is the result; mag[peak-1] wraps for peak 0 (Python negative
     index) and mag[peak+1] raises IndexError past the end, like the reference."""
     a, b, c = mag[peak_idx - 1], mag[peak_idx], mag[peak_idx + 1]
@@ -311,7 +311,7 @@ def no_offset(mag, peak_idx):
 
 def gaussian_offset(mag, peak_idx):
     """The parabola through the LOGARITHMS of the three magnitudes
-    (experimental/carrier_interpolators.py:52-58; float32 in, float32 out)."""
+    (experimental/carrier_interpolators.py:48-54; float32 in, float32 out)."""
     a, b, c = mag[peak_idx - 1], mag[peak_idx], mag[peak_idx + 1]
     with np.errstate(divide="ignore", invalid="ignore"):
         a, b, c = np.log(a), np.log(b), np.log(c)
@@ -319,7 +319,7 @@ def gaussian_offset(mag, peak_idx):
 
 
 def cosine_offset(mag, peak_idx):
-    """experimental/carrier_interpolators.py:92-100."""
+    """experimental/carrier_interpolators.py:84-92."""
     a, b, c = mag[peak_idx - 1], mag[peak_idx], mag[peak_idx + 1]
     with np.errstate(divide="ignore", invalid="ignore"):
         cos_omega = (a + c) / (2 * b)
@@ -335,7 +335,7 @@ CARRIER_INTERPOLATORS = {"parabolic": parabolic_offset, "none": no_offset,
 
 
 def parabole_fit_offset(width):
-    """experimental/carrier_interpolators.py:61-70: vertex of the least-squares parabola through
+    """experimental/carrier_interpolators.py:57-66: vertex of the least-squares parabola through
     the width + 1 magnitudes around the peak."""
     def interpolate(mag, peak_idx):
         x = np.arange(-(width // 2), width // 2 + 1)
@@ -345,7 +345,7 @@ def parabole_fit_offset(width):
 
 
 def corr_parabolic_offset(corr_width, block_len, carrier_len):
-    """experimental/carrier_interpolators.py:73-81: the three-point parabola on the magnitudes
+    """experimental/carrier_interpolators.py:69-81: the three-point parabola on the magnitudes
     correlated with the Dirichlet kernel (its own kernel: no absolute value, 1 at x = 0, :7-14)."""
     rel = np.arange(-(corr_width // 2), corr_width // 2 + 1)
     xr = np.array(rel, dtype=np.float64)

@@ -60,10 +60,11 @@ constexpr int kItemSegBits = 3;
 // neighbours) and rows RLO + 1 .. 14 - RHI entirely inside it (the launchers check):
 // the outside rows then cost nothing -- not even their share of pass C, whose unused outputs
 // the compiler drops -- and the inside rows skip the window test.  Uniform run-time branches for
-// the same purpose cost more schedule than they save (profiles/README.md); the geometries
-// instantiated are BASELINE's (history 4096, 1023-sample template: 1, 2), the example
-// detector.cfg's (history 4920, 4914-sample template: 0, 4) and, for sections, (0, 3) -- BASELINE's
-// 65536-sample blocks; any other runs the generic form.
+// the same purpose cost more schedule than they save (profiles/README.md), so the variants are a
+// small closed table, correlate16k_geom.hpp: RLO = 0 .. 2 x RHI = 0 .. 4 (RLO = 0 for sections) --
+// BASELINE's history 4096 / 1023-sample template is (1, 2), the example detector.cfg (0, 4),
+// BASELINE's 65536-sample blocks (0, 3) in every section; a window outside the table runs the
+// generic form.
 //
 // SEG (block_len NL > 16384, detect_seg.hip): the correlation the reference keeps,
 // ifft(X^ conj(T^))[:corr_len] with the template zero-padded to NL (soa_estimator.py:97-102), is a

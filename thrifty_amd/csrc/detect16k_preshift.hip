@@ -2,7 +2,7 @@
 // reference thrifty/experimental/detect_preshift.py:24-80).
 //
 // The reference variant avoids FFT#2: the carrier offset comes from a 3-point parabola
-// on |FFT#1| (experimental/carrier_interpolators.py:44-49), FFT#1 is *rolled* by the
+// on |FFT#1| (experimental/carrier_interpolators.py:40-45), FFT#1 is *rolled* by the
 // rounded shift (carrier_sync.py:241-245) and the residual sub-bin shift selects the
 // nearest of `num` pre-shifted template spectra (detect_preshift.py:42-45).  With no
 // iterative fit between the transform and the matched filter the whole block becomes ONE
@@ -108,21 +108,21 @@ __device__ __forceinline__ PreshiftVerdict preshift_verdict(const DevCfg& cfg, f
     v.carrier = peak_mag > thr;
     v.peak_mag = peak_mag;
     v.noise_rms = noise_rms;
-    // (every interpolator but `none` reads fft_mag[peak + 1]: carrier_interpolators.py:47,55,94)
+    // (every interpolator but `none` reads fft_mag[peak + 1]: carrier_interpolators.py:43,51,85)
     v.index_error = v.carrier && (PARABOLIC_ONLY || cfg.interp != THR_INTERP_NONE) && peak_idx + 1 >= n;
     if (v.index_error) v.carrier = false;
     const float b = peak_mag;
     v.offset = 0.0f;
     if (v.carrier) {
         // float32 in, float32 out, operation by operation as NumPy evaluates the reference's lines
-        if (PARABOLIC_ONLY || cfg.interp == THR_INTERP_PARABOLIC) {   // carrier_interpolators.py:44-49
+        if (PARABOLIC_ONLY || cfg.interp == THR_INTERP_PARABOLIC) {   // carrier_interpolators.py:40-45
             const float two_a = 2.0f * a, two_c = 2.0f * c, four_b = 4.0f * b;
             v.offset = (c - a) / ((four_b - two_a) - two_c);
-        } else if (!PARABOLIC_ONLY && cfg.interp == THR_INTERP_GAUSSIAN) {   // :52-58, the same on the logarithms
+        } else if (!PARABOLIC_ONLY && cfg.interp == THR_INTERP_GAUSSIAN) {   // :48-54, the same on the logarithms
             const float la = logf(a), lb = logf(b), lc = logf(c);
             const float two_a = 2.0f * la, two_c = 2.0f * lc, four_b = 4.0f * lb;
             v.offset = (lc - la) / ((four_b - two_a) - two_c);
-        } else if (!PARABOLIC_ONLY && cfg.interp == THR_INTERP_COSINE) {     // :92-100
+        } else if (!PARABOLIC_ONLY && cfg.interp == THR_INTERP_COSINE) {     // :84-92
             const float cos_omega = (a + c) / (2.0f * b);
             if (!(cos_omega > 1.0f)) {
                 const float omega = acosf(cos_omega);

@@ -28,19 +28,19 @@ def none(fft_mag, peak):
 
 def parabolic(fft_mag, peak):
     """Sub-bin carrier offset from a parabola through |X[peak-1]|, |X[peak]|, |X[peak+1]|
-    (reference carrier_interpolators.py:44-49)."""
+    (reference carrier_interpolators.py:40-45)."""
     left, mid, right = fft_mag[peak - 1], fft_mag[peak], fft_mag[peak + 1]
     return (right - left) / (4 * mid - 2 * left - 2 * right)
 
 
 def gaussian(fft_mag, peak):
-    """The same on the logarithms of the three magnitudes (reference :52-58)."""
+    """The same on the logarithms of the three magnitudes (reference :48-54)."""
     left, mid, right = np.log(fft_mag[peak - 1]), np.log(fft_mag[peak]), np.log(fft_mag[peak + 1])
     return (right - left) / (4 * mid - 2 * left - 2 * right)
 
 
 def cosine(fft_mag, peak):
-    """Cosine fit through the three magnitudes (reference :92-100)."""
+    """Cosine fit through the three magnitudes (reference :84-92)."""
     left, mid, right = fft_mag[peak - 1], fft_mag[peak], fft_mag[peak + 1]
     cos_omega = (left + right) / (2 * mid)
     if cos_omega > 1:
@@ -69,7 +69,7 @@ def make_dirichlet(block_len, carrier_len, width=6):
 
 
 def make_parabole_fit(width):
-    """Vertex of the least-squares parabola through `width + 1` magnitudes (reference :61-70)."""
+    """Vertex of the least-squares parabola through `width + 1` magnitudes (reference :57-66)."""
     def _interpolator(fft_mag, peak):
         xdata = np.arange(-(width // 2), width // 2 + 1)
         coeffs = np.polyfit(xdata, fft_mag[peak + xdata], 2)
@@ -79,7 +79,7 @@ def make_parabole_fit(width):
 
 
 def make_corr_parabolic(corr_width, block_len, carrier_len):
-    """Three-point parabola on the magnitudes correlated with the Dirichlet kernel (reference :73-81)."""
+    """Three-point parabola on the magnitudes correlated with the Dirichlet kernel (reference :69-81)."""
     rel = np.arange(-(corr_width // 2), corr_width // 2 + 1)
     dirichlet = _dirichlet_kernel(rel, block_len, carrier_len)
 
