@@ -61,6 +61,7 @@ def run(batch, pop, seg, window=True, path=None):
     t_c = time.perf_counter()
     eng = F.Engine(n, h, tpl, thr, win, tuple(float(v) for v in g["corr_thresh"]), max_batch=batch)
     t_c = time.perf_counter() - t_c
+    cpu0 = time.process_time()
     with open(path, "rb") as f:
         mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
         view = memoryview(mm)
@@ -72,6 +73,7 @@ def run(batch, pop, seg, window=True, path=None):
         else:
             st = eng.run_stream(view, first_block_idx=0, out_fd=out_fd, rxid=0, batch_blocks=batch)
         dt = time.perf_counter() - t0
+        print("process CPU %.0f ms of %.0f ms wall; " % ((time.process_time() - cpu0) * 1e3, dt * 1e3), end="")
         wt = eng.debug_window_times() if window else {}
         pt = eng.debug_pipe_times()
         eng.input_window(None)
@@ -97,5 +99,11 @@ run(2048, 3, 128 << 20)
 run(2048, 3, 128 << 20, path=file_b)
 run(2048, 3, 128 << 20, path=file_b)
 run(2048, 3, 128 << 20)
+for pop in (1, 2):
+    run(2048, pop, 128 << 20)
+for seg in (32 << 20, 256 << 20):
+    run(2048, 3, seg)
+run(4096, 3, 128 << 20)
+run(2048, 3, 128 << 20, window=False)
 os.unlink(file_a)
 os.unlink(file_b)
