@@ -69,6 +69,92 @@ def test_gather_records_two_ranks(counts):
     assert list(got[:, 8]) == [1] * counts[0] + [2] * counts[1]  # rank order
 
 
+def _selftest_worker(rank, world, port, break_gather, ret):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        if break_gather == "raises":
+            def broken(*a, **k):
+                raise RuntimeError("backend has no gather")
+            dist.gather = broken                 # (a backend without the operation: it raises on every rank)
+        if break_gather == "garbles" and rank == 0:
+            real = dist.gather
+
+            def garbled(tensor, gather_list=None, dst=0, group=None):
+                real(tensor, gather_list, dst=dst, group=group)
+                gather_list[1].zero_()           # rank 0 receives something else than was sent
+            dist.gather = garbled
+        method = parallel.gather_selftest(world, rank, torch.device("cpu"))
+        # ... and the run's own gather then takes the method the rehearsal settled on
+        counts = [4, 0, 9][:world]
+        local = torch.full((counts[rank], 64), rank + 1, dtype=torch.uint8)
+        out = parallel.gather_records(local, world, rank)
+        ret.put((rank, method, out.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,break_gather,want", [(2, None, "gather"), (3, None, "gather"),
+                                                     (3, "raises", "all_gather"), (3, "garbles", "all_gather")])
+def test_gather_selftest_settles_the_method_collectively(world, break_gather, want):
+    """The pre-flight rehearsal of the record gather (uneven counts, one empty rank): a backend
+    whose `gather` raises, or delivers other bytes to rank 0 only, moves EVERY rank to the all_gather
+    form -- and the run's gather then uses it and still arrives complete and in rank order."""
+    import torch.multiprocessing as mp
+    assert parallel.selftest_counts(1) == [3] and parallel.selftest_counts(8)[-1] == 0
+    assert len(set(parallel.selftest_counts(8)[:-1])) > 1          # uneven
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_selftest_worker, args=(r, world, port, break_gather, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(world):
+        rank, method, out = ret.get(timeout=180)
+        got[rank] = (method, out)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert {m for m, _ in got.values()} == {want}
+    counts = [4, 0, 9][:world]
+    assert list(got[0][1][:, 0]) == [r + 1 for r in range(world) for _ in range(counts[r])]
+    assert all(got[r][1].shape == (0, 64) for r in range(1, world))
+
+
+def test_rank_env_is_the_same_on_every_launch_route(monkeypatch):
+    """The driver's `torch.distributed.run ... bench.py --gpus N` never went through
+    relaunch_under_torchrun(): rank_env() is what both routes apply, before torch / HIP initialise.
+    A value the caller exported wins."""
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    env = {}
+    assert parallel.rank_env(env) == {"HSA_ENABLE_IPC_MODE_LEGACY": "0"} and env == parallel.RANK_ENV
+    assert parallel.rank_env() == {"HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    assert os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert parallel.rank_env({"HSA_ENABLE_IPC_MODE_LEGACY": "1"}) == {"HSA_ENABLE_IPC_MODE_LEGACY": "1"}
+    # bench.py and the CLI call it before they import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "bench.py")).read()
+    main = src[src.index("def main():"):]
+    assert main.index("parallel.rank_env()") < main.index("import torch")
+    cli = open(os.path.join(root, "thrifty_amd", "detect.py")).read()
+    body = cli[cli.index("def detector_cli("):]
+    assert body.index("parallel.rank_env()") < body.index("parallel.sharded_env(")
+
+
+def test_populators_are_sized_from_the_hosts_cpus_per_rank(monkeypatch):
+    monkeypatch.setattr(parallel, "cpu_budget", lambda: 16)
+    assert [parallel.populate_threads(w) for w in (1, 2, 4, 8)] == [3, 3, 1, 1]
+    monkeypatch.setattr(parallel, "cpu_budget", lambda: 256)
+    assert [parallel.populate_threads(w) for w in (1, 8)] == [3, 3]
+    monkeypatch.setattr(parallel, "cpu_budget", lambda: 2)
+    assert parallel.populate_threads(1) == 1
+    assert parallel.cpu_budget.__name__ == "<lambda>"       # (the real one reads affinity + cgroup cpu.max)
+
+
 # ---------------------------------------------------------------------------------------------
 # `thrifty detect --gpus N` host logic: reader sharding and the sharded run (gloo stands in for
 # RCCL; the engine is replaced by a deterministic record maker -- no GPU here)

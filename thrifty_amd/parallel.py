@@ -115,9 +115,13 @@ def selftest_counts(world):
 def gather_selftest(world, rank, device, group=None):
     """One tiny gather_records() round on the REAL backend, before anything is timed: every rank
     sends selftest_counts()[rank] records stamped (rank, position); rank 0 checks count, order and
-    bytes.  If the backend's `gather` raises on any rank or delivers something else, every rank
-    switches to the all_gather form (decided collectively, re-checked); if that fails too the run
-    ends here with a sentence instead of inside the timed region.  -> the method in use."""
+    bytes.  If the backend's `gather` raises (an operation it does not offer raises on every rank)
+    or delivers something else to rank 0, every rank switches to the all_gather form (decided
+    collectively: an all-reduce of the ranks' verdicts; re-checked); if that fails too the run ends
+    here with a sentence instead of inside the timed region.  (A collective that ONE rank never
+    enters hangs its peers on any backend: that is what the process group's timeout is for, and
+    the driver's clock would show it in front of the first step, not inside one.)  -> the method
+    in use."""
     import torch
     import torch.distributed as dist
     global _gather_method
