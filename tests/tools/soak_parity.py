@@ -3,13 +3,29 @@ the oracle spread over worker processes.  Usage: soak_parity.py [n_blocks] [proc
 variant: default (BASELINE configs[1]) | preshift | fullwin (configs[1] with the reference's default
 carrier window '0--1': the full-spectrum carrier kernel) | c3 (configs[2]: 65536-sample blocks, the
 sectioned correlate stage) | c3u (the same through the unsectioned kernels) | n32k (32768-sample
-blocks, same template: three sections)"""
+blocks, same template: three sections) | c1 (BASELINE configs[0]'s geometry: the example detector.cfg --
+history 4920, the 4914-sample extracted template of tests/golden/c1.npz -- on 16384-sample blocks)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import multiprocessing as mp
 import numpy as np
 
 H = 4096
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def history(variant):
+    return 4920 if variant == "c1" else H
+
+
+def template_of(variant, bits, sps):
+    """(engine template, template the synthetic bursts are made of)"""
+    from thrifty_amd import synth
+    if variant == "c1":
+        tpl = np.load(os.path.join(ROOT, "tests", "golden", "c1.npz"))["template"].astype(np.float64)
+        return tpl, (tpl - tpl.min()) / (tpl.max() - tpl.min()) * 2 - 1
+    tpl = synth.gold_template(bits, 2, sps).astype(np.float64)
+    return tpl, tpl
 
 
 def geometry(variant):
@@ -29,7 +45,7 @@ def work(args):
     if variant == "preshift":
         orc = onp.OraclePreshiftDetector(N, H, tpl, (0, 15, 0), (7, 110), (0, 15, 0), num=21)
     else:
-        orc = onp.OracleDetector(N, H, tpl, (0, 15, 0), cwin, (0, 15, 0))
+        orc = onp.OracleDetector(N, history(variant), tpl, (0, 15, 0), cwin, (0, 15, 0))
     out = []
     for i in range(len(blocks)):
         r = orc.detect_u8(lo + i, blocks[i])
@@ -51,13 +67,14 @@ def main():
     from thrifty_amd import _native as F, synth
     dev = torch.device("cuda", 0)
     N, cwin, bits, sps = geometry(variant)
-    tpl = synth.gold_template(bits, 2, sps).astype(np.float64)
-    pad = H - len(tpl) + 1
+    tpl, synth_tpl = template_of(variant, bits, sps)
+    h = history(variant)
+    pad = h - len(tpl) + 1
     window = (pad // 2, (N - len(tpl) + 1) - (pad - pad // 2))
     gen = torch.Generator(device=dev)
     gen.manual_seed(777)
-    data = bench.synth_on_device(torch, dev, gen, total, N, tpl, window, 0.9)
-    eng = F.Engine(N, H, tpl, (0, 15, 0), cwin, (0, 15, 0), max_batch=8192,
+    data = bench.synth_on_device(torch, dev, gen, total, N, synth_tpl, window, 0.9)
+    eng = F.Engine(N, h, tpl, (0, 15, 0), cwin, (0, 15, 0), max_batch=8192,
                    preshift_num=21 if variant == "preshift" else 0,
                    path="unsectioned" if variant == "c3u" else "auto")
     rec = torch.zeros((total, 64), dtype=torch.uint8, device=dev)
