@@ -507,3 +507,46 @@ def test_bench_gpus_n_starts_its_own_ranks_and_fails_loudly_without_a_gpu():
     assert res.stderr.count("bench.py needs an MI355X; there is no CPU fallback") >= 1
     assert "torch.distributed" in res.stderr          # the ranks were started by the launcher
     assert not [ln for ln in res.stdout.split("\n") if ln.startswith("{")]     # and no line was fabricated
+
+
+def test_a_flag_change_rebuild_leaves_no_object_of_the_old_flags_behind(tmp_path, monkeypatch):
+    """thrifty_amd/build.py: when THR_EXTRA_CFLAGS differ from the stamp, every object and the
+    library go BEFORE anything is compiled and the stamp is written LAST, after the link -- an
+    interrupted rebuild is still seen as 'flags differ' by the next one, never linked from leftovers."""
+    import subprocess
+    from thrifty_amd import build
+    csrc = tmp_path / "csrc"
+    csrc.mkdir()
+    for name in build.SOURCES + [h for h in build.HEADERS if not h.startswith("..")]:
+        (csrc / name).write_text("// stub\n")
+    inc = tmp_path / "include"
+    inc.mkdir()
+    (inc / "thrifty_hip.h").write_text("// stub\n")
+    monkeypatch.setattr(build, "CSRC", str(csrc))
+    monkeypatch.setattr(build, "HEADERS", [h if not h.startswith("..") else str(inc / "thrifty_hip.h")
+                                           for h in build.HEADERS])
+    lib = tmp_path / "libthriftyhip.so"
+    monkeypatch.setattr(build, "LIB", str(lib))
+    for src in build.SOURCES:                                     # objects + library of the "old" flags
+        (csrc / src.replace(".hip", ".o")).write_text("old object")
+    lib.write_text("old library")
+    (csrc / ".build_flags").write_text("-DOLD")
+    seen = {}
+
+    class Boom(Exception):
+        pass
+
+    def fake_popen(cmd):
+        # the first compile of the rebuild: by now nothing of the old build may be left, and the
+        # stamp must not yet name the new flags
+        seen["objects"] = sorted(p.name for p in csrc.glob("*.o"))
+        seen["lib"] = lib.exists()
+        seen["stamp"] = (csrc / ".build_flags").exists()
+        raise Boom()                                              # ... and the rebuild is interrupted here
+
+    monkeypatch.setattr(subprocess, "Popen", fake_popen)
+    monkeypatch.setenv("THR_EXTRA_CFLAGS", "-DNEW")
+    with pytest.raises(Boom):
+        build.build_native()
+    assert seen == {"objects": [], "lib": False, "stamp": False}
+    assert build.needs_build()                                    # the next build starts from scratch again

@@ -1,6 +1,7 @@
 """Host-side stream behaviour that the reference has and a batching reader can lose:
 live pipes deliver per record (reference card_reader / block_reader return per line / per
 block, block_data.py:70-131), timestamps are per block, errors surface at their block."""
+import io
 import os
 import threading
 import time
@@ -35,6 +36,9 @@ def test_card_stream_on_a_live_pipe_returns_per_arrival():
                 w.write(ln)
                 time.sleep(0.3)
 
+    # (the framing routine lives in the engine library: load it BEFORE the clock starts -- the first
+    # dlopen of a 12 MB library can take longer than the 0.25 s this test allows the first line)
+    block_data.CardStream(io.BytesIO(lines[0]), 256).next_batch(4)
     th = threading.Thread(target=produce)
     t0 = time.perf_counter()
     th.start()
@@ -365,6 +369,44 @@ def test_defaults_follow_the_live_attribute():
     src = inspect.getsource(detect.Detector.__init__)
     assert "_UNKNOWN_FILL_S if live is None" in src and "_SLOW_SOURCE_S if live else" in src
     assert detect._UNKNOWN_FILL_S <= 0.1 and detect._SLOW_SOURCE_S <= 0.01
+
+
+def test_in_memory_sequences_count_as_not_live():
+    """A list / tuple / ndarray of blocks has no `.live` attribute but never has to be waited for:
+    it is read ahead of and fills whole batches (the docstring said so; the code treated it as
+    'does not say' -- 50 ms batches, no read-ahead)."""
+    import inspect
+    src = inspect.getsource(detect.Detector.__init__)
+    assert "isinstance(blocks, (list, tuple, np.ndarray))" in src
+    assert src.index("isinstance(blocks, (list, tuple, np.ndarray))") < src.index("self._known_not_live =")
+
+
+def test_an_index_error_leaves_no_stale_read_error_and_no_locked_window():
+    """After the IndexError block ended the iteration, an error the read-ahead had parked (it
+    belongs to blocks BEHIND the one that ended the loop) must not surface on the next call, and a
+    page-locked input must be let go: next() -> StopIteration, window closed."""
+    recs = np.zeros(8, dtype=_native.RECORD_DTYPE)
+    recs["flags"] = [3, 3, 4, 3, 3, 3, 3, 3]
+    recs["carrier_bin"] = 62
+
+    def source():
+        for i in range(6):
+            yield float(i), i, np.zeros(64, dtype=np.complex64)
+        raise ValueError("malformed .card line far behind the block that ended the loop")
+
+    d = _bare_detector(recs, source(), batch_size=3)
+    closed = []
+    d._engine.input_window = lambda buf=None, **kw: closed.append(buf)
+    d._pin = True
+    out = []
+    with pytest.raises(IndexError):
+        for det, res in d:
+            out.append(res.block)
+    assert out == [0, 1]
+    with pytest.raises(StopIteration):
+        next(d)                             # not the parked ValueError
+    assert d._read_error is None and closed == [None] and not d._pin
+    assert d._engine.open == 0
 
 
 def test_an_error_in_the_read_ahead_does_not_swallow_the_batch_before_it():
