@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Benchmark of the `thrifty detect` hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3] [--templates T]
-                    [--batch B] [--mix dense|sparse]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c1] [--templates T]
+                    [--batch B] [--mix dense|sparse] [--scaling weak|strong]
 
 One "step" = one pass of the hot path (FFT -> carrier detect -> fit -> shift ->
 FFT -> x conj(T) -> IFFT -> SoA) over one batch of synthetic IQ blocks that are
@@ -10,23 +10,34 @@ already resident in HBM.  A step's batch is R launch batches of B blocks (B = th
 engine's max_batch, 32768 at N = 16384); R is chosen after a calibration burst so
 that the K timed steps last at least --min-seconds (default 2 s: a sustained rate
 on a part that clocks to its power budget, not a 40 ms burst).  The default run
-then adds bounded legs for the other single-GPU configs (`configs`: c3, t4,
-sparse), each with its own recomputable roofline.  Workloads (BASELINE.json `configs`):
+then adds bounded legs for the other single-GPU configs (`configs`: c3, t4, sparse,
+fullwin, c3t4, c1, c1_sparse), each with its own recomputable roofline figures, the CPU
+baseline, and the file legs (.card / raw file -> .toad).  Workloads (BASELINE.json `configs`):
 
   --config c2 (default, the headline): configs[1] -- block_len 16384, history 4096,
       1023-chip Gold template, K*B (default 32 * 32768 = 1 Mi) blocks per GPU
   --config c2 --templates 4: configs[4] in its 1-GPU form -- 4 TX Gold templates per block
   --config c3: configs[2] -- block_len 65536, history 4096, 2047-chip Gold code at 2 samples
       per chip (W = 4094), the long-FFT regime (a block does not fit the LDS)
+  --config c1: configs[0]'s geometry kernel-resident -- the example detector.cfg (history 4920,
+      the 4914-sample extracted template; tests/golden/c1.npz holds both)
+
+Output: ONE JSON line on stdout, < 7 KB (the driver keeps the last 8 KB): the contract keys,
+`roofline` and `cpu_baseline` as flat objects, `configs` with the agreed compact keys per leg, and
+LAST a flat `summary` of every leg's blocks/s.  Everything else (every kernel's mean duration per
+leg, the VALU view, workload prose, the file loops' time budget) goes to
+gpurun_out/bench_detail_<config>_n<N>.json and to stderr.
 
 Metric: IQ blocks/s, whole job.  For N > 1 the driver launches
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
-and a plain `python bench.py --gpus N` starts exactly that by itself.  Blocks are sharded by
-contiguous block-index ranges (weak scaling: K*B blocks per GPU); the only collective is the
-gather of detection records to rank 0.  `--dist-backend gloo` rehearses the whole N-rank body
-(pre-flight, step-size broadcast, MAX all-reduce of the time, record gather) on ONE GPU: every
-rank computes on cuda:0 and the collectives carry CPU tensors.
+and a plain `python bench.py --gpus N` starts exactly that by itself; both routes apply the same
+rank environment first (parallel.rank_env).  Blocks are sharded by contiguous block-index ranges
+(weak scaling: K*B blocks per GPU; --scaling strong: one GPU's job split over the ranks); the only
+collective is the gather of detection records to rank 0, rehearsed in the pre-flight.
+`--dist-backend gloo` rehearses the whole N-rank body (pre-flight, gather rehearsal, step-size
+broadcast, MAX all-reduce of the time, record gather) on ONE GPU: every rank computes on cuda:0
+and the collectives carry CPU tensors.
 """
 from __future__ import annotations
 
