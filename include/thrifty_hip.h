@@ -384,6 +384,15 @@ int thr_submit_card(thr_handle* h, const char* text, size_t text_len, const int6
 int thr_submit_stream(thr_handle* h, const uint8_t* stream, size_t n_bytes, int64_t first_block_idx,
                       thr_record* out, size_t out_capacity, size_t* n_blocks_out, uint64_t* ticket);
 int thr_collect(thr_handle* h, uint64_t ticket);
+/*
+ * How thr_collect (and the drains of the synchronous host entry points, and thr_run_*) wait for a
+ * batch: 0 (default) = hipEventSynchronize -- the HIP runtime polls, the calling thread is busy for
+ * the length of the wait: lowest latency, one CPU per handle; 1 = ask (hipEventQuery) and nap 40 us
+ * in between -- for hosts whose CPUs are shared by several ranks (eight ranks on a 16-CPU cgroup:
+ * eight polling threads would take half of it from the ranks' text and page-locking threads).  With
+ * batches in flight ahead of the one waited for, the naps cost no throughput.
+ */
+int thr_set_wait_mode(thr_handle* h, int sleeping);
 int thr_inputs_consumed(thr_handle* h, uint64_t ticket);
 int thr_poll(thr_handle* h, uint64_t ticket, int* done);
 

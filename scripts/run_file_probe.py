@@ -55,12 +55,15 @@ win = tuple(int(v) for v in g["carrier_window"])
 out_fd = os.open(os.devnull, os.O_WRONLY)
 
 
-def run(batch, pop, seg, window=True, path=None):
+def run(batch, pop, seg, window=True, path=None, sleepy=False):
     path = path or file_a
     size = os.path.getsize(path)
     t_c = time.perf_counter()
     eng = F.Engine(n, h, tpl, thr, win, tuple(float(v) for v in g["corr_thresh"]), max_batch=batch)
     t_c = time.perf_counter() - t_c
+    if sleepy:
+        eng.set_wait_mode(True)
+        print("sleeping waits; ", end="")
     cpu0 = time.process_time()
     with open(path, "rb") as f:
         mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
@@ -101,6 +104,7 @@ run(2048, 3, 128 << 20, path=file_b)
 run(2048, 3, 128 << 20)
 for pop in (1, 2):
     run(2048, pop, 128 << 20)
+run(2048, 1, 128 << 20, sleepy=True)       # a rank of eight on a 16-CPU host
 for seg in (32 << 20, 256 << 20):
     run(2048, 3, seg)
 run(4096, 3, 128 << 20)

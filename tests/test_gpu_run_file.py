@@ -57,6 +57,10 @@ def test_card_file_through_the_library_loop_equals_the_python_loop_and_the_golde
     open(path, "wb").write(text.encode())
     st = settings_of(g)
     got, stats = library_loop(st, path, lambda f: CardStream(f, n), rxid=3, batch_size=batch)
+    # (a rank on a node short of CPUs: one populator, waits that nap instead of polling -- same bytes)
+    lean, _ = library_loop(st, path, lambda f: CardStream(f, n), rxid=3, batch_size=batch, populate_threads=1,
+                           low_cpu=True)
+    assert lean == got
     want = python_loop_text(st, CardStream(io.BytesIO(text.encode()), n), rxid=3, batch_size=batch)
     assert got == want and got.count(b"\n") == stats["detections"] > 0
     assert stats["blocks"] == len(lines) and stats["calls"][-1]["batches"] == -(-len(lines) // batch)

@@ -30,7 +30,7 @@ EXPORTS = [
     "thr_debug_stage", "thr_identify", "thr_frame_card",
     "thr_submit", "thr_submit_card", "thr_submit_stream", "thr_collect", "thr_inputs_consumed", "thr_poll",
     "thr_set_stream_default", "thr_format_toad",
-    "thr_run_card", "thr_run_stream", "thr_get_settings", "thr_input_window_ex", "thr_input_window_release", "thr_detect_offsets", "thr_debug_window", "thr_debug_window_times", "thr_debug_correlate_geom", "thr_debug_pipe_times",
+    "thr_run_card", "thr_run_stream", "thr_get_settings", "thr_input_window_ex", "thr_input_window_release", "thr_detect_offsets", "thr_set_wait_mode", "thr_debug_window", "thr_debug_window_times", "thr_debug_correlate_geom", "thr_debug_pipe_times",
 ]
 ERR_ARG, ERR_DEVICE, ERR_STATE, ERR_INDEX = -1, -2, -3, -4       # THR_ERR_*
 VARIANT_DEFAULT, VARIANT_PRESHIFT, VARIANT_FASTDET = 0, 1, 2      # THR_VARIANT_*
@@ -606,6 +606,12 @@ class Engine(object):
         _check(self._lib, self._lib.thr_debug_window_times(self._h, out))
         keys = ("populate_s", "register_s", "unregister_s", "acquire_wait_s", "acquire_waits", "pageable_copies")
         return dict(zip(keys, (float(v) for v in out)))
+
+    def set_wait_mode(self, sleeping):
+        """thr_set_wait_mode: True = collect() naps between queries of the batch's event instead of
+        polling it (a CPU per rank saved on hosts shared by several ranks)."""
+        self._lib.thr_set_wait_mode.argtypes = [C.c_void_p, C.c_int]
+        _check(self._lib, self._lib.thr_set_wait_mode(self._h, int(bool(sleeping))))
 
     def collect(self, ticket):
         """thr_collect: wait for the ticket's batch -> its records [B, n_templates]."""

@@ -400,6 +400,7 @@ struct thr_handle {
     // array; nullptr = the Dirichlet fit), and the staging behind it
     const double* forced = nullptr;
     double* d_forced = nullptr;
+    bool sleepy_waits = false;   // thr_set_wait_mode: wait for a batch by query + short sleeps, not by polling
     double t_pipe[8] = {};
     double t_pipe_max[8] = {};   // the longest single occurrence of each phase
 
@@ -713,11 +714,34 @@ int pipe_grow(void** buf, size_t* have, size_t need) {
     return THR_OK;
 }
 
+// Wait for an event.  hipEventSynchronize polls (the calling thread stays busy for the length of the
+// wait, whatever flags the event was created with -- measured); on a host whose CPUs are shared by
+// several ranks that is a CPU per rank taken from the ranks' text and page-locking threads.  The
+// sleeping form asks and naps: three batches are in flight, so a nap of 40 us in front of a 1.3 ms
+// wait costs the pipeline nothing.
+int wait_event(thr_handle* h, hipEvent_t ev) {
+    if (!h->sleepy_waits) {
+        HIP_TRY(hipEventSynchronize(ev));
+        return THR_OK;
+    }
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) return THR_OK;
+        if (e != hipErrorNotReady)
+            return fail(THR_ERR_DEVICE, "hipEventQuery failed: %s", hipGetErrorString(e));
+        (void)hipGetLastError();          // (hipErrorNotReady is sticky in hipGetLastError)
+        std::this_thread::sleep_for(std::chrono::microseconds(40));
+    }
+}
+
 // hand the finished chunk of buffer b to the caller (waits for it); THR_OK if nothing is pending
 int pipe_drain(thr_handle* h, int b) {
     auto& p = h->hp;
     if (p.pend_n[b] == 0) return THR_OK;
-    HIP_TRY(hipEventSynchronize(p.ev_done[b]));
+    {
+        const int wrc = wait_event(h, p.ev_done[b]);
+        if (wrc != THR_OK) return wrc;
+    }
     pipe_inputs_done(h, b);
     std::memcpy(p.pend_dst[b], p.h_rec[b], p.pend_n[b] * sizeof(thr_record));
     const size_t n = p.pend_n[b], first = p.pend_first[b];
@@ -1458,6 +1482,12 @@ void thr_destroy(thr_handle* h) {
         if (b) (void)hipFree(b);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
+}
+
+int thr_set_wait_mode(thr_handle* h, int sleeping) {
+    if (!h) return fail(THR_ERR_ARG, "thr_set_wait_mode: null handle");
+    h->sleepy_waits = sleeping != 0;
+    return THR_OK;
 }
 
 int thr_get_settings(const thr_handle* h, thr_settings* out) {

@@ -170,7 +170,7 @@ class Detector(object):
 
     def __init__(self, settings, blocks=None, rxid=-1, yield_data=False, batch_size=None,
                  device_id=0, _preshift_num=0, _fastdet=False, max_wait=None, max_fill=None,
-                 pin_input=True, _interpolator="parabolic", _path="auto", populate_threads=0):
+                 pin_input=True, _interpolator="parabolic", _path="auto", populate_threads=0, low_cpu=False):
         """Batching a classic `(timestamp, idx, block)` iterator must not hold results back the way
         the reference's per-block loop never did.  What ends the batch being filled (what has
         arrived is processed instead of waiting for a full batch) depends on what the source says
@@ -187,7 +187,9 @@ class Detector(object):
         `max_wait` / `max_fill` given explicitly apply to any source.  `pin_input`: page-lock a
         mapped input file ahead of the copies while it is read (thr_input_window; best effort);
         `populate_threads`: the library threads that map its pages ahead of the locking (0 = the
-        library's default; a rank of a sharded run passes parallel.populate_threads(world))."""
+        library's default; a rank of a sharded run passes parallel.populate_threads(world));
+        `low_cpu`: wait for batches by asking and napping instead of polling (thr_set_wait_mode: about
+        half a CPU less per detector, what a rank takes when the node's CPUs are short)."""
         if batch_size is None:      # ~64 MiB of u8 samples per engine batch (the staging chunk size)
             batch_size = max(64, min(65536, (64 << 20) // (2 * int(settings.block_len))))
             if yield_data:          # every block of a batch holds two N-point stage dumps in _ready
@@ -221,6 +223,8 @@ class Detector(object):
             settings.carrier_window, settings.corr_thresh, carrier_len=settings.carrier_len,
             device_id=device_id, max_batch=self.batch_size, preshift_num=_preshift_num,
             fastdet=_fastdet, interpolator=_interpolator, path=_path)
+        if low_cpu:
+            self._engine.set_wait_mode(True)
         # a mapped input file becomes the engine's input window: a library thread page-locks it a
         # bounded distance ahead of the chunk copies, which are then asynchronous DMA out of the
         # page cache -- this thread frames the next batch and formats the previous one meanwhile
@@ -781,12 +785,12 @@ class MultiTemplateDetector(Detector):
     _multi = True
 
     def __init__(self, settings, blocks=None, rxid=-1, yield_data=False, batch_size=None,
-                 device_id=0, max_wait=None, populate_threads=0):
+                 device_id=0, max_wait=None, populate_threads=0, low_cpu=False):
         if yield_data:
             raise TypeError("stage dumps (yield_data) are a single-template facility")
         super(MultiTemplateDetector, self).__init__(settings, blocks, rxid=rxid, batch_size=batch_size,
                                                     device_id=device_id, max_wait=max_wait,
-                                                    populate_threads=populate_threads)
+                                                    populate_threads=populate_threads, low_cpu=low_cpu)
         self.n_templates = int(np.asarray(settings.template).shape[0])
 
     def _flat(self, stamps, idxs, recs):
@@ -971,6 +975,7 @@ def detector_cli(detector_class, parser=None, extra_args=None, argv=None):
         blocks.shard(rank, world)
         if "populate_threads" not in kwargs and detector_class in (Detector, MultiTemplateDetector):
             kwargs["populate_threads"] = parallel.populate_threads(world)   # the ranks share the host's CPUs
+            kwargs["low_cpu"] = parallel.cpu_budget() // max(1, world) < 4  # (fewer than 4 CPUs per rank)
         detections = detector_class(settings, blocks, rxid=config.rxid, device_id=local, **kwargs)
         if not hasattr(detections, "iter_detected_records"):
             raise SystemExit("--gpus: %s does not expose iter_detected_records() (the records that "
