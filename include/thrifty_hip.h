@@ -34,7 +34,8 @@ extern "C" {
  *    thr_host_register / thr_host_unregister, thr_input_window (additions only).
  *    No environment variable changes what a handle computes or how it schedules any more. */
 /* 7: + thr_run_card / thr_run_stream (the whole file -> .toad loop in one call, text on a library
- *    thread), thr_get_settings, thr_input_window_ex (populator threads / segment size), THR_ERR_INDEX
+ *    thread), thr_get_settings, thr_input_window_ex (populator threads / segment size) / _release,
+ *    thr_detect_offsets, thr_set_wait_mode, THR_PATH_GENERIC_ROWS, THR_ERR_INDEX, THR_FLAG_INT_OFFSET
  *    (additions only) */
 #define THR_ABI_VERSION 7
 
