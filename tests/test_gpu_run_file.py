@@ -85,6 +85,41 @@ def test_four_templates_txid_column_and_order(golden, tmp_path):
     assert keys == sorted(keys)                                     # [block][template] order
 
 
+@pytest.mark.parametrize("interp", ["parabolic", "none", "cosine"])
+def test_preshift_detector_files_take_the_library_loop_too(golden, tmp_path, interp):
+    """The variants are engine handles like any other: PreshiftDetector's float32 carrier offset
+    (printed widened), interpolator `none`'s int 0 and cosine's early `return 0` come out of
+    thr_run_card's formatter exactly as out of the Python loop."""
+    from thrifty_amd.experimental.detect_preshift import PreshiftDetector
+    g = golden("c2")
+    st = settings_of(g)
+    text = card_text(g)
+    if interp == "cosine":      # some blocks with a stronger bin just below the window: the int-0 branch
+        rng = np.random.default_rng(3)
+        tpl, n = np.asarray(g["template"], dtype=np.float64), 16384
+        extra = []
+        for k, car in enumerate((6.15, 6.24, 6.41)):
+            p = int(rng.integers(1537, 13825))
+            z = rng.normal(0, 0.02, n) + 1j * rng.normal(0, 0.02, n) + 0.08 * np.exp(2j * np.pi * car * np.arange(n) / n)
+            z[p:p + len(tpl)] += 0.3 * (tpl + 1) / 2 * np.exp(2j * np.pi * car * (np.arange(len(tpl)) + p) / n)
+            extra.append(block_data.card_line(2000.0 + k, 500 + k, synth.quantise_iq(z)))
+        text += "".join(extra)
+    path = str(tmp_path / "rx.card")
+    open(path, "wb").write(text.encode())
+    got, stats = library_loop(st, path, lambda f: CardStream(f, 16384), cls=PreshiftDetector, rxid=2, num=21,
+                              interpolator=interp, batch_size=6)
+    want = python_loop_text(st, CardStream(io.BytesIO(text.encode()), 16384), cls=PreshiftDetector, rxid=2,
+                            num=21, interpolator=interp, batch_size=6)
+    assert got == want and stats["detections"] >= 18
+    offsets = [ln.split()[9] for ln in got.decode().strip().split("\n")]
+    if interp == "none":
+        assert set(offsets) == {"0"}
+    elif interp == "cosine":
+        assert offsets.count("0") == 2 and all("." in o for o in offsets if o != "0")
+    else:
+        assert all("." in o and float(np.float32(float(o))) == float(o) for o in offsets)   # widened float32
+
+
 @pytest.mark.parametrize("n,h,bits,sps,batch", [(16384, 4096, 10, 1.0, 4), (16384, 4920, 10, 1.0, 64),
                                                 (65536, 4098, 11, 2.0, 3), (4096, 1024, 9, 1.0, 7)])
 def test_raw_file_through_the_library_loop_equals_the_python_loop(tmp_path, n, h, bits, sps, batch):
