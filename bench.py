@@ -791,10 +791,14 @@ def main():
     # then runs through the same collectives as the multi-GPU case
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
     if use_dist:
+        # (a rank that dies must not leave its peers waiting for the default half hour: five minutes
+        # cover the slowest phase, 32 GiB of synthetic blocks per rank, many times over)
+        import datetime
+        limit = datetime.timedelta(minutes=5)
         if gloo:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=limit)
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=limit)
 
     K, W, T = args.steps, args.warmup, args.templates
     pnum = args.preshift_num if args.variant == "preshift" else 0

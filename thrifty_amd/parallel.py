@@ -246,7 +246,7 @@ def run_sharded(detections, rank, world, local, output_file, backend="nccl"):
         dev = torch.device("cuda", local)
         torch.cuda.set_device(dev)
         if not dist.is_initialized():
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev)      # (default timeout: a rank's shard may be hours of capture)
     else:
         dev = torch.device("cpu")
         if not dist.is_initialized():
