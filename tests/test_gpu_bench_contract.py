@@ -117,7 +117,7 @@ SHORT = ["--steps", "2", "--warmup", "1", "--min-seconds", "0.2", "--legs", "non
          "--resident-blocks", "65536"]
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_gpus_n_launches_itself_and_the_whole_n_rank_body_runs_over_gloo(world):
     """`python bench.py --gpus N` with no torchrun around it: the script starts its own ranks.
     --dist-backend gloo puts every rank on cuda:0, so pre-flight, the step-size broadcast, the MAX
@@ -130,6 +130,7 @@ def test_gpus_n_launches_itself_and_the_whole_n_rank_body_runs_over_gloo(world):
                          cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     d = _one_line(res)
     _check_dist_line(d, world, "gloo")
+    assert res.stdout.strip().split("\n")[-1].startswith("{")       # the contract line is the LAST line
     assert "pre-flight ok: backend gloo, %d rank(s)" % world in res.stderr
     # the environment of every rank and the gather rehearsal (uneven counts, an empty rank) are on record
     for r in range(world):

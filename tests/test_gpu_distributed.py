@@ -116,6 +116,38 @@ def test_thrifty_detect_gpus_cli_writes_the_single_process_toad(golden, tmp_path
     assert_toad_close((tmp_path / "one.toad").read_text().strip().split("\n"), g["toad"])
 
 
+@pytest.mark.parametrize("k,raw", [(8, False), (3, True)])
+def test_the_cli_with_more_ranks_than_gpus_rehearsed_over_gloo(golden, tmp_path, k, raw):
+    """`python -m thrifty_amd.detect --gpus 8 --dist-backend gloo rx.card -o rx.toad` on the one-GPU
+    box: the CLI re-launches itself, eight ranks shard the file (each through the library loop with
+    a record sink, one populator and napping waits where CPUs are short), the gather rehearsal and
+    the gather run over gloo, rank 0 writes ONE file -- the single-process file, byte for byte."""
+    from thrifty_amd.detect import Detector, detector_cli
+    g = golden("c2")
+    _write_case(tmp_path, g)
+    src = str(tmp_path / "rx.card")
+    extra = []
+    if raw:     # the same blocks' NEW samples as a raw stream (block i = previous tail + these)
+        n, h = 16384, 4096
+        step = 2 * (n - h)
+        with open(tmp_path / "rx.bin", "wb") as f:
+            for i in range(60):
+                f.write(np.ascontiguousarray(g["blocks"][i % len(g["blocks"])][-step:]).tobytes())
+        src, extra = str(tmp_path / "rx.bin"), ["--raw"]
+    common = [src, "--quiet", "-c", str(tmp_path / "detector.cfg")] + extra
+    detector_cli(Detector, argv=common + ["-o", str(tmp_path / "one.toad")])
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "THRIFTY_SHARDED"):
+        env.pop(key, None)
+    res = subprocess.run([sys.executable, "-m", "thrifty_amd.detect", "--gpus", str(k), "--dist-backend", "gloo"]
+                         + common + ["-o", str(tmp_path / "many.toad")], env=env, cwd=ROOT, capture_output=True,
+                         text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    one, many = (tmp_path / "one.toad").read_text(), (tmp_path / "many.toad").read_text()
+    strip = (lambda t: [" ".join(ln.split()[:1] + ln.split()[2:]) for ln in t.strip().split("\n")]) if raw else (lambda t: t)
+    assert strip(many) == strip(one) and len(one.strip().split("\n")) >= 15      # (raw: wall-clock stamps differ)
+
+
 def test_thrifty_detect_raw_gpus_cli_equals_single_process(tmp_path):
     """`--raw --gpus 1` under torchrun (block-range sharding of a raw u8 stream, lead-in blocks on
     rank 0) writes the same .toad as the single-process CLI, and detects the planted bursts."""

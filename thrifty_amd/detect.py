@@ -930,6 +930,10 @@ def detector_cli(detector_class, parser=None, extra_args=None, argv=None):
                         help="do not write anything to standard output")
     parser.add_argument("--gpus", dest="gpus", type=int, default=1,
                         help="shard a regular input file over this many GPUs of the node")
+    parser.add_argument("--dist-backend", dest="dist_backend", choices=["nccl", "gloo"], default="nccl",
+                        help="with --gpus N: nccl = RCCL, one GPU per rank (the real thing); gloo = a "
+                             "rehearsal of the N-rank run on ONE GPU (every rank computes on device 0, "
+                             "the records travel over gloo)")
     parser.add_argument("--templates", dest="templates", nargs="+", metavar="NPY", default=None,
                         help="correlate every block against several TX templates (.npy files of "
                              "equal length, instead of the `template` setting); detections carry "
@@ -976,11 +980,13 @@ def detector_cli(detector_class, parser=None, extra_args=None, argv=None):
         if "populate_threads" not in kwargs and detector_class in (Detector, MultiTemplateDetector):
             kwargs["populate_threads"] = parallel.populate_threads(world)   # the ranks share the host's CPUs
             kwargs["low_cpu"] = parallel.cpu_budget() // max(1, world) < 4  # (fewer than 4 CPUs per rank)
+        if args.dist_backend == "gloo":
+            local = 0               # rehearsal: every rank computes on device 0
         detections = detector_class(settings, blocks, rxid=config.rxid, device_id=local, **kwargs)
         if not hasattr(detections, "iter_detected_records"):
             raise SystemExit("--gpus: %s does not expose iter_detected_records() (the records that "
                              "travel between the ranks)" % type(detections).__name__)
-        parallel.run_sharded(detections, rank, world, local, output_file)
+        parallel.run_sharded(detections, rank, world, local, output_file, backend=args.dist_backend)
         return
     detections = detector_class(settings, blocks, rxid=config.rxid, **kwargs)
     if args.quiet and hasattr(detections, "only_detections"):
