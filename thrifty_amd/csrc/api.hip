@@ -100,12 +100,15 @@ struct EventPair {
 }  // namespace
 
 // thr_input_window(): a caller mapping (the input file) that the host entry points read
-// sequentially.  A worker thread page-locks it one 128 MiB segment at a time, a bounded distance
-// ahead of the chunk copies, and unlocks what lies behind them: the copies are then asynchronous
-// DMA out of the page cache (they return at once instead of occupying the calling thread while the
-// runtime stages pageable memory), the locking itself -- 10 to 40 ms per GiB, as much host time as
-// the staging it replaces -- runs beside the caller instead of in front of it, and never more than
-// kAhead segments are locked whatever the size of the file.
+// sequentially.  Library threads keep a bounded stretch of it page-locked around the read position,
+// one segment (128 MiB) at a time: populators map the pages of the segments ahead, a locking worker
+// hipHostRegister()s them up to kAhead segments in front of the chunk copies, an unlocking worker
+// hipHostUnregister()s what the copies have left behind.  The copies are then asynchronous DMA out
+// of the page cache (they return at once instead of occupying the calling thread while the runtime
+// stages pageable memory), the locking -- 5 ms per GiB on mapped pages, 17 ms per GiB to unlock --
+// runs beside the caller instead of in front of it, and never more than 2 x kAhead segments are
+// locked whatever the size of the file.  (Round 5: locking and unlocking on ONE thread filled a
+// whole run -- the caller waited for locks queued behind unlocks; see profiles/README.md.)
 struct InputWindow {
     static constexpr size_t kSegDefault = size_t(128) << 20;
     static constexpr size_t kAheadBytes = size_t(1) << 30;   // the worker runs at most this far ahead of `consumed`
