@@ -162,3 +162,37 @@ def test_detect_offsets_entry_point(golden):
         a = e.detect_offsets(gg["blocks"], r["carrier_offset"], gg["block_idx"])[:, 0]
         keep = (r["flags"] & F.FLAG_INDEX_ERROR) == 0
         assert a[keep].tobytes() == r[keep].tobytes(), name
+
+
+@pytest.mark.parametrize("method,quiet", [("parabolic", True), ("cosine", False), ("dirichlet", True)])
+def test_the_references_command_line(golden, tmp_path, monkeypatch, capsys, method, quiet):
+    """`python -m thrifty_amd.experimental.detect_carrier_interpol --method M rx.card -o rx.toad`
+    (reference detect_carrier_interpol.py:43-59): a replaced interpolator takes the per-block loop
+    even under --quiet; the default `dirichlet` is the engine's own fit and takes the library loop."""
+    from thrifty_amd.experimental import detect_carrier_interpol as mod
+    from test_gpu_detector_api import assert_toad_close
+    src = golden("c2")
+    np.save(tmp_path / "template.npy", src["template"])
+    (tmp_path / "detector.cfg").write_text(
+        "rxid: 0\nsample_rate: 2.4M\nblock_size: 16384\nblock_history: 4096\n"
+        "carrier_window: 7 - 110\ncarrier_threshold: 15 * snr\ncorr_threshold: 15*snr\n"
+        "template: %s\n" % (tmp_path / "template.npy"))
+    (tmp_path / "rx.card").write_text(card_text(src))
+    argv = ["detect_carrier_interpol", str(tmp_path / "rx.card"), "-o", str(tmp_path / "rx.toad"),
+            "-c", str(tmp_path / "detector.cfg"), "--method", method] + (["--quiet"] if quiet else [])
+    monkeypatch.setattr("sys.argv", argv)
+    mod._main()
+    lines = (tmp_path / "rx.toad").read_text().strip().split("\n")
+    want = str(src["toad"] if method == "dirichlet" else golden("interpol_c2_" + method)["toad"])
+    if method == "dirichlet":
+        assert_toad_close(lines, want)
+    else:
+        ref = want.split("\n")
+        assert len(lines) == len(ref)
+        for a, b in zip(lines, ref):
+            fa, fb = a.split(), b.split()
+            assert fa[:3] == fb[:3] and fa[4] == fb[4] and fa[8] == fb[8]
+            np.testing.assert_allclose(float(fa[9]), float(fb[9]), atol=5e-5)
+            np.testing.assert_allclose([float(v) for v in fa[5:8]], [float(v) for v in fb[5:8]], rtol=1e-4, atol=1e-4)
+    out = capsys.readouterr().out
+    assert (out.strip() == "") == quiet                 # the per-block summary lines unless --quiet
