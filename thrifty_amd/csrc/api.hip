@@ -217,11 +217,7 @@ struct InputWindow {
         (void)hipSetDevice(device);
         std::unique_lock<std::mutex> lk(mu);
         while (!stop) {
-#ifdef THR_DEV_NO_UNLOCK   // dev A/B only: nothing is unlocked before the window closes
-            if (false) {
-#else
             if (reg_lo < std::min(consumed, reg_hi)) {
-#endif
                 const size_t sgm = reg_lo;
                 lk.unlock();
                 const double t0 = now_s();
