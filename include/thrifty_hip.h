@@ -542,6 +542,13 @@ int thr_debug_fft(thr_handle* h, const void* samples, int format, size_t n_block
 int thr_debug_stage(thr_handle* h, const void* samples, int format, size_t n_blocks,
                     int template_id, float* shifted_fft_out /* [n][block_len][2] */,
                     float* corr_out /* [n][block_len][2] */);
+/* thr_debug_stage_offsets: the same dump with the sub-bin carrier offsets GIVEN (NULL: the engine's
+ *   own fit), as thr_detect_offsets takes them -- what a replaced `soa_estimate.interpolate`
+ *   (reference experimental/detect_xcorr_interpol.py:36-62) looks at when `sync.interpolator` has
+ *   been replaced too. */
+int thr_debug_stage_offsets(thr_handle* h, const void* samples, int format, size_t n_blocks,
+                            int template_id, const double* carrier_offset /* [n] or NULL */,
+                            float* shifted_fft_out, float* corr_out);
 
 /*
  * identify: merge-side post-processing of detections (thrifty/identify.py:26-181) --

@@ -216,16 +216,100 @@ def clip_offset(v, lim=0.6):
     return -lim if v < -lim else lim if v > lim else v
 
 
-def soa_estimate(xhat, bank, coeffs):
-    """(CorrStage, corr)  (soa_estimator.py:78-92)."""
+def soa_estimate(xhat, bank, coeffs, interpolate=None):
+    """(CorrStage, corr)  (soa_estimator.py:78-92).  interpolate: None = the SoaEstimator's own
+    gaussian_interpolation, or what the reference's experiment assigns to `soa_estimate.interpolate`
+    (experimental/detect_xcorr_interpol.py:36-62), here called as (corr_mag, peak_idx, xhat)."""
     corr = despread(xhat, bank)
     mag = np.abs(corr)
     idx, peak = corr_peak(mag, bank.window)
     noise = corr_noise(xhat, bank, peak)
     thr = threshold_value(mag, coeffs, noise)
     det = bool(peak > thr)
-    off = clip_offset(log_parabola(mag, idx) if det else 0)
+    if interpolate is None:
+        off = clip_offset(log_parabola(mag, idx) if det else 0)
+    else:
+        off = clip_offset(interpolate(mag, idx, xhat) if det else 0)
     return CorrStage(det, idx, off, peak, noise, thr), corr
+
+
+# -- what the experiment offers for `interpolate`      (experimental/xcorr_interpolators.py)
+def xcorr_none(mag, idx, xhat=None):
+    """xcorr_interpolators.py:31-32."""
+    return 0
+
+
+def xcorr_parabolic(mag, idx, xhat=None):
+    """xcorr_interpolators.py:35-38: no edge rule, the three magnitudes as they are."""
+    a, b, c = mag[idx - 1], mag[idx], mag[idx + 1]
+    return 0.5 * (c - a) / (2 * b - a - c)
+
+
+def xcorr_gaussian(mag, idx, xhat=None):
+    """xcorr_interpolators.py:41-45."""
+    a, b, c = np.log(mag[idx - 1]), np.log(mag[idx]), np.log(mag[idx + 1])
+    return 0.5 * (c - a) / (2 * b - a - c)
+
+
+def xcorr_cosine(mag, idx, xhat=None):
+    """xcorr_interpolators.py:48-56."""
+    a, b, c = mag[idx - 1], mag[idx], mag[idx + 1]
+    cw = (a + c) / (2 * b)
+    if cw > 1:
+        return 0
+    w = np.arccos(cw)
+    return -np.arctan((a - c) / (2 * b * np.sin(w))) / w
+
+
+def xcorr_autocorr(template):
+    """xcorr_interpolators.py:59-92: the five magnitudes around the peak, delayed by `offset` through
+    their own spectrum, least-squares against the template's correlation with its on-off-keyed form
+    at the same five lags (sigma |lag| + 1, amplitude in [0.1, 2], offset in +-0.55)."""
+    import scipy.optimize
+    template = np.asarray(template)
+    ook = (template - template.min()) * 2
+    size = len(template)
+
+    def fit(mag, idx, xhat=None, n=2):
+        guess = clip_offset(xcorr_gaussian(mag, idx), 0.5)
+        lags = np.arange(-n, n + 1)
+        seen = mag[idx + lags]
+        want = np.zeros(len(lags), dtype=template.dtype)
+        for j, lag in enumerate(lags):
+            want[j] = np.sum(template[max(0, lag):min(size, size + lag)]
+                             * np.conj(ook)[max(0, -lag):min(size, size - lag)])
+        want *= np.sum(seen) / np.sum(want)
+        freqs = np.fft.fftfreq(len(seen))
+
+        def model(_x, amplitude, offset):
+            return amplitude * np.abs(np.fft.ifft(np.fft.fft(seen) * np.exp(2j * np.pi * offset * freqs)))
+
+        try:
+            popt, _ = scipy.optimize.curve_fit(model, lags, want, p0=(1, guess),
+                                               bounds=([0.1, -0.55], [2, 0.55]), sigma=np.abs(lags) + 1)
+        except RuntimeError:
+            return guess
+        return popt[1]
+
+    return fit
+
+
+def xcorr_maximise(template):
+    """IterativeSoaEstimator (detect_xcorr_interpol.py:20-34) with xcorr_interpolators.py:95-112: on
+    the template-long slice of ifft(xhat) at the peak, maximise the correlation with the template
+    delayed by a sub-sample offset in +-0.55, starting from the log-parabola's value."""
+    import scipy.optimize
+    spec = np.conj(np.fft.fft(template))
+
+    def refine(mag, idx, xhat):
+        signal = np.fft.ifft(xhat)
+        cross = np.fft.fft(signal[idx:idx + len(template)]) * spec
+        freqs = np.fft.fftfreq(len(cross))
+        res = scipy.optimize.minimize(lambda o: -np.abs(np.sum(cross * np.exp(2j * np.pi * o * freqs))),
+                                      xcorr_gaussian(mag, idx), bounds=[(-0.55, 0.55)])
+        return res.x[0]
+
+    return refine
 
 
 # --------------------------------------------------------------------------
@@ -239,12 +323,13 @@ class OracleDetector(object):
     running the reference once per template yields)."""
 
     def __init__(self, block_len, history_len, templates, carrier_thresh,
-                 carrier_window, corr_thresh, carrier_len=None, interpolator="dirichlet"):
+                 carrier_window, corr_thresh, carrier_len=None, interpolator="dirichlet", interpolate=None):
         """interpolator: "dirichlet" (the default Synchronizer's, carrier_sync.py:150-196), None (no
         sub-bin estimate, carrier_sync.py:66-68) or a callable (mag, peak_idx) -> offset -- what the
         reference's InterpolationDetector assigns to `sync.interpolator`
         (experimental/detect_carrier_interpol.py:17-40)."""
         self.interpolator = interpolator
+        self.interpolate = interpolate      # of the correlation peak: see soa_estimate()
         if isinstance(templates, np.ndarray) and templates.ndim == 1:
             templates = [templates]
         self.block_len = block_len
@@ -282,7 +367,7 @@ class OracleDetector(object):
                 out.append(BlockResult(False, None, car, None))
                 data.append((None, None))
                 continue
-            cs, corr = soa_estimate(xhat, bank, self.corr_thresh)
+            cs, corr = soa_estimate(xhat, bank, self.corr_thresh, self.interpolate)
             soa = self.new_len * block_idx + cs.sample + cs.offset
             out.append(BlockResult(cs.detected, soa, car, cs))
             data.append((xhat, corr))

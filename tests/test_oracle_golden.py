@@ -270,6 +270,52 @@ def test_replaced_interpolator_reproduces_the_references_interpolation_detector(
     assert "\n".join(lines) == str(g["toad"])
 
 
+XCORR = {"none": lambda t: onp.xcorr_none, "parabolic": lambda t: onp.xcorr_parabolic,
+         "gaussian": lambda t: onp.xcorr_gaussian, "cosine": lambda t: onp.xcorr_cosine,
+         "autocorr": onp.xcorr_autocorr, "maximise": onp.xcorr_maximise}
+XCORR_CASES = [("c2", "none"), ("c2", "parabolic"), ("c2", "cosine"), ("c2", "gaussian"), ("c2", "maximise"),
+               ("c1", "autocorr"), ("c1", "maximise"), ("c1", "parabolic")]
+
+
+@pytest.mark.parametrize("src_name,method", XCORR_CASES)
+def test_replaced_correlation_interpolator_reproduces_the_references_experiment(src_name, method):
+    """`soa_estimate.interpolate = fn` / IterativeSoaEstimator (reference experimental/
+    detect_xcorr_interpol.py:20-62): the oracle with the same interpolator reproduces the reference's
+    `.toad` text byte for byte (the three-point ones and `none`) or to the optimiser's tolerance, the
+    +-0.6 clip (c1 / parabolic hits it twice) and the int 0 of none()."""
+    g = np.load(os.path.join(GOLDEN_DIR, "xcorr_%s_%s.npz" % (src_name, method)), allow_pickle=False)
+    src = np.load(os.path.join(GOLDEN_DIR, src_name + ".npz"), allow_pickle=False)
+    assert str(g["src"]) == src_name and str(g["method"]) == method
+    orc = onp.OracleDetector(int(src["block_len"]), int(src["history_len"]), src["template"],
+                             tuple(src["carrier_thresh"]), tuple(int(v) for v in src["carrier_window"]),
+                             tuple(src["corr_thresh"]), interpolate=XCORR[method](src["template"]))
+    exact = method not in ("autocorr", "maximise")
+    lines = []
+    for i, raw in enumerate(src["blocks"]):
+        (res,) = orc.detect_u8(int(src["block_idx"][i]), raw)
+        assert res.carrier.bin == g["cbin"][i] and res.carrier.detected == g["carrier_det"][i]
+        assert res.detected == g["det"][i]
+        if not res.carrier.detected:
+            continue
+        assert res.carrier.offset == g["coff"][i] and res.corr.sample == g["sample"][i]
+        assert isinstance(res.corr.offset, int) == bool(g["soff_is_int"][i])
+        assert abs(res.corr.offset) <= 0.6
+        if exact:
+            assert res.corr.offset == g["soff"][i]
+        else:
+            np.testing.assert_allclose(res.corr.offset, g["soff"][i], atol=1e-6)
+        if res.detected:
+            lines.append(onp.toad_line(int(src["rxid"]), 1000.0 + i, int(src["block_idx"][i]), res))
+    if exact:
+        assert "\n".join(lines) == str(g["toad"])
+    if (src_name, method) == ("c1", "parabolic"):
+        assert (np.abs(g["soff"][g["det"]]) == 0.6).sum() == 2
+
+
+def test_the_fixture_generator_and_the_test_name_the_same_cases():
+    assert [list(c) for c in XCORR_CASES] == [list(c) for c in _declared("make_golden_xcorr.py", ["CASES"])["CASES"]]
+
+
 def _declared(generator, names):
     """Module-level list / dict literals of a fixture generator, read with `ast` -- the generators
     import the reference at import time, which exists in the build container only."""
@@ -292,6 +338,9 @@ def test_every_fixture_holds_exactly_the_keys_its_generator_writes():
     pre = _declared("make_golden_preshift.py", ["KEYS", "KEYS_OWN_BLOCKS", "KEYS_SHARED_BLOCKS"])
     ide = _declared("make_golden_identify.py", ["KEYS", "KEYS_AUTO", "KEYS_MAP"])
     itp = _declared("make_golden_interpol.py", ["KEYS"])
+    xco = _declared("make_golden_xcorr.py", ["KEYS", "CASES"])
+    assert sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN_DIR, "xcorr_*.npz"))) == sorted(
+        "xcorr_%s_%s.npz" % tuple(c) for c in xco["CASES"])
     seen = 0
     for path in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))):
         name = os.path.basename(path)[:-4]
@@ -301,6 +350,8 @@ def test_every_fixture_holds_exactly_the_keys_its_generator_writes():
             want = pre["KEYS"] + (pre["KEYS_SHARED_BLOCKS"] if shared else pre["KEYS_OWN_BLOCKS"])
         elif name.startswith("interpol_"):
             want = itp["KEYS"]
+        elif name.startswith("xcorr_"):
+            want = xco["KEYS"]
         elif name.startswith("identify_"):
             want = ide["KEYS"] + (ide["KEYS_MAP"] if name == "identify_map" else ide["KEYS_AUTO"])
         else:

@@ -27,7 +27,7 @@ EXPORTS = [
     "thr_abi_version", "thr_last_error", "thr_create", "thr_destroy", "thr_detect",
     "thr_create_preshift", "thr_create_fastdet", "thr_create_ex", "thr_plan_sections", "thr_host_register", "thr_host_unregister", "thr_input_window", "thr_detect_card", "thr_detect_stream", "thr_detect_stream_device", "thr_detect_device", "thr_sync", "thr_set_stream", "thr_compact_device",
     "thr_profile_enable", "thr_profile_read", "thr_kernel_name", "thr_debug_fft",
-    "thr_debug_stage", "thr_identify", "thr_frame_card",
+    "thr_debug_stage", "thr_debug_stage_offsets", "thr_identify", "thr_frame_card",
     "thr_submit", "thr_submit_card", "thr_submit_stream", "thr_collect", "thr_inputs_consumed", "thr_poll",
     "thr_set_stream_default", "thr_format_toad",
     "thr_run_card", "thr_run_stream", "thr_get_settings", "thr_input_window_ex", "thr_input_window_release", "thr_detect_offsets", "thr_set_wait_mode", "thr_debug_window", "thr_debug_window_times", "thr_debug_correlate_geom", "thr_debug_pipe_times",
@@ -186,6 +186,7 @@ def load_library():
     lib.thr_profile_read.argtypes = [vp, C.POINTER(C.c_double), i64p]
     lib.thr_debug_fft.argtypes = [vp, vp, C.c_int, C.c_size_t, vp]
     lib.thr_debug_stage.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_int, vp, vp]
+    lib.thr_debug_stage_offsets.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_int, vp, vp, vp]
     lib.thr_identify.argtypes = [C.c_int, C.c_size_t, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp, vp,
                                  vp, C.POINTER(C.c_size_t)]
     _lib = lib
@@ -678,11 +679,16 @@ class Engine(object):
                                                   out.ctypes.data))
         return out
 
-    def debug_stage(self, blocks, template_id=0):
+    def debug_stage(self, blocks, template_id=0, carrier_offset=None):
         a, fmt = self._as_input(blocks)
         xhat = np.zeros((a.shape[0], self.block_len), dtype=np.complex64)
         corr = np.zeros((a.shape[0], self.block_len), dtype=np.complex64)
-        _check(self._lib, self._lib.thr_debug_stage(self._h, a.ctypes.data, fmt, a.shape[0],
-                                                    template_id, xhat.ctypes.data,
-                                                    corr.ctypes.data))
+        off = None
+        if carrier_offset is not None:
+            off = np.ascontiguousarray(carrier_offset, dtype=np.float64)
+            if off.shape != (a.shape[0],):
+                raise ValueError("carrier_offset: one value per block")
+        _check(self._lib, self._lib.thr_debug_stage_offsets(self._h, a.ctypes.data, fmt, a.shape[0],
+                                                            template_id, off.ctypes.data if off is not None else None,
+                                                            xhat.ctypes.data, corr.ctypes.data))
         return xhat, corr

@@ -2261,7 +2261,14 @@ int thr_detect_offsets(thr_handle* h, const void* samples, int format, const int
 
 int thr_debug_stage(thr_handle* h, const void* samples, int format, size_t n_blocks,
                     int template_id, float* shifted_fft_out, float* corr_out) {
+    return thr_debug_stage_offsets(h, samples, format, n_blocks, template_id, nullptr, shifted_fft_out, corr_out);
+}
+
+int thr_debug_stage_offsets(thr_handle* h, const void* samples, int format, size_t n_blocks, int template_id,
+                            const double* carrier_offset, float* shifted_fft_out, float* corr_out) {
     if (!h || !samples) return fail(THR_ERR_ARG, "thr_debug_stage: null argument");
+    if (carrier_offset && h->preshift_num)
+        return fail(THR_ERR_ARG, "thr_debug_stage_offsets: the default detector only");
     if (format != THR_IN_U8 && format != THR_IN_C64) return fail(THR_ERR_ARG, "bad format %d", format);
     if (n_blocks > size_t(h->cfg.max_batch)) return fail(THR_ERR_ARG, "n_blocks exceeds max_batch");
     if (template_id < 0 || template_id >= h->cfg.n_templates) return fail(THR_ERR_ARG, "bad template_id");
@@ -2286,8 +2293,21 @@ int thr_debug_stage(thr_handle* h, const void* samples, int format, size_t n_blo
             rc = fail(THR_ERR_DEVICE, "staging failed");
             break;
         }
+        if (carrier_offset) {
+            if (!h->d_forced && hipMalloc(&h->d_forced, size_t(h->cfg.max_batch) * sizeof(double)) != hipSuccess) {
+                rc = fail(THR_ERR_DEVICE, "hipMalloc failed");
+                break;
+            }
+            if (hipMemcpyAsync(h->d_forced, carrier_offset, n_blocks * sizeof(double), hipMemcpyHostToDevice,
+                               h->stream) != hipSuccess) {
+                rc = fail(THR_ERR_DEVICE, "staging failed");
+                break;
+            }
+            h->forced = h->d_forced;
+        }
         rc = run_batch(h, h->d_in, format, nullptr, int(n_blocks), h->d_rec, nullptr, d_x, d_c,
                        template_id, false);
+        h->forced = nullptr;
         if (rc != THR_OK) break;
         if (shifted_fft_out &&
             hipMemcpyAsync(shifted_fft_out, d_x, dump_bytes, hipMemcpyDeviceToHost, h->stream) != hipSuccess) {

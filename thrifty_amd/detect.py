@@ -132,15 +132,41 @@ class _SoaStage(object):
     body of the reference's `Detector.detect` (detect.py:60-78).  Any other spectrum would have to be
     correlated from host memory, which the engine has no entry point for."""
 
+    _DEVICE = object()          # `interpolate` not assigned: the engine's log-parabola (k_finish)
+
     def __init__(self, det, settings, template, corr_len):
         self._det = det
+        self._interpolate = self._DEVICE
+        self.last_fft = None        # the shifted spectrum of the block a replaced `interpolate` is looking at
         self.template = template
         self.template_energy = float(np.sum(np.abs(template) ** 2))
         self.corr_len = corr_len
         self.thresh_coeffs = settings.corr_thresh
         self.window = unique_window(settings.block_len, settings.history_len, template.shape[-1])
 
+    @property
+    def interpolate(self):
+        """The correlation-peak interpolator (reference soa_estimator.py:74: `self.interpolate =
+        gaussian_interpolation`).  Assignable like the reference's (experimental/
+        detect_xcorr_interpol.py:62): any callable `(corr_mag, peak_idx) -> offset`, evaluated on the
+        HOST for the detected blocks of a batch -- a slow path for analysis scripts."""
+        return self._device_interpolate if self._interpolate is self._DEVICE else self._interpolate
+
+    @interpolate.setter
+    def interpolate(self, fn):
+        if not callable(fn):
+            raise TypeError("soa_estimate.interpolate takes a callable (corr_mag, peak_idx) -> offset")
+        self._det._use_host_soa_interpolator()
+        self._interpolate = fn
+
+    def _device_interpolate(self, corr_mag, peak_idx):
+        raise NotImplementedError("the log-parabola runs inside the engine (k_finish): call "
+                                  "soa_estimate(shifted_fft) -- or assign soa_estimate.interpolate a host callable")
+
     def soa_estimate(self, fft):
+        if self._interpolate is not self._DEVICE:
+            raise NotImplementedError("soa_estimate(fft) evaluates the engine's own stages; with a replaced "
+                                      "interpolator use Detector.detect(timestamp, block_idx, block)")
         last = self._det.sync._last
         if last is None or fft is not last[0]:
             raise NotImplementedError(
@@ -167,6 +193,13 @@ class Detector(object):
     _offset_type = float      # CarrierSyncInfo.offset as the reference types it
     _multi = False            # MultiTemplateDetector: settings.template is [n_templates, len]
     _host_interp = False      # `sync.interpolator` has been assigned: the two-pass slow path
+    _host_soa = False         # `soa_estimate.interpolate` has been assigned: the correlation comes to the host
+
+    @property
+    def _host_path(self):
+        """A stage has been replaced by a host callable: batches run one at a time through
+        _detect_batch_host (no tickets, no device ingest, no library loop)."""
+        return self._host_interp or self._host_soa
 
     def __init__(self, settings, blocks=None, rxid=-1, yield_data=False, batch_size=None,
                  device_id=0, _preshift_num=0, _fastdet=False, max_wait=None, max_fill=None,
@@ -248,7 +281,7 @@ class Detector(object):
         corr_len = settings.block_len - template.shape[-1] + 1
         # twins of the reference's sub-objects (detect.py:46-58): the same attributes, and CALLABLE
         # like them -- evaluated by the engine, one block at a time (_SyncStage / _SoaStage below)
-        self._host_interp = False   # sync.interpolator has been assigned: the slow path below
+        self._host_interp = self._host_soa = False   # a stage replaced by a host callable: the slow path below
         self.sync = _SyncStage(self, settings)
         self.soa_estimate = _SoaStage(self, settings, template, corr_len)
 
@@ -331,7 +364,7 @@ class Detector(object):
         in flight the synchronous entry point would refuse to run (thr_detect waits for open
         tickets to be collected), so a direct detect() between two next() calls rides the
         ticket interface too."""
-        if not self._ahead or self.yield_data or self._host_interp:
+        if not self._ahead or self.yield_data or self._host_path:
             return self._engine.detect(arr, idx)
         step = self.batch_size
         return np.concatenate([self._engine.collect(self._engine.submit(arr[s:s + step], idx[s:s + step]))
@@ -342,12 +375,23 @@ class Detector(object):
         """`sync.interpolator = fn` was assigned (reference experimental/detect_carrier_interpol.py:
         17-40): from here on every batch makes two engine passes with the callable in between, one
         batch at a time, blocks pulled through the classic per-block iterator."""
-        if self._engine.preshift_num or self._multi or self.yield_data:
-            raise NotImplementedError("a replaced interpolator is offered by the default single-template "
-                                      "Detector (this variant interpolates inside its fused kernel)")
-        if self._ahead or self._ready:
-            raise RuntimeError("assign sync.interpolator before iterating")
+        self._enter_host_path("sync.interpolator")
         self._host_interp = True
+
+    def _use_host_soa_interpolator(self):
+        """`soa_estimate.interpolate = fn` was assigned (reference experimental/detect_xcorr_interpol.py:
+        36-62): the engine's verdicts and peak stay, the correlation magnitudes of the detected blocks
+        come to the host (stage dump) and the callable `(corr_mag, peak_idx) -> offset` replaces the
+        log-parabola; the offset is clipped to +-0.6 like the reference's (soa_estimator.py:87-89)."""
+        self._enter_host_path("soa_estimate.interpolate")
+        self._host_soa = True
+
+    def _enter_host_path(self, what):
+        if self._engine.preshift_num or self._multi or self.yield_data:
+            raise NotImplementedError("a replaced %s is offered by the default single-template Detector "
+                                      "(the variants interpolate inside their fused kernels)" % what)
+        if self._ahead or self._ready:
+            raise RuntimeError("assign %s before iterating" % what)
         self._card = self._raw = None          # (the readers also iterate as (timestamp, idx, block))
         if self._pin:
             self._engine.input_window(None)
@@ -360,37 +404,72 @@ class Detector(object):
         blocks that carry a carrier; engine pass 2 with those offsets (thr_detect_offsets).  An
         exception of the callable (IndexError at the spectrum's end, like the reference's own
         interpolators) belongs to its block: the results before it still come out, then it is raised."""
-        fn = self.sync._interpolator
         arr = self._stack([it[2] for it in items])
         idx = np.array([int(it[1]) for it in items], dtype=np.int64)
-        first = self._engine.detect(arr, idx)[:, 0]
-        has = (first["flags"] & (_native.FLAG_CARRIER | _native.FLAG_INDEX_ERROR)) != 0
-        spectra = self._engine.debug_fft(arr) if has.any() and fn is not None else None
-        vals, error, n_ok = [0] * len(items), None, len(items)
-        for i in np.flatnonzero(has).tolist():
-            if fn is None:
-                continue                        # `if self.interpolator is not None` (carrier_sync.py:66)
-            try:
-                vals[i] = fn(np.abs(spectra[i]), int(first["carrier_bin"][i]))
-            except Exception as exc:            # noqa: BLE001 -- whatever the callable raises is the block's
-                error, n_ok = exc, i
-                break
+        vals, error, n_ok, offsets = [0] * len(items), None, len(items), None
+        if self._host_interp:
+            fn = self.sync._interpolator
+            first = self._engine.detect(arr, idx)[:, 0]
+            has = (first["flags"] & (_native.FLAG_CARRIER | _native.FLAG_INDEX_ERROR)) != 0
+            spectra = self._engine.debug_fft(arr) if has.any() and fn is not None else None
+            for i in np.flatnonzero(has).tolist():
+                if fn is None:
+                    continue                        # `if self.interpolator is not None` (carrier_sync.py:66)
+                try:
+                    vals[i] = fn(np.abs(spectra[i]), int(first["carrier_bin"][i]))
+                except Exception as exc:            # noqa: BLE001 -- whatever the callable raises is the block's
+                    error, n_ok = exc, i
+                    break
+            offsets = np.array([float(v) for v in vals[:n_ok]])
         out = []
         if n_ok:
-            recs = self._engine.detect_offsets(arr[:n_ok], np.array([float(v) for v in vals[:n_ok]]), idx[:n_ok])[:, 0]
+            recs = (self._engine.detect_offsets(arr[:n_ok], offsets, idx[:n_ok]) if offsets is not None
+                    else self._engine.detect(arr[:n_ok], idx[:n_ok]))[:, 0]
             out = self._results([it[0] for it in items[:n_ok]], idx[:n_ok], recs)
-            for (detected, res), v in zip(out, vals):
-                if res.corr_info is not None:   # the offset as the callable returned it (none() -> the int 0)
-                    res.carrier_info = res.carrier_info._replace(offset=v)
+            if offsets is not None:
+                for (detected, res), v in zip(out, vals):
+                    if not isinstance(res, _Deferred) and res.corr_info is not None:
+                        # the offset as the callable returned it (none() -> the int 0)
+                        res.carrier_info = res.carrier_info._replace(offset=v)
+            if self._host_soa:
+                out, err2 = self._interpolate_on_host(out, arr[:n_ok], recs, offsets)
+                error = err2 if err2 is not None else error
         if error is not None:
             out.append(_Deferred(error))
         return out
+
+    def _interpolate_on_host(self, out, arr, recs, offsets):
+        """`soa_estimate.interpolate` replaced: for every DETECTED block the callable gets the
+        correlation magnitudes (the reference's `corr.mag`, all corr_len lags) and the peak index
+        (soa_estimator.py:87: `offset = 0 if not detected else self.interpolate(corr.mag, peak_idx)`),
+        its value is clipped to +-0.6 and becomes CorrDetectionInfo.offset; `soa` follows.
+        `soa_estimate.last_fft` holds the block's shifted spectrum meanwhile (what the reference's
+        IterativeSoaEstimator keeps, detect_xcorr_interpol.py:27-34).  -> (results up to an exception
+        of the callable, that exception or None)"""
+        fn = self.soa_estimate._interpolate
+        hits = [i for i, item in enumerate(out) if not isinstance(item, _Deferred) and item[0]]
+        if not hits:
+            return out, None
+        xhat, corr = self._engine.debug_stage(arr, carrier_offset=offsets)
+        corr_len = self.soa_estimate.corr_len
+        for i in hits:
+            detected, res = out[i]
+            self.soa_estimate.last_fft = xhat[i]
+            try:
+                off = fn(np.abs(corr[i][:corr_len]), res.corr_info.sample)
+            except Exception as exc:                # noqa: BLE001 -- the block's own error
+                return out[:i], exc
+            off = -0.6 if off < -0.6 else 0.6 if off > 0.6 else off       # _clip_offset (soa_estimator.py:16-17)
+            res.corr_info = res.corr_info._replace(offset=off)
+            res.soa = self.new_len * res.block + res.corr_info.sample + off
+        self.soa_estimate.last_fft = None
+        return out, None
 
     def detect_batch(self, items):
         """[(timestamp, block_idx, block), ...] -> [(detected, DetectionResult), ...]."""
         if not items:
             return []
-        if self._host_interp:
+        if self._host_path:
             out = self._detect_batch_host(items)
             if out and isinstance(out[-1], _Deferred):
                 raise out[-1].exc
@@ -467,7 +546,7 @@ class Detector(object):
                 break
         if not items:
             return None
-        if self.yield_data or self._host_interp:
+        if self.yield_data or self._host_path:
             return items
         arr = self._stack([it[2] for it in items])
         idx = np.array([int(it[1]) for it in items], dtype=np.int64)
@@ -486,7 +565,7 @@ class Detector(object):
             if first is None:
                 return None
             self._ahead.append(first)
-        if self.yield_data or self._host_interp:
+        if self.yield_data or self._host_path:
             return self._ahead.popleft()
         while (len(self._ahead) <= self._depth and not self._exhausted and self._read_error is None
                and self._may_read_ahead(self._ahead[-1][2])):
@@ -514,7 +593,7 @@ class Detector(object):
         """The iteration ends here (the reference's loop died on this block): never leave a ticket open."""
         while self._ahead:
             pending = self._ahead.popleft()
-            if not (self.yield_data or self._host_interp):
+            if not (self.yield_data or self._host_path):
                 self._engine.collect(pending[2])
         # nothing of the input is read any more: an error the read-ahead had parked belongs to
         # blocks behind the one that ended the iteration, and the input's pages can be unlocked
@@ -547,7 +626,7 @@ class Detector(object):
         if self.yield_data:
             self._ready.extend(self.detect(*it) for it in got)
             return
-        if self._host_interp:
+        if self._host_path:
             self._ready.extend(self._detect_batch_host(got))
             return
         stamps, idxs, recs = got
@@ -572,7 +651,7 @@ class Detector(object):
         that error after the detections before it have been yielded."""
         if self.blocks is None:
             raise TypeError("Detector was constructed without a block source")
-        if self.yield_data or self._host_interp:
+        if self.yield_data or self._host_path:
             raise TypeError("record iteration is not available with yield_data / a replaced interpolator: "
                             "iterate the detector")
         while self._more():
@@ -992,13 +1071,13 @@ def detector_cli(detector_class, parser=None, extra_args=None, argv=None):
     if args.quiet and hasattr(detections, "only_detections"):
         detections.only_detections = True   # nothing is printed for the other blocks anyway
     if (args.quiet and output_file is not None and hasattr(detections, "write_toad")
-            and not getattr(detections, "_host_interp", False)):
+            and not getattr(detections, "_host_path", False)):
         # nothing per block is needed: a mapped input runs entirely inside the library
         # (thr_run_card / thr_run_stream), anything else a batch of text at a time
         detections.write_toad(output_file)
         return
     if (args.quiet and output_file is not None and hasattr(detections, "iter_toad_text")
-            and not getattr(detections, "_host_interp", False)):
+            and not getattr(detections, "_host_path", False)):
         for text in detections.iter_toad_text():
             output_file.write(text.decode("ascii"))
         output_file.flush()
