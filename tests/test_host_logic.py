@@ -204,6 +204,34 @@ def test_library_exports_every_declared_symbol():
     assert _native.RECORD_DTYPE.itemsize == 64
 
 
+def test_no_entry_point_lets_a_cpp_exception_out():
+    """"No exceptions across the ABI" (include/thrifty_hip.h): every `int thr_*` entry point with a
+    body of its own is a function-try-block that ends in thr::on_exception (host memory, a thread
+    the OS refuses); the one-liners only forward to such a function or read a constant."""
+    csrc = os.path.join(ROOT, "thrifty_amd", "csrc")
+    seen = set()
+    for name in sorted(os.listdir(csrc)):
+        if not name.endswith(".hip"):
+            continue
+        text = open(os.path.join(csrc, name)).read()
+        for m in re.finditer(r'^(?:extern "C" )?int (thr_[a-z_0-9]+)\(', text, re.M):
+            sym = m.group(1)
+            rest = text[m.start():]
+            head = rest[:rest.index("{") + 1]
+            line_end = rest.index("\n", len(head) - 1)
+            if rest[:line_end].rstrip().endswith("}"):         # a one-line body
+                body = rest[len(head):line_end]
+                assert re.fullmatch(r"\s*return [\w:]+(\(.*\))?;\s*}", body), (sym, body)
+                seen.add(sym)
+                continue
+            assert re.search(r"\)\s*try \{$", head), sym
+            end = rest.index("\n}\n")
+            assert rest[:end + 2].rstrip().endswith('return thr::on_exception("%s");\n}' % sym), sym
+            seen.add(sym)
+    declared = set(re.findall(r"\bint\s+(thr_[a-z_0-9]+)\s*\(", open(os.path.join(ROOT, "include", "thrifty_hip.h")).read()))
+    assert declared <= seen, sorted(declared - seen)
+
+
 def test_engine_fails_loudly_without_gpu():
     """No silent CPU fallback: without a HIP device construction raises."""
     _lib_or_skip()

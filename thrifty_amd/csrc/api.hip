@@ -10,7 +10,9 @@
 #include <charconv>
 #include <chrono>
 #include <condition_variable>
+#include <exception>
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 
@@ -46,6 +48,24 @@ int fail_msg(int code, const char* fmt, ...) {
     va_end(ap);
     g_last_error = buf;
     return code;
+}
+// No exception leaves the C ABI (include/thrifty_hip.h): every entry point that allocates or starts
+// a thread is a function-try-block ending here.  Host memory exhaustion and a refused thread
+// (std::system_error: a pids / thread limit, eight ranks on one host) become THR_ERR_DEVICE.
+int on_exception(const char* who) noexcept {
+    try {
+        try {
+            throw;
+        } catch (const std::bad_alloc&) {
+            return fail_msg(THR_ERR_DEVICE, "%s: out of host memory", who);
+        } catch (const std::exception& e) {
+            return fail_msg(THR_ERR_DEVICE, "%s: %s", who, e.what());
+        } catch (...) {
+            return fail_msg(THR_ERR_DEVICE, "%s: unknown C++ exception", who);
+        }
+    } catch (...) {         // (the message itself could not be stored)
+        return THR_ERR_DEVICE;
+    }
 }
 }  // namespace thr
 
@@ -246,21 +266,26 @@ struct InputWindow {
         populated.assign(n_seg, 0);
         stop = failed = draining = false;
         device = dev;
-        worker = std::thread([this] { run(); });
-        unlocker = std::thread([this] { unlock_run(); });
         populators.clear();
-        for (int i = 0; i < std::max(1, n_populators); ++i) populators.emplace_back([this] { populate_run(); });
+        try {
+            worker = std::thread([this] { run(); });
+            unlocker = std::thread([this] { unlock_run(); });
+            for (int i = 0; i < std::max(1, n_populators); ++i) populators.emplace_back([this] { populate_run(); });
+        } catch (...) {        // a thread could not be started: stop the ones that were, no window
+            close();
+            throw;
+        }
     }
 
     void close() {
-        if (!worker.joinable()) return;
+        if (!worker.joinable() && !unlocker.joinable() && populators.empty()) return;
         {
             std::lock_guard<std::mutex> lk(mu);
             stop = true;
         }
         cv.notify_all();
-        worker.join();
-        unlocker.join();
+        if (worker.joinable()) worker.join();
+        if (unlocker.joinable()) unlocker.join();
         for (auto& t : populators) t.join();
         populators.clear();
         for (size_t sgm = reg_lo; sgm < reg_hi; ++sgm)      // what is still locked
@@ -1096,8 +1121,10 @@ static int create_fastdet(const thr_settings* s, thr_handle** out, int path) {
     return create_impl(s, 1, out, 2, path);
 }
 
-int thr_create_fastdet(const thr_settings* s, thr_handle** out) {
+int thr_create_fastdet(const thr_settings* s, thr_handle** out) try {
     return create_fastdet(s, out, THR_PATH_AUTO);
+} catch (...) {
+    return thr::on_exception("thr_create_fastdet");
 }
 
 static int create_preshift(const thr_settings* s, int num_arg, thr_handle** out, int path) {
@@ -1111,14 +1138,16 @@ static int create_preshift(const thr_settings* s, int num_arg, thr_handle** out,
     return create_impl(s, num_shifts, out, -1, path, interp);
 }
 
-int thr_create_preshift(const thr_settings* s, int num_shifts, thr_handle** out) {
+int thr_create_preshift(const thr_settings* s, int num_shifts, thr_handle** out) try {
     return create_preshift(s, num_shifts, out, THR_PATH_AUTO);
+} catch (...) {
+    return thr::on_exception("thr_create_preshift");
 }
 
 namespace {
 constexpr uintptr_t kPage = 4096;
 }
-int thr_host_register(const void* p, size_t bytes) {
+int thr_host_register(const void* p, size_t bytes) try {
     if (!p || bytes == 0) return fail(THR_ERR_ARG, "thr_host_register: empty range");
     const uintptr_t a = reinterpret_cast<uintptr_t>(p) & ~(kPage - 1);
     const uintptr_t e = (reinterpret_cast<uintptr_t>(p) + bytes + kPage - 1) & ~(kPage - 1);
@@ -1128,9 +1157,11 @@ int thr_host_register(const void* p, size_t bytes) {
         return fail(THR_ERR_DEVICE, "hipHostRegister(%zu bytes) failed: %s", size_t(e - a), hipGetErrorString(rc));
     }
     return THR_OK;
+} catch (...) {
+    return thr::on_exception("thr_host_register");
 }
 
-int thr_host_unregister(const void* p) {
+int thr_host_unregister(const void* p) try {
     if (!p) return fail(THR_ERR_ARG, "thr_host_unregister: null");
     const uintptr_t a = reinterpret_cast<uintptr_t>(p) & ~(kPage - 1);
     const hipError_t rc = hipHostUnregister(reinterpret_cast<void*>(a));
@@ -1139,13 +1170,17 @@ int thr_host_unregister(const void* p) {
         return fail(THR_ERR_DEVICE, "hipHostUnregister failed: %s", hipGetErrorString(rc));
     }
     return THR_OK;
+} catch (...) {
+    return thr::on_exception("thr_host_unregister");
 }
 
-int thr_input_window(thr_handle* h, const void* p, size_t bytes) {
+int thr_input_window(thr_handle* h, const void* p, size_t bytes) try {
     return thr_input_window_ex(h, p, bytes, 0, 0);
+} catch (...) {
+    return thr::on_exception("thr_input_window");
 }
 
-int thr_input_window_ex(thr_handle* h, const void* p, size_t bytes, int populate_threads, size_t segment_bytes) {
+int thr_input_window_ex(thr_handle* h, const void* p, size_t bytes, int populate_threads, size_t segment_bytes) try {
     if (!h) return fail(THR_ERR_ARG, "thr_input_window: null handle");
     if (populate_threads < 0 || populate_threads > 16)
         return fail(THR_ERR_ARG, "thr_input_window_ex: populate_threads %d out of range [0, 16]", populate_threads);
@@ -1161,9 +1196,11 @@ int thr_input_window_ex(thr_handle* h, const void* p, size_t bytes, int populate
     if (p && bytes)
         h->win.open(p, bytes, h->device, populate_threads ? populate_threads : InputWindow::kPopulators, segment_bytes);
     return THR_OK;
+} catch (...) {
+    return thr::on_exception("thr_input_window_ex");
 }
 
-int thr_debug_window(thr_handle* h, size_t out[4]) {
+int thr_debug_window(thr_handle* h, size_t out[4]) try {
     if (!h || !out) return fail(THR_ERR_ARG, "thr_debug_window: null argument");
     std::lock_guard<std::mutex> lk(h->win.mu);
     out[0] = h->win.base ? h->win.consumed * h->win.kSeg : 0;
@@ -1171,9 +1208,11 @@ int thr_debug_window(thr_handle* h, size_t out[4]) {
     out[2] = h->win.reg_hi * h->win.kSeg;
     out[3] = h->win.base ? h->win.kSeg : 0;
     return THR_OK;
+} catch (...) {
+    return thr::on_exception("thr_debug_window");
 }
 
-int thr_debug_correlate_geom(thr_handle* h, int* rows_lo, int* rows_hi) {
+int thr_debug_correlate_geom(thr_handle* h, int* rows_lo, int* rows_hi) try {
     if (!h || !rows_lo || !rows_hi) return fail(THR_ERR_ARG, "thr_debug_correlate_geom: null argument");
     *rows_lo = *rows_hi = -1;
     int lo = -1, hi = -1;
@@ -1187,9 +1226,11 @@ int thr_debug_correlate_geom(thr_handle* h, int* rows_lo, int* rows_hi) {
         *rows_hi = hi;
     }
     return THR_OK;
+} catch (...) {
+    return thr::on_exception("thr_debug_correlate_geom");
 }
 
-int thr_debug_pipe_times(thr_handle* h, double out[16]) {
+int thr_debug_pipe_times(thr_handle* h, double out[16]) try {
     if (!h || !out) return fail(THR_ERR_ARG, "thr_debug_pipe_times: null argument");
     for (int i = 0; i < 8; ++i) {
         out[i] = h->t_pipe[i];
@@ -1197,9 +1238,11 @@ int thr_debug_pipe_times(thr_handle* h, double out[16]) {
         h->t_pipe[i] = h->t_pipe_max[i] = 0;
     }
     return THR_OK;
+} catch (...) {
+    return thr::on_exception("thr_debug_pipe_times");
 }
 
-int thr_debug_window_times(thr_handle* h, double out[6]) {
+int thr_debug_window_times(thr_handle* h, double out[6]) try {
     if (!h || !out) return fail(THR_ERR_ARG, "thr_debug_window_times: null argument");
     std::lock_guard<std::mutex> lk(h->win.mu);
     out[0] = h->win.t_populate;
@@ -1209,9 +1252,11 @@ int thr_debug_window_times(thr_handle* h, double out[6]) {
     out[4] = double(h->win.n_acquire_waits);
     out[5] = double(h->win.n_pageable);
     return THR_OK;
+} catch (...) {
+    return thr::on_exception("thr_debug_window_times");
 }
 
-int thr_input_window_release(thr_handle* h) {
+int thr_input_window_release(thr_handle* h) try {
     if (!h) return fail(THR_ERR_ARG, "thr_input_window_release: null handle");
     if (hipSetDevice(h->device) != hipSuccess) return fail(THR_ERR_DEVICE, "hipSetDevice(%d) failed", h->device);
     if (h->hp.async_open != 0)
@@ -1222,10 +1267,12 @@ int thr_input_window_release(thr_handle* h) {
     for (auto& e : h->hp.win_lo) e = 0;
     h->win.release_all();
     return THR_OK;
+} catch (...) {
+    return thr::on_exception("thr_input_window_release");
 }
 
 int thr_plan_sections(int block_len, int history_len, int template_len, int* n_sections, int* start,
-                      int* win_lo, int* win_hi, int* sum_lo, int* sum_hi) {
+                      int* win_lo, int* win_hi, int* sum_lo, int* sum_hi) try {
     if (!n_sections || !start || !win_lo || !win_hi || !sum_lo || !sum_hi)
         return fail(THR_ERR_ARG, "thr_plan_sections: null argument");
     if (block_len <= 0 || (block_len & (block_len - 1)) || template_len < 1 || template_len > block_len ||
@@ -1248,9 +1295,11 @@ int thr_plan_sections(int block_len, int history_len, int template_len, int* n_s
         sum_hi[g] = d.seg_sum_hi[g] + d.seg_start[g];
     }
     return THR_OK;
+} catch (...) {
+    return thr::on_exception("thr_plan_sections");
 }
 
-int thr_create_ex(const thr_settings* s, int variant, int variant_arg, int path, thr_handle** out) {
+int thr_create_ex(const thr_settings* s, int variant, int variant_arg, int path, thr_handle** out) try {
     if (path != THR_PATH_AUTO && path != THR_PATH_MULTIPASS && path != THR_PATH_UNSECTIONED &&
         path != THR_PATH_GENERIC_ROWS)
         return fail(THR_ERR_ARG, "thr_create_ex: unknown path %d", path);
@@ -1260,13 +1309,29 @@ int thr_create_ex(const thr_settings* s, int variant, int variant_arg, int path,
         case THR_VARIANT_FASTDET: return create_fastdet(s, out, path);
     }
     return fail(THR_ERR_ARG, "thr_create_ex: unknown variant %d", variant);
+} catch (...) {
+    return thr::on_exception("thr_create_ex");
 }
 
+
+static int create_body(thr_handle*& h, const thr_settings* s, int preshift_num, thr_handle** out, int variant,
+                       int path, int interp);
 
 static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out, int variant, int path,
                        int interp) {
     if (!s || !out) return fail(THR_ERR_ARG, "thr_create: null argument");
     *out = nullptr;
+    thr_handle* h = nullptr;       // what create_body had built when it threw (host memory) goes back
+    try {
+        return create_body(h, s, preshift_num, out, variant, path, interp);
+    } catch (...) {
+        if (h) thr_destroy(h);
+        return thr::on_exception("thr_create");
+    }
+}
+
+static int create_body(thr_handle*& h, const thr_settings* s, int preshift_num, thr_handle** out, int variant,
+                       int path, int interp) {
     const int n = s->block_len;
     if (n <= 0 || (n & (n - 1))) return fail(THR_ERR_ARG, "block_len %d is not a power of two", n);
     if (n < 64 || n > (1 << 20))
@@ -1287,7 +1352,7 @@ static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out
     if (s->device_id < 0 || s->device_id >= ndev)
         return fail(THR_ERR_ARG, "device_id %d out of range (%d devices)", s->device_id, ndev);
 
-    thr_handle* h = new thr_handle();
+    h = new thr_handle();
     h->cfg = *s;
     h->cfg.templates = nullptr;  // not retained beyond this call (re-pointed below)
     h->device = s->device_id;
@@ -1439,7 +1504,9 @@ static int create_impl(const thr_settings* s, int preshift_num, thr_handle** out
 #undef CREATE_TRY
     } while (0);
     if (rc != THR_OK) {
-        thr_destroy(h);
+        thr_handle* dead = h;
+        h = nullptr;
+        thr_destroy(dead);
         return rc;
     }
     *out = h;
@@ -1483,40 +1550,50 @@ void thr_destroy(thr_handle* h) {
     delete h;
 }
 
-int thr_set_wait_mode(thr_handle* h, int sleeping) {
+int thr_set_wait_mode(thr_handle* h, int sleeping) try {
     if (!h) return fail(THR_ERR_ARG, "thr_set_wait_mode: null handle");
     h->sleepy_waits = sleeping != 0;
     return THR_OK;
+} catch (...) {
+    return thr::on_exception("thr_set_wait_mode");
 }
 
-int thr_get_settings(const thr_handle* h, thr_settings* out) {
+int thr_get_settings(const thr_handle* h, thr_settings* out) try {
     if (!h || !out) return fail(THR_ERR_ARG, "thr_get_settings: null argument");
     *out = h->cfg;
     out->templates = nullptr;
     return THR_OK;
+} catch (...) {
+    return thr::on_exception("thr_get_settings");
 }
 
-int thr_set_stream(thr_handle* h, void* hip_stream) {
+int thr_set_stream(thr_handle* h, void* hip_stream) try {
     if (!h) return fail(THR_ERR_ARG, "null handle");
     h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
     return THR_OK;
+} catch (...) {
+    return thr::on_exception("thr_set_stream");
 }
 
-int thr_set_stream_default(thr_handle* h) {
+int thr_set_stream_default(thr_handle* h) try {
     if (!h) return fail(THR_ERR_ARG, "null handle");
     h->stream = nullptr;   // the legacy default stream (handle value 0): ordered with every blocking stream
     return THR_OK;
+} catch (...) {
+    return thr::on_exception("thr_set_stream_default");
 }
 
-int thr_sync(thr_handle* h) {
+int thr_sync(thr_handle* h) try {
     if (!h) return fail(THR_ERR_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return THR_OK;
+} catch (...) {
+    return thr::on_exception("thr_sync");
 }
 
 int thr_detect_device(thr_handle* h, const void* d_samples, int format,
-                      const int64_t* d_block_idx, size_t n_blocks, thr_record* d_out) {
+                      const int64_t* d_block_idx, size_t n_blocks, thr_record* d_out) try {
     if (!h || !d_samples || !d_out) return fail(THR_ERR_ARG, "thr_detect_device: null argument");
     if (format != THR_IN_U8 && format != THR_IN_C64) return fail(THR_ERR_ARG, "bad format %d", format);
     if (n_blocks == 0) return THR_OK;
@@ -1525,6 +1602,8 @@ int thr_detect_device(thr_handle* h, const void* d_samples, int format,
     HIP_TRY(hipSetDevice(h->device));
     return run_batch(h, d_samples, format, reinterpret_cast<const long long*>(d_block_idx),
                      int(n_blocks), d_out, nullptr, nullptr, nullptr, 0, false);
+} catch (...) {
+    return thr::on_exception("thr_detect_device");
 }
 
 // Raw-stream framing on the device (block_data.py:70-98; fastcard raw_reader.c:15-46): block i
@@ -1540,7 +1619,7 @@ static int stream_stride(thr_handle* h, size_t* stride) {
 }
 
 int thr_detect_stream_device(thr_handle* h, const uint8_t* d_stream, const int64_t* d_block_idx,
-                             size_t n_blocks, thr_record* d_out) {
+                             size_t n_blocks, thr_record* d_out) try {
     if (!h || !d_stream || !d_out) return fail(THR_ERR_ARG, "thr_detect_stream_device: null argument");
     if (n_blocks == 0) return THR_OK;
     if (n_blocks > size_t(h->cfg.max_batch))
@@ -1553,6 +1632,8 @@ int thr_detect_stream_device(thr_handle* h, const uint8_t* d_stream, const int64
     HIP_TRY(hipSetDevice(h->device));
     return run_batch(h, d_stream, THR_IN_U8, reinterpret_cast<const long long*>(d_block_idx),
                      int(n_blocks), d_out, nullptr, nullptr, nullptr, 0, false, stride);
+} catch (...) {
+    return thr::on_exception("thr_detect_stream_device");
 }
 
 // ---- one chunk of each host entry point: stage the inputs into pipe buffer b (copy stream), run
@@ -1662,7 +1743,7 @@ static int pipe_enter_sync(thr_handle* h, const char* who) {
 }
 
 int thr_detect_stream(thr_handle* h, const uint8_t* stream, size_t n_bytes, int64_t first_block_idx,
-                      thr_record* out, size_t out_capacity, size_t* n_blocks_out) {
+                      thr_record* out, size_t out_capacity, size_t* n_blocks_out) try {
     if (!h || !stream || !out || !n_blocks_out)
         return fail(THR_ERR_ARG, "thr_detect_stream: null argument");
     *n_blocks_out = 0;
@@ -1691,10 +1772,12 @@ int thr_detect_stream(thr_handle* h, const uint8_t* stream, size_t n_bytes, int6
     if (rc != THR_OK) return rc;
     *n_blocks_out = n_blocks;
     return THR_OK;
+} catch (...) {
+    return thr::on_exception("thr_detect_stream");
 }
 
 int thr_detect(thr_handle* h, const void* samples, int format, const int64_t* block_idx,
-               size_t n_blocks, thr_record* out) {
+               size_t n_blocks, thr_record* out) try {
     if (!h || !samples || !out) return fail(THR_ERR_ARG, "thr_detect: null argument");
     if (format != THR_IN_U8 && format != THR_IN_C64) return fail(THR_ERR_ARG, "bad format %d", format);
     int rc = pipe_enter_sync(h, "thr_detect");
@@ -1715,11 +1798,13 @@ int thr_detect(thr_handle* h, const void* samples, int format, const int64_t* bl
         done += nb;
     }
     return pipe_finish(h, rc);
+} catch (...) {
+    return thr::on_exception("thr_detect");
 }
 
 int thr_frame_card(const char* text, size_t text_len, int block_len, int at_eof, size_t max_records,
                    double* timestamps, int64_t* block_idx, int64_t* payload_off, size_t* n_records,
-                   size_t* consumed) {
+                   size_t* consumed) try {
     if (!text || !timestamps || !block_idx || !payload_off || !n_records || !consumed)
         return fail(THR_ERR_ARG, "thr_frame_card: null argument");
     if (block_len <= 0) return fail(THR_ERR_ARG, "thr_frame_card: bad block_len %d", block_len);
@@ -1796,11 +1881,13 @@ int thr_frame_card(const char* text, size_t text_len, int block_len, int at_eof,
     *n_records = n;
     *consumed = pos;
     return THR_OK;
+} catch (...) {
+    return thr::on_exception("thr_frame_card");
 }
 
 
 int thr_detect_card(thr_handle* h, const char* text, size_t text_len, const int64_t* payload_off,
-                    const int64_t* block_idx, size_t n_blocks, thr_record* out) {
+                    const int64_t* block_idx, size_t n_blocks, thr_record* out) try {
     if (!h || !text || !payload_off || !out) return fail(THR_ERR_ARG, "thr_detect_card: null argument");
     int rc = pipe_enter_sync(h, "thr_detect_card");
     if (rc != THR_OK) return rc;
@@ -1816,6 +1903,8 @@ int thr_detect_card(thr_handle* h, const char* text, size_t text_len, const int6
         done += nb;
     }
     return pipe_finish(h, rc);
+} catch (...) {
+    return thr::on_exception("thr_detect_card");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1860,7 +1949,7 @@ static int submit_leave(thr_handle* h, int b, int rc, uint64_t* ticket) {
 }
 
 int thr_submit(thr_handle* h, const void* samples, int format, const int64_t* block_idx,
-               size_t n_blocks, thr_record* out, uint64_t* ticket) {
+               size_t n_blocks, thr_record* out, uint64_t* ticket) try {
     if (!h || !samples || !out) return fail(THR_ERR_ARG, "thr_submit: null argument");
     if (format != THR_IN_U8 && format != THR_IN_C64) return fail(THR_ERR_ARG, "bad format %d", format);
     int b = 0;
@@ -1869,20 +1958,24 @@ int thr_submit(thr_handle* h, const void* samples, int format, const int64_t* bl
     const size_t blk_bytes = size_t(h->cfg.block_len) * (format == THR_IN_U8 ? 2 : 8);
     rc = chunk_samples(h, b, samples, format, blk_bytes, 0, block_idx, 0, n_blocks, out, 0);
     return submit_leave(h, b, rc, ticket);
+} catch (...) {
+    return thr::on_exception("thr_submit");
 }
 
 int thr_submit_card(thr_handle* h, const char* text, size_t text_len, const int64_t* payload_off,
-                    const int64_t* block_idx, size_t n_blocks, thr_record* out, uint64_t* ticket) {
+                    const int64_t* block_idx, size_t n_blocks, thr_record* out, uint64_t* ticket) try {
     if (!h || !text || !payload_off || !out) return fail(THR_ERR_ARG, "thr_submit_card: null argument");
     int b = 0;
     int rc = submit_enter(h, "thr_submit_card", n_blocks, ticket, &b);
     if (rc != THR_OK || n_blocks == 0) return rc;
     rc = chunk_card(h, b, text, text_len, payload_off, block_idx, 0, n_blocks, out);
     return submit_leave(h, b, rc, ticket);
+} catch (...) {
+    return thr::on_exception("thr_submit_card");
 }
 
 int thr_submit_stream(thr_handle* h, const uint8_t* stream, size_t n_bytes, int64_t first_block_idx,
-                      thr_record* out, size_t out_capacity, size_t* n_blocks_out, uint64_t* ticket) {
+                      thr_record* out, size_t out_capacity, size_t* n_blocks_out, uint64_t* ticket) try {
     if (!h || !stream || !out || !n_blocks_out)
         return fail(THR_ERR_ARG, "thr_submit_stream: null argument");
     *n_blocks_out = 0;
@@ -1901,9 +1994,11 @@ int thr_submit_stream(thr_handle* h, const uint8_t* stream, size_t n_bytes, int6
     rc = submit_leave(h, b, rc, ticket);
     if (rc == THR_OK) *n_blocks_out = n_blocks;
     return rc;
+} catch (...) {
+    return thr::on_exception("thr_submit_stream");
 }
 
-int thr_collect(thr_handle* h, uint64_t ticket) {
+int thr_collect(thr_handle* h, uint64_t ticket) try {
     if (!h) return fail(THR_ERR_ARG, "thr_collect: null handle");
     if (ticket == 0) return THR_OK;   // the ticket of an empty batch
     auto& p = h->hp;
@@ -1921,9 +2016,11 @@ int thr_collect(thr_handle* h, uint64_t ticket) {
     }
     return fail(THR_ERR_STATE, "thr_collect: ticket %llu is not open (never issued, or collected already)",
                 (unsigned long long)ticket);
+} catch (...) {
+    return thr::on_exception("thr_collect");
 }
 
-int thr_inputs_consumed(thr_handle* h, uint64_t ticket) {
+int thr_inputs_consumed(thr_handle* h, uint64_t ticket) try {
     if (!h) return fail(THR_ERR_ARG, "thr_inputs_consumed: null handle");
     if (ticket == 0) return THR_OK;
     auto& p = h->hp;
@@ -1935,9 +2032,11 @@ int thr_inputs_consumed(thr_handle* h, uint64_t ticket) {
         return THR_OK;
     }
     return fail(THR_ERR_STATE, "thr_inputs_consumed: ticket %llu is not open", (unsigned long long)ticket);
+} catch (...) {
+    return thr::on_exception("thr_inputs_consumed");
 }
 
-int thr_poll(thr_handle* h, uint64_t ticket, int* done) {
+int thr_poll(thr_handle* h, uint64_t ticket, int* done) try {
     if (!h || !done) return fail(THR_ERR_ARG, "thr_poll: null argument");
     *done = 1;
     if (ticket == 0) return THR_OK;
@@ -1953,6 +2052,8 @@ int thr_poll(thr_handle* h, uint64_t ticket, int* done) {
         return THR_OK;
     }
     return fail(THR_ERR_STATE, "thr_poll: ticket %llu is not open", (unsigned long long)ticket);
+} catch (...) {
+    return thr::on_exception("thr_poll");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2067,7 +2168,7 @@ char* put_fixed(char* out, double v) {
 
 int thr_format_toad(const thr_record* recs, const double* timestamps, size_t n, int64_t new_len,
                     int with_rxid, int64_t rxid, int with_txid, int carrier_offset_f32, char* out,
-                    size_t out_capacity, size_t* out_len) {
+                    size_t out_capacity, size_t* out_len) try {
     if ((!recs || !timestamps) && n) return fail(THR_ERR_ARG, "thr_format_toad: null argument");
     if (!out || !out_len) return fail(THR_ERR_ARG, "thr_format_toad: null output");
     *out_len = 0;
@@ -2118,10 +2219,12 @@ int thr_format_toad(const thr_record* recs, const double* timestamps, size_t n, 
     }
     *out_len = size_t(p - out);
     return THR_OK;
+} catch (...) {
+    return thr::on_exception("thr_format_toad");
 }
 
 int thr_compact_device(thr_handle* h, const thr_record* d_in, size_t n_records, thr_record* d_out,
-                       size_t* n_kept) {
+                       size_t* n_kept) try {
     if (!h || !d_in || !d_out || !n_kept) return fail(THR_ERR_ARG, "thr_compact_device: null argument");
     HIP_TRY(hipSetDevice(h->device));
     if (n_records > size_t(1) << 30) return fail(THR_ERR_ARG, "too many records");
@@ -2140,17 +2243,21 @@ int thr_compact_device(thr_handle* h, const thr_record* d_in, size_t n_records, 
     HIP_TRY(hipStreamSynchronize(h->stream));
     *n_kept = size_t(n);
     return THR_OK;
+} catch (...) {
+    return thr::on_exception("thr_compact_device");
 }
 
-int thr_profile_enable(thr_handle* h, int on) {
+int thr_profile_enable(thr_handle* h, int on) try {
     if (!h) return fail(THR_ERR_ARG, "null handle");
     h->prof_every = on < 0 ? 0 : on;
     h->batch_no = 0;
     return THR_OK;
+} catch (...) {
+    return thr::on_exception("thr_profile_enable");
 }
 
 int thr_profile_read(thr_handle* h, double ms[THR_N_KERNEL_SLOTS],
-                     int64_t launches[THR_N_KERNEL_SLOTS]) {
+                     int64_t launches[THR_N_KERNEL_SLOTS]) try {
     if (!h || !ms || !launches) return fail(THR_ERR_ARG, "thr_profile_read: null argument");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -2170,19 +2277,23 @@ int thr_profile_read(thr_handle* h, double ms[THR_N_KERNEL_SLOTS],
         h->launches[s] = 0;
     }
     return THR_OK;
+} catch (...) {
+    return thr::on_exception("thr_profile_read");
 }
 
 #ifdef THR_DEV
-int thr_debug_timeline(thr_handle* h, unsigned long long* out128) {
+int thr_debug_timeline(thr_handle* h, unsigned long long* out128) try {
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
     return hipMemcpy(out128, h->dev.timeline, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost) ==
                    hipSuccess ? 0 : -2;
+} catch (...) {
+    return thr::on_exception("thr_debug_timeline");
 }
 #endif
 
 int thr_debug_fft(thr_handle* h, const void* samples, int format, size_t n_blocks,
-                  float* spectra_out) {
+                  float* spectra_out) try {
     if (!h || !samples || !spectra_out) return fail(THR_ERR_ARG, "thr_debug_fft: null argument");
     if (format != THR_IN_U8 && format != THR_IN_C64) return fail(THR_ERR_ARG, "bad format %d", format);
     if (n_blocks > size_t(h->cfg.max_batch)) return fail(THR_ERR_ARG, "n_blocks exceeds max_batch");
@@ -2212,10 +2323,12 @@ int thr_debug_fft(thr_handle* h, const void* samples, int format, size_t n_block
     } while (0);
     (void)hipFree(d_dump);
     return rc;
+} catch (...) {
+    return thr::on_exception("thr_debug_fft");
 }
 
 int thr_detect_offsets(thr_handle* h, const void* samples, int format, const int64_t* block_idx,
-                       size_t n_blocks, const double* carrier_offset, thr_record* out) {
+                       size_t n_blocks, const double* carrier_offset, thr_record* out) try {
     if (!h || !samples || !carrier_offset || !out) return fail(THR_ERR_ARG, "thr_detect_offsets: null argument");
     if (format != THR_IN_U8 && format != THR_IN_C64) return fail(THR_ERR_ARG, "bad format %d", format);
     if (n_blocks > size_t(h->cfg.max_batch))
@@ -2257,15 +2370,19 @@ int thr_detect_offsets(thr_handle* h, const void* samples, int format, const int
     h->forced = nullptr;
     if (rc != THR_OK) (void)hipStreamSynchronize(h->stream);
     return rc;
+} catch (...) {
+    return thr::on_exception("thr_detect_offsets");
 }
 
 int thr_debug_stage(thr_handle* h, const void* samples, int format, size_t n_blocks,
-                    int template_id, float* shifted_fft_out, float* corr_out) {
+                    int template_id, float* shifted_fft_out, float* corr_out) try {
     return thr_debug_stage_offsets(h, samples, format, n_blocks, template_id, nullptr, shifted_fft_out, corr_out);
+} catch (...) {
+    return thr::on_exception("thr_debug_stage");
 }
 
 int thr_debug_stage_offsets(thr_handle* h, const void* samples, int format, size_t n_blocks, int template_id,
-                            const double* carrier_offset, float* shifted_fft_out, float* corr_out) {
+                            const double* carrier_offset, float* shifted_fft_out, float* corr_out) try {
     if (!h || !samples) return fail(THR_ERR_ARG, "thr_debug_stage: null argument");
     if (carrier_offset && h->preshift_num)
         return fail(THR_ERR_ARG, "thr_debug_stage_offsets: the default detector only");
@@ -2327,6 +2444,8 @@ int thr_debug_stage_offsets(thr_handle* h, const void* samples, int format, size
     (void)hipFree(d_x);
     (void)hipFree(d_c);
     return rc;
+} catch (...) {
+    return thr::on_exception("thr_debug_stage_offsets");
 }
 
 }  // extern "C"

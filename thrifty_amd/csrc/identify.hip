@@ -18,7 +18,8 @@
 #include "../../include/thrifty_hip.h"
 
 namespace thr {
-int fail_msg(int code, const char* fmt, ...);  // api.hip
+int fail_msg(int code, const char* fmt, ...);
+int on_exception(const char* who) noexcept;  // api.hip
 }
 
 namespace {
@@ -180,7 +181,7 @@ extern "C" int thr_identify(int device_id, size_t n_in, const int32_t* rxid, con
                             const double* timestamp, const int32_t* carrier_bin,
                             const double* carrier_offset, const double* energy,
                             const thr_freq_range* map, size_t n_map, int32_t* txid_out,
-                            uint8_t* keep_out, int64_t* kept_order_out, size_t* n_kept_out) {
+                            uint8_t* keep_out, int64_t* kept_order_out, size_t* n_kept_out) try {
     if (n_kept_out) *n_kept_out = 0;
     if (n_in == 0) return THR_OK;
     if (!rxid || !block || !timestamp || !carrier_bin || !carrier_offset || !energy || !txid_out ||
@@ -321,4 +322,6 @@ extern "C" int thr_identify(int device_id, size_t n_in, const int32_t* rxid, con
     ID_TRY(hipMemcpy(kept_order_out, d_wide.p, size_t(n_kept) * 8, hipMemcpyDeviceToHost));
     *n_kept_out = size_t(n_kept);
     return THR_OK;
+} catch (...) {
+    return thr::on_exception("thr_identify");
 }

@@ -34,6 +34,7 @@
 
 namespace thr {
 int fail_msg(int code, const char* fmt, ...);
+int on_exception(const char* who) noexcept;
 }
 
 namespace {
@@ -76,6 +77,18 @@ struct Runner {
     std::string fmt_err;
     size_t rec_n = 0;
     std::thread formatter;
+
+    // the end of the input for the formatter: it drains its queue and returns
+    void finish() {
+        if (!formatter.joinable()) return;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            producer_done = true;
+        }
+        cv.notify_all();
+        formatter.join();
+    }
+    ~Runner() { finish(); }
 
     int take_free() {
         std::unique_lock<std::mutex> lk(mu);
@@ -205,6 +218,7 @@ int drive(Runner& R, Next&& next, Submit&& submit) {
     int in_rc = THR_OK, col_rc = THR_OK;
     std::string in_err, col_err;
     bool dead = false;        // a collect failed: what was submitted after it is waited for and dropped
+    try {
     while (true) {
         if (!input_done && !dead && !R.stop.load() && flight.size() < size_t(THR_MAX_IN_FLIGHT)) {
             const int s = R.take_free();
@@ -258,12 +272,13 @@ int drive(Runner& R, Next&& next, Submit&& submit) {
         R.st.blocks += b.nb;
         R.enqueue(s);
     }
-    {
-        std::lock_guard<std::mutex> lk(R.mu);
-        R.producer_done = true;
+    } catch (...) {
+        // (host memory): the handle must not be left with open tickets, nor the formatter running
+        in_rc = thr::on_exception("thr_run");
+        in_err = thr_last_error();
+        for (int s : flight) (void)thr_collect(R.h, R.ring[size_t(s)].ticket);
     }
-    R.cv.notify_all();
-    R.formatter.join();
+    R.finish();
     R.st.total_s = secs(t_start, Clock::now());
     if (R.fmt_rc != THR_OK) return thr::fail_msg(R.fmt_rc, "%s", R.fmt_err.c_str());
     if (R.st.index_error_at != UINT64_MAX) {
@@ -309,7 +324,7 @@ int check(const char* who, thr_handle* h, const thr_run_opts* o, thr_run_stats* 
 extern "C" {
 
 int thr_run_card(thr_handle* h, const char* text, size_t text_len, const thr_run_opts* opts,
-                 thr_run_stats* stats) {
+                 thr_run_stats* stats) try {
     Runner R;
     int rc = check("thr_run_card", h, opts, stats, R);
     if (rc != THR_OK) return rc;
@@ -342,10 +357,12 @@ int thr_run_card(thr_handle* h, const char* text, size_t text_len, const thr_run
     R.st.bytes_in = pos;
     *stats = R.st;
     return rc;
+} catch (...) {
+    return thr::on_exception("thr_run_card");
 }
 
 int thr_run_stream(thr_handle* h, const uint8_t* stream, size_t n_bytes, int64_t first_block_idx,
-                   const thr_run_opts* opts, thr_run_stats* stats) {
+                   const thr_run_opts* opts, thr_run_stats* stats) try {
     Runner R;
     int rc = check("thr_run_stream", h, opts, stats, R);
     if (rc != THR_OK) return rc;
@@ -378,6 +395,8 @@ int thr_run_stream(thr_handle* h, const uint8_t* stream, size_t n_bytes, int64_t
     R.st.bytes_in = done ? (done - 1) * stride + blk : 0;
     *stats = R.st;
     return rc;
+} catch (...) {
+    return thr::on_exception("thr_run_stream");
 }
 
 }  // extern "C"
