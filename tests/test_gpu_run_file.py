@@ -259,6 +259,56 @@ def test_cli_quiet_output_runs_inside_the_library(golden, tmp_path, monkeypatch)
     assert_toad_close(lines[:half], g["toad"])
 
 
+def test_the_cli_closes_its_engine_and_a_script_that_never_does_still_exits(golden, tmp_path):
+    """`detector_cli` destroys the engine when its loop ends (threads joined, pages unlocked) instead
+    of leaving it to the interpreter's shutdown; and a script that drops out with an engine and an
+    input window still open -- the window's threads inside the HIP runtime -- exits cleanly: an
+    atexit hook of thrifty_amd._native closes what is left before the runtime's own destructors."""
+    import subprocess
+    import sys
+    from thrifty_amd.detect import detector_cli
+    g = golden("c2")
+    np.save(tmp_path / "template.npy", g["template"])
+    (tmp_path / "detector.cfg").write_text(
+        "rxid: 0\nsample_rate: 2.4M\nblock_size: 16384\nblock_history: 4096\n"
+        "carrier_window: 7 - 110\ncarrier_threshold: 15 * snr\ncorr_threshold: 15*snr\n"
+        "template: %s\n" % (tmp_path / "template.npy"))
+    (tmp_path / "rx.card").write_text(card_text(g))
+    made = []
+
+    class Watched(Detector):
+        def __init__(self, *a, **kw):
+            super(Watched, self).__init__(*a, **kw)
+            made.append(self)
+
+    for extra in (["--quiet"], []):
+        detector_cli(Watched, argv=[str(tmp_path / "rx.card"), "-c", str(tmp_path / "detector.cfg"),
+                                    "-o", str(tmp_path / "rx.toad")] + extra)
+    assert len(made) == 2 and all(d._engine._h is None for d in made)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import mmap, sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from thrifty_amd import _native as F\n"
+        "from thrifty_amd.detect import Detector, DetectorSettings\n"
+        "from thrifty_amd.block_data import CardStream\n"
+        "tpl = np.load(%r)\n"
+        "st = DetectorSettings(16384, 4096, len(tpl), (0, 15, 0), (7, 110), tpl, (0, 15, 0))\n"
+        "f = open(%r, 'rb')\n"
+        "det = Detector(st, CardStream(f, 16384), rxid=0)\n"
+        "assert det._pin\n"
+        "n = sum(len(b) for b in det.iter_toad_lines())\n"
+        "eng = F.Engine(16384, 4096, tpl, (0, 15, 0), (7, 110), (0, 15, 0))\n"
+        "mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)\n"
+        "eng.input_window(memoryview(mm))\n"
+        "print('lines', n, len(F._live_engines))\n"
+    ) % (root, str(tmp_path / "template.npy"), str(tmp_path / "rx.card"))
+    for _ in range(3):
+        res = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=120)
+        assert res.returncode == 0, res.stderr[-2000:]
+        assert res.stdout.split()[:2] == ["lines", str(int(g["det"].sum()))] and int(res.stdout.split()[2]) >= 2
+
+
 def test_window_is_never_released_past_the_start_of_an_open_chunk():
     """Chunks of a raw stream overlap by 2 * history bytes.  With three of them in flight, collecting
     the oldest must not release (let the worker unlock) input-window segments that the next chunk's

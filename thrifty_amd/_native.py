@@ -5,8 +5,10 @@ MI355X is visible, constructing an :class:`Engine` raises.
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -333,6 +335,24 @@ def plan_sections(block_len, history_len, template_len):
     return [dict((k, int(a[g])) for k, a in zip(keys, arrs)) for g in range(n.value)]
 
 
+# Handles still open when the interpreter exits are destroyed by an atexit hook -- threads joined,
+# pages unlocked, streams gone BEFORE the process runs the HIP runtime's own static destructors.  (A
+# Detector's stage objects refer back to it, so a script that never calls close() keeps its engine,
+# and its input window's threads inside the runtime, until then.)
+_live_engines = weakref.WeakSet()
+
+
+def _close_live_engines():
+    for eng in list(_live_engines):
+        try:
+            eng.close()
+        except Exception:       # noqa: BLE001 -- at exit: nothing to report to
+            pass
+
+
+atexit.register(_close_live_engines)
+
+
 class Engine(object):
     """One detector handle == one (device, stream).  Not thread-safe per handle."""
 
@@ -368,6 +388,7 @@ class Engine(object):
         self.path = path
         self.preshift_num = int(preshift_num)
         self._lib, self._h = lib, handle
+        _live_engines.add(self)
         self.block_len, self.n_templates = int(block_len), int(tpl.shape[0])
         self.history_len = int(history_len)
         self.max_batch = int(max_batch)

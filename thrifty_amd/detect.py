@@ -1061,13 +1061,34 @@ def detector_cli(detector_class, parser=None, extra_args=None, argv=None):
             kwargs["low_cpu"] = parallel.cpu_budget() // max(1, world) < 4  # (fewer than 4 CPUs per rank)
         if args.dist_backend == "gloo":
             local = 0               # rehearsal: every rank computes on device 0
+        # torch, the process group and the gather rehearsal first: the engine's threads start with it
+        parallel.init_rank(rank, world, local, backend=args.dist_backend)
         detections = detector_class(settings, blocks, rxid=config.rxid, device_id=local, **kwargs)
-        if not hasattr(detections, "iter_detected_records"):
-            raise SystemExit("--gpus: %s does not expose iter_detected_records() (the records that "
-                             "travel between the ranks)" % type(detections).__name__)
-        parallel.run_sharded(detections, rank, world, local, output_file, backend=args.dist_backend)
+        try:
+            if not hasattr(detections, "iter_detected_records"):
+                raise SystemExit("--gpus: %s does not expose iter_detected_records() (the records that "
+                                 "travel between the ranks)" % type(detections).__name__)
+            parallel.run_sharded(detections, rank, world, local, output_file, backend=args.dist_backend)
+        finally:
+            _close(detections)
         return
     detections = detector_class(settings, blocks, rxid=config.rxid, **kwargs)
+    try:
+        _cli_loop(detections, args, config, output_file, info_out)
+    finally:
+        # the engine goes NOW (threads joined, pages unlocked, device memory back), not whenever the
+        # interpreter's shutdown gets to an object whose stages refer back to it
+        _close(detections)
+
+
+def _close(detections):
+    close = getattr(detections, "close", None)
+    if callable(close):
+        close()
+
+
+def _cli_loop(detections, args, config, output_file, info_out):
+    """The reference's loop (detect.py:214-223) over whatever detector class the caller passed."""
     if args.quiet and hasattr(detections, "only_detections"):
         detections.only_detections = True   # nothing is printed for the other blocks anyway
     if (args.quiet and output_file is not None and hasattr(detections, "write_toad")

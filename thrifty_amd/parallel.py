@@ -229,6 +229,38 @@ def relaunch_under_torchrun(gpus, argv):
     return subprocess.call(cmd, env=env)
 
 
+_rank_ready = {}      # (backend, local) -> device, once init_rank has run in this process
+
+
+def init_rank(rank, world, local, backend="nccl"):
+    """Everything a rank needs of torch BEFORE it touches the engine: `import torch` (which loads and
+    registers thousands of device code objects), the process group on `backend`, and the rehearsal of
+    the record gather -> the torch device the collectives run on.  `thrifty detect --gpus N` calls this
+    before it constructs the Detector: an engine with an input window has library threads inside the
+    HIP runtime (page-locking the mapping) from the moment it exists, and loading torch / starting
+    RCCL beside them is a way to find out which of the runtime's locks they share.  Idempotent;
+    run_sharded calls it again and gets the same device."""
+    import torch
+    import torch.distributed as dist
+    key = (backend, local)
+    if key in _rank_ready and dist.is_initialized():
+        return _rank_ready[key]
+    if backend == "nccl":       # RCCL; "gloo" (CPU tensors) is for the tests and the rehearsals
+        dev = torch.device("cuda", local)
+        torch.cuda.set_device(dev)
+        if not dist.is_initialized():
+            dist.init_process_group("nccl", device_id=dev)      # (default timeout: a rank's shard may be hours of capture)
+    else:
+        dev = torch.device("cpu")
+        if not dist.is_initialized():
+            dist.init_process_group(backend)
+    # before any work: the record gather must run on this backend with uneven and empty ranks
+    # (falls back to the all_gather form, or ends the run with a sentence)
+    gather_selftest(world, rank, dev)
+    _rank_ready[key] = dev
+    return dev
+
+
 def run_sharded(detections, rank, world, local, output_file, backend="nccl"):
     """Body of one rank of `thrifty detect --gpus N`: run this rank's block range, gather the
     detected records to rank 0 (RCCL), write one .toad there in input order.
@@ -242,18 +274,7 @@ def run_sharded(detections, rank, world, local, output_file, backend="nccl"):
     from thrifty_amd import _native
     from thrifty_amd.detect import _offset_mode
 
-    if backend == "nccl":       # RCCL; "gloo" (CPU tensors) is for the tests of this function
-        dev = torch.device("cuda", local)
-        torch.cuda.set_device(dev)
-        if not dist.is_initialized():
-            dist.init_process_group("nccl", device_id=dev)      # (default timeout: a rank's shard may be hours of capture)
-    else:
-        dev = torch.device("cpu")
-        if not dist.is_initialized():
-            dist.init_process_group(backend)
-    # before any work: the record gather must run on this backend with uneven and empty ranks
-    # (falls back to the all_gather form, or ends the run with a sentence)
-    gather_selftest(world, rank, dev)
+    dev = init_rank(rank, world, local, backend)
     # this rank's detected records, each with its timestamp in `reserved` (a mapped shard runs
     # inside the library: thr_run_card / thr_run_stream with a record sink)
     error, mine = None, np.zeros(0, dtype=_native.RECORD_DTYPE)
@@ -298,6 +319,7 @@ def run_sharded(detections, rank, world, local, output_file, backend="nccl"):
         output_file.flush()
     dist.barrier()
     dist.destroy_process_group()
+    _rank_ready.clear()
     if first_bad < world:
         raise error if error is not None else IndexError(
             "rank %d hit a block on which the reference raises IndexError" % first_bad)
