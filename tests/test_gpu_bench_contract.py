@@ -2,10 +2,12 @@
 keys, a recomputable `roofline`, `cpu_baseline`, and the legs of the other single-GPU configs."""
 import json
 import os
-import subprocess
 import sys
 
 import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import bounded_run  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -21,10 +23,9 @@ def test_default_run_line_has_every_contract_key():
     detail_path = os.path.join(ROOT, "gpurun_out", "bench_detail_c2_n1.json")
     if os.path.exists(detail_path):
         os.remove(detail_path)
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
-                          "--min-seconds", "0.2", "--leg-seconds", "0.1", "--cpu-seconds", "0.5",
-                          "--cpu-procs", "2", "--card-blocks", "256"],
-                         cwd=ROOT, capture_output=True, text=True, timeout=900)
+    res = bounded_run.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
+                           "--min-seconds", "0.2", "--leg-seconds", "0.1", "--cpu-seconds", "0.5",
+                           "--cpu-procs", "2", "--card-blocks", "256"], cwd=ROOT, timeout=600, label="bench_default")
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.split("\n") if ln.startswith("{")]
     assert len(lines) == 1
@@ -125,9 +126,8 @@ def test_gpus_n_launches_itself_and_the_whole_n_rank_body_runs_over_gloo(world):
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world),
-                          "--dist-backend", "gloo"] + SHORT,
-                         cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    res = bounded_run.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world),
+                           "--dist-backend", "gloo"] + SHORT, cwd=ROOT, timeout=500, env=env, label="bench_gloo%d" % world)
     d = _one_line(res)
     _check_dist_line(d, world, "gloo")
     assert res.stdout.strip().split("\n")[-1].startswith("{")       # the contract line is the LAST line
@@ -146,9 +146,9 @@ def test_strong_scaling_splits_one_gpus_job_over_the_ranks():
         env.pop(k, None)
     lines = {}
     for world in (1, 2):
-        res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world),
-                              "--dist-backend", "gloo", "--scaling", "strong"] + SHORT + ["--steps", "4"],
-                             cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+        res = bounded_run.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world),
+                               "--dist-backend", "gloo", "--scaling", "strong"] + SHORT + ["--steps", "4"],
+                              cwd=ROOT, timeout=500, env=env, label="bench_strong%d" % world)
         lines[world] = _one_line(res)
         assert lines[world]["scaling"] == "strong"
     one, two = lines[1], lines[2]
@@ -169,10 +169,10 @@ def test_one_rank_under_torchrun_runs_the_same_body_over_rccl():
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
-                          "--master-addr", "127.0.0.1", "--master-port", str(port),
-                          os.path.join(ROOT, "bench.py"), "--gpus", "1"] + SHORT,
-                         cwd=ROOT, capture_output=True, text=True, timeout=900)
+    res = bounded_run.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port),
+                           os.path.join(ROOT, "bench.py"), "--gpus", "1"] + SHORT, cwd=ROOT, timeout=500,
+                          label="bench_rccl1")
     d = _one_line(res)
     _check_dist_line(d, 1, "nccl")
     assert "pre-flight env: rank 0 " in res.stderr and "HSA_ENABLE_IPC_MODE_LEGACY=0" in res.stderr
@@ -185,7 +185,7 @@ def test_more_ranks_than_gpus_is_refused_legibly():
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + SHORT,
-                         cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    res = bounded_run.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + SHORT,
+                          cwd=ROOT, timeout=400, env=env, label="bench_refused")
     assert res.returncode != 0
     assert "one GPU per rank" in res.stderr

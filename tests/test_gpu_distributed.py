@@ -4,11 +4,13 @@ collectives); K = 2 and 8 run when the box has that many GPUs.  Rank 0's gathere
 must equal the single-process result byte for byte, ordered by block index."""
 import os
 import socket
-import subprocess
 import sys
 
 import numpy as np
 import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import bounded_run  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -30,12 +32,12 @@ def _world_sizes():
     return [k for k in (1, 2, 8) if k <= max(n, 1)]
 
 
-def _torchrun(k, target, extra, timeout=600):
+def _torchrun(k, target, extra, timeout=300):
     # (THRIFTY_SHARDED: what the CLI's own re-launch sets -- marks the ranks as its children)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT, THRIFTY_SHARDED="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(k),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + target + extra
-    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    res = bounded_run.run(cmd, env=env, cwd=ROOT, timeout=timeout, label="torchrun%d" % k)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     return res
 
@@ -104,9 +106,8 @@ def test_thrifty_detect_gpus_cli_writes_the_single_process_toad(golden, tmp_path
     common = [str(tmp_path / "rx.card"), "--quiet", "-c", str(tmp_path / "detector.cfg")]
     detector_cli(Detector, argv=common + ["-o", str(tmp_path / "one.toad")])
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
-    res = subprocess.run([sys.executable, "-m", "thrifty_amd.detect", "--gpus", str(k)] + common +
-                         ["-o", str(tmp_path / "many.toad")], env=env, cwd=ROOT, capture_output=True,
-                         text=True, timeout=600)
+    res = bounded_run.run([sys.executable, "-m", "thrifty_amd.detect", "--gpus", str(k)] + common +
+                          ["-o", str(tmp_path / "many.toad")], env=env, cwd=ROOT, timeout=300, label="cli%d" % k)
     if k == 1:      # --gpus 1 is the plain single-process CLI; also run it as ONE rank under torchrun
         assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
         _torchrun(1, ["-m", "thrifty_amd.detect"], ["--gpus", "1"] + common + ["-o", str(tmp_path / "rank.toad")])
@@ -139,9 +140,9 @@ def test_the_cli_with_more_ranks_than_gpus_rehearsed_over_gloo(golden, tmp_path,
     env = dict(os.environ, PYTHONPATH=ROOT)
     for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "THRIFTY_SHARDED"):
         env.pop(key, None)
-    res = subprocess.run([sys.executable, "-m", "thrifty_amd.detect", "--gpus", str(k), "--dist-backend", "gloo"]
-                         + common + ["-o", str(tmp_path / "many.toad")], env=env, cwd=ROOT, capture_output=True,
-                         text=True, timeout=900)
+    res = bounded_run.run([sys.executable, "-m", "thrifty_amd.detect", "--gpus", str(k), "--dist-backend", "gloo"]
+                          + common + ["-o", str(tmp_path / "many.toad")], env=env, cwd=ROOT, timeout=400,
+                          label="cli_gloo%d" % k)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
     one, many = (tmp_path / "one.toad").read_text(), (tmp_path / "many.toad").read_text()
     strip = (lambda t: [" ".join(ln.split()[:1] + ln.split()[2:]) for ln in t.strip().split("\n")]) if raw else (lambda t: t)
