@@ -215,11 +215,14 @@ def cpu_baseline(n, h, blocks_u8, idx, template, budget_s, gpu_rec, preshift_num
             "parity_checked": done, "parity_mismatches": mism}
 
 
-def _compute_view(kernel, n, n_templates, blocks_per_launch, avg_ms):
+def _compute_view(kernel, n, n_templates, blocks_per_launch, avg_ms, n_sec=0):
     """Nominal flop of the dominant kernel per block -> achieved TFLOP/s vs the VALU peak."""
     fft = 5.0 * n * np.log2(n)
     point = 6.0 * n
-    if kernel in ("k_correlate", "k_correlate_sub", "k_correlate_seg"):  # shift, FFT#2, then per template: product, IFFT, |.|^2
+    if kernel == "k_correlate_4k":   # per block n_sec sections of 4096 points: shift, FFT, product, IFFT, |.|^2
+        m = 4096.0
+        flop = n_sec * (6.0 * m + 5.0 * m * 12 + 6.0 * m + 5.0 * m * 12 + 3.0 * m)
+    elif kernel in ("k_correlate", "k_correlate_sub", "k_correlate_seg"):  # shift, FFT#2, then per template: product, IFFT, |.|^2
         flop = point + fft + n_templates * (point + fft + 3.0 * n)
     elif kernel == "k_preshift":     # FFT#1, |X|^2, product, IFFT, |.|^2
         flop = fft + 3.0 * n + point + fft + 3.0 * n
@@ -478,6 +481,10 @@ class Leg(object):
         self.sectioned = self.n > 16384 and not pnum and bool(F.plan_sections(self.n, self.h, self.wlen))
         self.engs = [F.Engine(self.n, self.h, self.tpls, self.thresh[0], self.cwin, self.thresh[1], device_id=local,
                               max_batch=self.B, preshift_num=pnum) for _ in range(n_handles)]
+        # block_len 16384, ONE short template: the correlate slot times k_correlate_4k over the (block,
+        # 4096-sample section) items (csrc/detect16k_sec.hip); the engine says whether it does
+        self.sec4k = self.engs[0].sections()[1] == 4096
+        self.n_sec = self.engs[0].sections()[0]
         self.resident_batches = max(1, (resident or cfg["resident"]) // self.B)
         self.total = self.resident_batches * self.B
         self.first = first
@@ -549,6 +556,8 @@ class Leg(object):
         rename = {}
         if self.pnum:   # the fused kernel is timed in k_correlate's event slot
             rename["k_correlate"] = "k_preshift"
+        if self.sec4k:
+            rename["k_correlate"] = "k_correlate_4k"
         if self.n > 16384:
             # long blocks: the correlate slot times k_correlate<SEG> over the (block, section) items --
             # or, for templates too long to section, the fused sub-transform + combination kernel
@@ -597,7 +606,7 @@ class Leg(object):
             except Exception:
                 traffic = clock = pipeline = stale = None
         alg_launch = self.bytes_per_block * units
-        comp = _compute_view(dom, self.n, self.T, units, avg_ms)
+        comp = _compute_view(dom, self.n, self.T, units, avg_ms, self.n_sec)
         roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "avg_launch_ms": avg_ms, "launches": dom_cnt, "blocks_per_launch": units,

@@ -40,7 +40,12 @@ extern "C" {
  *    thread), thr_get_settings, thr_input_window_ex (populator threads / segment size) / _release,
  *    thr_detect_offsets, thr_set_wait_mode, THR_PATH_GENERIC_ROWS, THR_ERR_INDEX, THR_FLAG_INT_OFFSET
  *    (additions only) */
-#define THR_ABI_VERSION 7
+/* 8: block_len 16384 with ONE template short enough for four 4096-sample sections (and no stddev
+ *    term in the correlation threshold): THR_PATH_AUTO runs the correlate stage sectioned
+ *    (csrc/detect16k_sec.hip); thr_plan_sections answers for block_len 16384 too,
+ *    THR_PATH_UNSECTIONED applies to it, + THR_PATH_UNSECTIONED_GENERIC_ROWS, thr_debug_sections
+ *    (additions; records of such handles change in the last bits of their float fields only) */
+#define THR_ABI_VERSION 8
 
 /* status codes */
 #define THR_OK 0
@@ -164,16 +169,21 @@ int thr_create_fastdet(const thr_settings* settings, thr_handle** out);
  *   THR_PATH_MULTIPASS    the generic multi-pass pipeline (Stockham passes through HBM) whatever
  *                         the block length -- an independent implementation of the same arithmetic,
  *                         kept for cross-checking the fused kernels on identical input;
- *   THR_PATH_UNSECTIONED  block_len 32768 / 65536 only: the correlate stage as ONE block_len-point
- *                         transform pair (decimated sub-transforms, detect_long.hip) instead of
- *                         overlap-save sections of 16384 points (detect_seg.hip).  AUTO falls back
- *                         to it by itself for templates longer than 9361 samples (at 65536) and for
- *                         thr_debug_stage dumps.
+ *   THR_PATH_UNSECTIONED  the correlate stage as ONE block_len-point transform pair instead of
+ *                         overlap-save sections: block_len 32768 / 65536 (decimated sub-transforms,
+ *                         detect_long.hip, instead of sections of 16384 points, detect_seg.hip --
+ *                         AUTO falls back to it by itself for templates longer than 9361 samples at
+ *                         65536) and block_len 16384 (k_correlate instead of up to four sections of
+ *                         4096 points, detect16k_sec.hip, which AUTO takes for ONE template of at
+ *                         most about 1000 samples with no stddev threshold term).  thr_debug_stage
+ *                         dumps always come from the unsectioned kernels.
  *   THR_PATH_GENERIC_ROWS AUTO, except that the correlate kernel of block_len 16384 (and of the
  *                         sections of longer blocks) is the generic one, with the unique-window test
  *                         in all 16 rows of lags, instead of the window-row specialisation the
  *                         geometry selects (csrc/correlate16k_geom.hpp): same arithmetic, so the
  *                         records are equal byte for byte -- which is what the tests use it for.
+ *                         (A sectioned block_len 16384 handle: the same, for its sections' rows.)
+ *   THR_PATH_UNSECTIONED_GENERIC_ROWS  both of the above (block_len 16384: the generic k_correlate).
  * All paths implement the same reference semantics and agree to rounding (tests/test_gpu_*.py).
  */
 #define THR_VARIANT_DEFAULT 0
@@ -187,6 +197,7 @@ int thr_create_fastdet(const thr_settings* settings, thr_handle** out);
 #define THR_PATH_MULTIPASS 1
 #define THR_PATH_UNSECTIONED 2
 #define THR_PATH_GENERIC_ROWS 3
+#define THR_PATH_UNSECTIONED_GENERIC_ROWS 4
 int thr_create_ex(const thr_settings* settings, int variant, int variant_arg, int path, thr_handle** out);
 /*
  * The overlap-save plan THR_PATH_AUTO uses for the correlate stage of a long block (host-only, no
@@ -199,9 +210,16 @@ int thr_create_ex(const thr_settings* settings, int variant, int variant_arg, in
  * window of soa_estimator.calculate_window (soa_estimator.py:20-39) and the sum ranges tile
  * [0, corr_len), each exactly once, ascending in g, and every searched lag has both neighbours
  * inside its section.  Arrays hold THR_MAX_SECTIONS ints.  *n_sections = 0 when the block is not
- * sectioned (block_len <= 16384, or more than THR_MAX_SECTIONS would be needed: templates longer
- * than 9361 samples at block_len 65536).  Geometry only: whether an engine handle
- * uses the plan also depends on its block length and path.
+ * sectioned (block_len < 16384, or more than THR_MAX_SECTIONS would be needed: templates longer
+ * than 9361 samples at block_len 65536).
+ * block_len 16384 (ABI 8): sections of 4096 samples, [start[g], start[g] + 4096), starts on multiples
+ * of 8 samples, at most FOUR (a fifth would cost more than the 16384-point transform pair: *n_sections
+ * = 0 then, as for templates longer than 4081 samples); only the unique window is tiled (win_lo /
+ * win_hi; sum_lo = sum_hi = start: a stddev threshold term keeps the unsectioned kernel), and a
+ * searched lag has both neighbours inside its section unless it is the first or the last kept lag
+ * of the block, where the reference takes no neighbours either (soa_estimator.py:163-164).
+ * Geometry only: whether an engine handle uses the plan also depends on its block length, template
+ * count, thresholds and path (thr_debug_sections).
  */
 #define THR_MAX_SECTIONS 8
 int thr_plan_sections(int block_len, int history_len, int template_len, int* n_sections, int* start,
@@ -524,6 +542,10 @@ const char* thr_kernel_name(int slot);
  *   a stddev threshold term, another block length or variant).  Decided by the same function the
  *   launcher calls. */
 int thr_debug_correlate_geom(thr_handle* h, int* rows_lo, int* rows_hi);
+/* thr_debug_sections: the overlap-save sections this handle's plain correlate launches run in:
+ *   *n_sections (0: unsectioned) of *section_len samples (16384 for long blocks, 4096 for block_len
+ *   16384). */
+int thr_debug_sections(thr_handle* h, int* n_sections, int* section_len);
 /* thr_debug_window: the input window's state, in bytes from its (page-aligned) start:
  *   out[0] = everything below this offset has been released by the chunk copies (may be unlocked),
  *   out[1], out[2] = the range that is page-locked now, out[3] = the segment size (0: no window). */

@@ -21,6 +21,8 @@ def short(name):
     m = re.search(r"k_correlate<[^>]*, (\w+)>", name)
     if m and m.group(1) in ("true", "1"):
         return "k_correlate_seg"
+    if "k_correlate_4k" in name:     # block_len 16384, short template: the (block, 4096-sample section) items
+        return "k_correlate_4k"
     for k in ("k_carrier_pruned", "k_carrier_dit", "k_carrier_sub_pruned", "k_carrier_sub", "k_carrier_small",
               "k_carrier", "k_select_dit", "k_select", "k_fit_preshift", "k_fit", "k_finish",
               "k_correlate_sub", "k_correlate_small", "k_correlate", "k_combine", "k_preshift",

@@ -49,7 +49,7 @@ def test_default_run_line_has_every_contract_key():
     # the main roofline object: recomputable, flat scalars only (the driver's record drops nested ones)
     r = d["roofline"]
     assert all(not isinstance(v, (dict, list)) for v in r.values())
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "k_correlate"
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "k_correlate_4k"
     want = r["algorithmic_bytes_per_block"] * r["blocks_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9
     assert abs(r["achieved"] - want) <= 1e-6 * want and abs(r["frac"] - want / 8000.0) <= 1e-9
     assert abs(r["pipeline_frac"] - d["value"] * r["algorithmic_bytes_per_block"] / 8e12) <= 1e-9

@@ -57,7 +57,9 @@ def test_the_table_covers_every_window_it_claims():
         rows_lo = (lo - 1) // 1024 if lo > 0 else 0          # rows whose last lag is below lo - 1
         rows_hi = (N - hi - 1) // 1024 if hi < N else 0      # rows whose first lag is above hi
         want = (rows_lo, rows_hi) if rows_lo <= 2 and rows_hi <= 4 else (-1, -1)
-        eng = F.Engine(N, h, np.sign(rng.normal(0, 1, w)), (0, 15, 0), (7, 110), (0, 15, 0), max_batch=1)
+        # (short templates run sectioned by default -- detect16k_sec.hip; the table is k_correlate's)
+        eng = F.Engine(N, h, np.sign(rng.normal(0, 1, w)), (0, 15, 0), (7, 110), (0, 15, 0), max_batch=1,
+                       path="unsectioned")
         assert eng.correlate_geom() == want, (h, w, lo, hi)
         eng.close()
         seen.add(want)
@@ -77,12 +79,14 @@ def test_bursts_on_the_window_edges_equal_the_oracle(h, w, geom):
     blocks, truth = synth.synth_blocks(rng, nb, N, tpl, (lo, hi), signal_frac=1.0, positions=pos,
                                        carrier_bins=(12.0, 100.0))
     thr = (0, 15, 0)
-    eng = F.Engine(N, h, tpl, thr, (7, 110), thr, max_batch=64)
-    assert eng.correlate_geom() == (geom or (-1, -1))
+    # (k_correlate itself: a one-template handle of a short template would run sectioned by default,
+    # tests/test_gpu_sections16k.py)
+    eng = F.Engine(N, h, tpl, thr, (7, 110), thr, max_batch=64, path="unsectioned")
+    assert eng.correlate_geom() == (geom or (-1, -1)) and eng.sections() == (0, 0)
     rec = eng.detect(blocks, np.arange(nb))[:, 0]
     # the same blocks through the generic kernel (window test in all 16 rows): equal byte for byte;
     # so are four templates per block (the MULTI variants of the same table entry) and complex64 input
-    gen = F.Engine(N, h, tpl, thr, (7, 110), thr, max_batch=64, path="generic_rows")
+    gen = F.Engine(N, h, tpl, thr, (7, 110), thr, max_batch=64, path="unsectioned_generic_rows")
     assert gen.correlate_geom() == (-1, -1)
     assert gen.detect(blocks, np.arange(nb))[:, 0].tobytes() == rec.tobytes()
     tpl4 = np.stack([tpl, -tpl[::-1], np.roll(tpl, 7), tpl * np.sign(rng.normal(0, 1, w))])

@@ -59,7 +59,7 @@ def test_plan_tiles_window_and_lags_exactly_once(n, h, w):
     assert np.array_equal(win_seen, expect)
 
 
-@pytest.mark.parametrize("n,h,w", [(16384, 4096, 1023), (65536, 9400, 9362), (65536, 20000, 16384),
+@pytest.mark.parametrize("n,h,w", [(16384, 4920, 4914), (16384, 1100, 1023), (65536, 9400, 9362), (65536, 20000, 16384),
                                    (8192, 2048, 511), (131072, 12000, 12000)])
 def test_geometries_that_are_not_sectioned(n, h, w):
     assert _plan(n, h, w) == []

@@ -23,7 +23,7 @@ FLAG_INDEX_ERROR = 4
 FLAG_INT_OFFSET = 8
 N_KERNEL_SLOTS = 5
 
-ABI_VERSION = 7     # THR_ABI_VERSION of include/thrifty_hip.h
+ABI_VERSION = 8     # THR_ABI_VERSION of include/thrifty_hip.h
 
 EXPORTS = [
     "thr_abi_version", "thr_last_error", "thr_create", "thr_destroy", "thr_detect",
@@ -32,12 +32,12 @@ EXPORTS = [
     "thr_debug_stage", "thr_debug_stage_offsets", "thr_identify", "thr_frame_card",
     "thr_submit", "thr_submit_card", "thr_submit_stream", "thr_collect", "thr_inputs_consumed", "thr_poll",
     "thr_set_stream_default", "thr_format_toad",
-    "thr_run_card", "thr_run_stream", "thr_get_settings", "thr_input_window_ex", "thr_input_window_release", "thr_detect_offsets", "thr_set_wait_mode", "thr_debug_window", "thr_debug_window_times", "thr_debug_correlate_geom", "thr_debug_pipe_times",
+    "thr_run_card", "thr_run_stream", "thr_get_settings", "thr_input_window_ex", "thr_input_window_release", "thr_detect_offsets", "thr_set_wait_mode", "thr_debug_window", "thr_debug_window_times", "thr_debug_correlate_geom", "thr_debug_sections", "thr_debug_pipe_times",
 ]
 ERR_ARG, ERR_DEVICE, ERR_STATE, ERR_INDEX = -1, -2, -3, -4       # THR_ERR_*
 VARIANT_DEFAULT, VARIANT_PRESHIFT, VARIANT_FASTDET = 0, 1, 2      # THR_VARIANT_*
 INTERPOLATORS = {"parabolic": 0, "none": 1, "gaussian": 2, "cosine": 3}      # THR_INTERP_*
-PATHS = {"auto": 0, "multipass": 1, "unsectioned": 2, "generic_rows": 3}      # THR_PATH_*
+PATHS = {"auto": 0, "multipass": 1, "unsectioned": 2, "generic_rows": 3, "unsectioned_generic_rows": 4}      # THR_PATH_*
 MAX_IN_FLIGHT = 3       # THR_MAX_IN_FLIGHT
 TOAD_LINE_MAX = 384     # THR_TOAD_LINE_MAX
 
@@ -610,6 +610,14 @@ class Engine(object):
         self._lib.thr_debug_correlate_geom.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         _check(self._lib, self._lib.thr_debug_correlate_geom(self._h, C.byref(lo), C.byref(hi)))
         return lo.value, hi.value
+
+    def sections(self):
+        """thr_debug_sections -> (n_sections, section_len) of this handle's plain correlate launches
+        ((0, 0): unsectioned)."""
+        n, ln = C.c_int(0), C.c_int(0)
+        self._lib.thr_debug_sections.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        _check(self._lib, self._lib.thr_debug_sections(self._h, C.byref(n), C.byref(ln)))
+        return n.value, ln.value
 
     def debug_pipe_times(self):
         """thr_debug_pipe_times -> seconds per phase of the host entry points' chunks (reads and resets)."""

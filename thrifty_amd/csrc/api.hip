@@ -356,6 +356,8 @@ struct thr_handle {
     bool seg = false;               // long: correlate stage as overlap-save sections (detect_seg.hip)
     float4* d_tspec16k = nullptr;   // sectioned: templates zero-padded to 16384, k_correlate's layout
     thr::CorrStats* d_seg_stats = nullptr;   // sectioned: [long_batch][T][n_seg]
+    bool sec4k = false;             // block_len 16384, short template: correlate stage as 4096-sample sections (detect16k_sec.hip)
+    float4* d_tspec4k = nullptr;    // sec4k: the template zero-padded to 4096, the short-block kernels' layout
     int path = 0;                   // THR_PATH_* the handle was created with
     int gen_batch = 0;       // generic path: blocks per internal sub-batch
     float2* d_gen_scratch = nullptr;  // generic path: 3 * gen_batch * N complex
@@ -520,6 +522,44 @@ bool plan_sections(thr::DevCfg& d, int template_len) {
     return true;
 }
 
+// The same idea one size down (detect16k_sec.hip): a 16384-sample block whose template is short
+// enough that FOUR 4096-sample sections or fewer cover its unique window [corr_lo, corr_hi) -- then
+// the sections' transforms cost less than the block's (4 x 4096 x 12 < 16384 x 14 butterfly
+// stages).  Only the window is covered (no stddev term on this path: its sums run over every kept
+// lag).  A section holds V = 4096 - W + 1 exact lags; it owns at most V - 2 of them (the lag below
+// and the lag above every owned lag must be in it too, for the peak's neighbours,
+// soa_estimator.py:159-170 -- except at the two ends of the kept lags, where the reference takes no
+// neighbours either).  Sections start on multiples of 8 samples (u8 samples are fetched 16 bytes
+// per thread), every D = (V - 2) & ~7 samples from the last multiple of 8 at or below corr_lo - 1,
+// the last one no later than block_len - 4096.  BASELINE (history 4096, 1023 samples): starts
+// 1536 + 3072 g, every section owns its lags [1, 3073).
+bool plan_sections_4k(thr::DevCfg& d, int template_len) {
+    const int m = 4096, n = d.block_len;
+    d.n_seg = 0;
+    const int v = m - template_len + 1;
+    if (n != 16384 || v < 16) return false;
+    const int stride = (v - 2) & ~7;
+    const int s0 = std::max(d.corr_lo - 1, 0) & ~7;
+    int own_lo = d.corr_lo, g = 0;
+    while (own_lo < d.corr_hi) {
+        if (g == 4) return false;      // a fifth section: the 16384-point kernel is cheaper
+        const int start = std::min(s0 + g * stride, n - m);
+        // lags [start, start + v) are in the section; it owns from the previous section's end up to its
+        // last lag but one -- or up to its last lag, where that is the last kept lag of the block
+        const int cap = start + v == d.corr_len ? d.corr_len : start + v - 1;
+        const int own_hi = std::min(cap, d.corr_hi);
+        if (own_hi <= own_lo || (own_lo > 0 && own_lo - 1 < start)) return false;
+        d.seg_start[g] = start;
+        d.seg_lo[g] = own_lo - start;
+        d.seg_hi[g] = own_hi - start;
+        d.seg_sum_lo[g] = d.seg_sum_hi[g] = 0;
+        own_lo = own_hi;
+        ++g;
+    }
+    d.n_seg = g;
+    return g > 0;
+}
+
 int build_constants(thr_handle* h) {
     const int n = h->cfg.block_len;
     // --- LDS twiddle tables (forward sign): C[32][32], A[16][32], Bt[16][32]  (fast path)
@@ -536,7 +576,7 @@ int build_constants(thr_handle* h) {
     // --- pass-1 / pass-B twiddles W_16384^(k1 q) of k_correlate (one template) and of the
     //     short-block kernels as one L2-resident table in global memory
     h->dev.gtw = nullptr;
-    if (h->small || h->fast || h->seg) {
+    if (h->small || h->fast || h->seg || h->sec4k) {
         std::vector<float2> g(16 * 1024);
         for (int k1 = 0; k1 < 16; ++k1)
             for (int q = 0; q < 1024; ++q) g[k1 * 1024 + q] = unit_root((long long)k1 * q, 16384);
@@ -619,6 +659,23 @@ int build_constants(thr_handle* h) {
         }
         HIP_TRY(hipMalloc(&h->d_tspec16k, s16.size() * sizeof(float2)));
         HIP_TRY(hipMemcpy(h->d_tspec16k, s16.data(), s16.size() * sizeof(float2), hipMemcpyHostToDevice));
+    }
+    if (h->sec4k) {
+        // 4096-sample sections of a 16384-sample block: conj(FFT(template zero-padded to 4096)) / 4096,
+        // thread column c = row * 32 + k2 holds bins row + 4 k2 + 128 k3 (the short-block layout, R1 = 4)
+        const int m = 4096, r1 = 4, tb = 128;
+        std::vector<float2> s4(m);
+        std::vector<std::complex<double>> buf(m, 0.0);
+        for (int i = 0; i < w; ++i) buf[i] = h->cfg.templates[i];
+        host_fft(buf);
+        for (int c = 0; c < tb; ++c)
+            for (int k3 = 0; k3 < 32; ++k3) {
+                const int k = (c >> 5) + r1 * (c & 31) + tb * k3;
+                const std::complex<double> cc = std::conj(buf[k]) / double(m);
+                s4[((k3 >> 1) * tb + c) * 2 + (k3 & 1)] = float2{float(cc.real()), float(cc.imag())};
+            }
+        HIP_TRY(hipMalloc(&h->d_tspec4k, s4.size() * sizeof(float2)));
+        HIP_TRY(hipMemcpy(h->d_tspec4k, s4.data(), s4.size() * sizeof(float2), hipMemcpyHostToDevice));
     }
     float2* d_spec = nullptr;
     HIP_TRY(hipMalloc(&d_spec, spec.size() * sizeof(float2)));
@@ -876,16 +933,26 @@ int run_batch_fast(thr_handle* h, const void* d_samples_all, int format,
                                     h->d_work_list, h->d_work_count, d_out, h->d_corr_stats, h->stream,
                                     h->forced ? h->forced + off : nullptr));
         }
+        // short template: 4096-sample sections, four 2-wave workgroups per CU (detect16k_sec.hip);
+        // the stage dumps are the unsectioned kernel's
+        const bool sec = h->sec4k && !dump_xhat && !dump_corr;
         {
             ProfScope p(h, 2);
-            HIP_TRY(thr::launch_correlate_16k(
-                format, d_samples, h->dev, h->d_tables, h->d_twn, h->d_tspec, h->d_shifts, h->d_work_list,
-                h->d_work_count, h->d_corr_stats, dump_xhat, dump_corr, dump_template, grid, h->stream));
+            if (sec)
+                HIP_TRY(thr::launch_correlate_4k(format, d_samples, h->dev, h->d_tables, h->d_twn, h->d_tspec4k,
+                                                 h->d_shifts, h->d_work_list, h->d_work_count, h->d_seg_stats,
+                                                 int(std::min<long long>((long long)n_blocks * h->dev.n_seg,
+                                                                         4ll * h->n_cu)),
+                                                 h->stream));
+            else
+                HIP_TRY(thr::launch_correlate_16k(
+                    format, d_samples, h->dev, h->d_tables, h->d_twn, h->d_tspec, h->d_shifts, h->d_work_list,
+                    h->d_work_count, h->d_corr_stats, dump_xhat, dump_corr, dump_template, grid, h->stream));
         }
         {
             ProfScope p(h, 3);
             HIP_TRY(thr::launch_finish(n_blocks * h->cfg.n_templates, h->dev, h->d_corr_stats, d_out,
-                                       h->d_work_count, h->stream));
+                                       h->d_work_count, h->stream, sec ? h->d_seg_stats : nullptr));
         }
     }
     return THR_OK;
@@ -1230,6 +1297,15 @@ int thr_debug_correlate_geom(thr_handle* h, int* rows_lo, int* rows_hi) try {
     return thr::on_exception("thr_debug_correlate_geom");
 }
 
+int thr_debug_sections(thr_handle* h, int* n_sections, int* section_len) try {
+    if (!h || !n_sections || !section_len) return fail(THR_ERR_ARG, "thr_debug_sections: null argument");
+    *n_sections = (h->seg || h->sec4k) ? h->dev.n_seg : 0;
+    *section_len = h->sec4k ? 4096 : h->seg ? 16384 : 0;
+    return THR_OK;
+} catch (...) {
+    return thr::on_exception("thr_debug_sections");
+}
+
 int thr_debug_pipe_times(thr_handle* h, double out[16]) try {
     if (!h || !out) return fail(THR_ERR_ARG, "thr_debug_pipe_times: null argument");
     for (int i = 0; i < 8; ++i) {
@@ -1285,7 +1361,10 @@ int thr_plan_sections(int block_len, int history_len, int template_len, int* n_s
     const int pad = history_len - template_len + 1;   // soa_estimator.py:20-39
     d.corr_lo = pad / 2;
     d.corr_hi = d.corr_len - (pad - pad / 2);
-    plan_sections(d, template_len);
+    if (block_len == 16384)
+        plan_sections_4k(d, template_len);   // (4096-sample sections; the sums are not sectioned: 0, 0)
+    else
+        plan_sections(d, template_len);
     *n_sections = d.n_seg;
     for (int g = 0; g < d.n_seg; ++g) {
         start[g] = d.seg_start[g];
@@ -1301,7 +1380,7 @@ int thr_plan_sections(int block_len, int history_len, int template_len, int* n_s
 
 int thr_create_ex(const thr_settings* s, int variant, int variant_arg, int path, thr_handle** out) try {
     if (path != THR_PATH_AUTO && path != THR_PATH_MULTIPASS && path != THR_PATH_UNSECTIONED &&
-        path != THR_PATH_GENERIC_ROWS)
+        path != THR_PATH_GENERIC_ROWS && path != THR_PATH_UNSECTIONED_GENERIC_ROWS)
         return fail(THR_ERR_ARG, "thr_create_ex: unknown path %d", path);
     switch (variant) {
         case THR_VARIANT_DEFAULT: return create_impl(s, 0, out, -1, path);
@@ -1424,11 +1503,17 @@ static int create_body(thr_handle*& h, const thr_settings* s, int preshift_num, 
                 d.car_prune = 2;  // any narrow window: pre-shift by win_lo - 3
         }
         d.cor_want_std = s->corr_thresh[2] != 0.0;
-        d.no_row_geom = path == THR_PATH_GENERIC_ROWS;
+        d.no_row_geom = path == THR_PATH_GENERIC_ROWS || path == THR_PATH_UNSECTIONED_GENERIC_ROWS;
         h->small = thr::small_supported(n) && !multipass && !preshift_num;
         // long blocks: the correlate stage in overlap-save sections wherever the template allows
-        h->seg = h->lng && path != THR_PATH_UNSECTIONED && plan_sections(d, s->template_len);
+        const bool unsectioned = path == THR_PATH_UNSECTIONED || path == THR_PATH_UNSECTIONED_GENERIC_ROWS;
+        h->seg = h->lng && !unsectioned && plan_sections(d, s->template_len);
         if (!h->seg) d.n_seg = 0;
+        // block_len 16384, one short template, no stddev term: the correlate stage as 4096-sample
+        // sections (detect16k_sec.hip); stage dumps and every other launch keep k_correlate
+        h->sec4k = h->fast && !preshift_num && d.variant == 0 && s->n_templates == 1 && !d.cor_want_std &&
+                   !unsectioned && plan_sections_4k(d, s->template_len);
+        if (!h->seg && !h->sec4k) d.n_seg = 0;
 
         h->cfg.templates = s->templates;
         rc = build_constants(h);
@@ -1497,6 +1582,7 @@ static int create_body(thr_handle*& h, const thr_settings* s, int preshift_num, 
         CREATE_TRY(hipMalloc(&h->d_stats, mb * sizeof(thr::CarStats)));
         CREATE_TRY(hipMalloc(&h->d_shifts, mb * sizeof(thr::ShiftParams)));
         CREATE_TRY(hipMalloc(&h->d_corr_stats, mb * s->n_templates * sizeof(thr::CorrStats)));
+        if (h->sec4k) CREATE_TRY(hipMalloc(&h->d_seg_stats, mb * size_t(d.n_seg) * sizeof(thr::CorrStats)));
         CREATE_TRY(hipMalloc(&h->d_work_list, mb * sizeof(int)));
         CREATE_TRY(hipMalloc(&h->d_work_count, 4 * sizeof(int)));  // [0] work count, [1] dynamic cursor
         CREATE_TRY(hipMemset(h->d_work_count, 0, 4 * sizeof(int)));  // re-armed by k_finish
@@ -1542,7 +1628,7 @@ void thr_destroy(thr_handle* h) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
     }
-    void* bufs[] = {h->d_tables, h->d_twn, h->d_tspec, h->d_stats, h->d_shifts, h->d_corr_stats, h->d_gen_scratch, h->d_tspec_nat, h->d_bank, h->d_gtw, h->d_tspec16k, h->d_seg_stats, h->d_win_pow, h->d_partial, h->d_dsub, h->d_work_list,
+    void* bufs[] = {h->d_tables, h->d_twn, h->d_tspec, h->d_stats, h->d_shifts, h->d_corr_stats, h->d_gen_scratch, h->d_tspec_nat, h->d_bank, h->d_gtw, h->d_tspec16k, h->d_tspec4k, h->d_seg_stats, h->d_win_pow, h->d_partial, h->d_dsub, h->d_work_list,
                     h->d_work_count, h->d_xhat_scratch, h->d_ncompact, h->d_compact_tiles, h->d_in, h->d_idx, h->d_rec, h->d_forced};
     for (void* b : bufs)
         if (b) (void)hipFree(b);

@@ -36,8 +36,9 @@ struct DevCfg {
     const void* gtw;   // [16][1024] W_16384^(k1 q) for k_correlate's passes 1 and B (kernels compiled for the LDS-table form ignore it)
     int variant;       // 0 reference Detector, 1 PreshiftDetector, 2 fastdet-compatible (power-domain verdicts)
     int interp;        // PreshiftDetector: carrier interpolator (THR_INTERP_*: 0 parabolic, 1 none, 2 gaussian, 3 cosine)
-    // Overlap-save sections of the correlate stage (block_len > 16384, detect_seg.hip; 0 = none):
-    // section g covers samples [seg_start[g], seg_start[g] + 16384) of a block.  In SECTION
+    // Overlap-save sections of the correlate stage (0 = none): block_len > 16384 (detect_seg.hip):
+    // section g covers samples [seg_start[g], seg_start[g] + 16384) of a block; block_len 16384 with a
+    // short template (detect16k_sec.hip): [seg_start[g], seg_start[g] + 4096).  In SECTION
     // coordinates (lag - seg_start[g]): it owns the window lags [seg_lo[g], seg_hi[g]) and, for the
     // stddev term, sums the lags [seg_sum_lo[g], seg_sum_hi[g]); the owned ranges tile the block's
     // [corr_lo, corr_hi) resp. [0, corr_len) exactly once (plan_sections, api.hip).
@@ -129,6 +130,15 @@ hipError_t launch_correlate_seg(int fmt, const void* samples, const DevCfg& cfg,
                                 const float2* twn, const float4* tspec16k, const ShiftParams* shifts,
                                 const int* work_list, const int* work_count, CorrStats* seg_stats,
                                 int grid, hipStream_t stream);
+
+// detect16k_sec.hip (block_len 16384, ONE short template, no stddev term: the correlate stage as up
+// to four overlap-save sections of 4096 samples, a 128-thread workgroup each; seg_stats:
+// [block][section]; tspec4k = the template zero-padded to 4096, the short-block kernels' layout)
+size_t lds_bytes_4k();
+hipError_t launch_correlate_4k(int fmt, const void* samples, const DevCfg& cfg, const float2* tables,
+                               const float2* twn, const float4* tspec4k, const ShiftParams* shifts,
+                               const int* work_list, const int* work_count, CorrStats* seg_stats,
+                               int grid, hipStream_t stream);
 
 // detect_long.hip (block_len = 2 or 4 x 16384: R0 LDS-resident sub-transforms per block)
 bool long_supported(int block_len);
