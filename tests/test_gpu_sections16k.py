@@ -29,7 +29,7 @@ CASES = [
     (8200, 1023, 3),
     (2300, 200, 4),      # sections of 3896 kept lags: row 3 partly owned
     (6200, 1200, 4),
-    (12300, 30, 2),
+    (10000, 300, 2),
 ]
 
 

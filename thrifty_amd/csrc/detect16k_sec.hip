@@ -298,20 +298,34 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(2))) void k_
                size_t(cfg.seg_start[item & 7]) * kSampleBytes;
     };
 
+    // Work distribution: a TICKET is one carrier-positive block, its n_seg sections are consecutive
+    // items of one workgroup (items = ticket * n_seg + section).  A workgroup's first two tickets are
+    // static (g and g + G), every later one comes from a global cursor -- one atomic per BLOCK: with
+    // one per section (131072 same-address atomics per 1.5 ms launch) the kernel ran at the pace of
+    // the cursor, whatever else was taken out of it.  The cursor is read by thread 0 at the top of
+    // the iteration that needs it and handed round through LDS across the pass-1 barrier, two items
+    // ahead of its use.
+    const int G = int(gridDim.x);
+    auto last_of_ticket = [&](int wi) -> bool { return n_seg == 4 ? ((wi + 1) & 3) == 0 : (wi + 1) % n_seg == 0; };
+    bool static_ticket = true;   // ticket g + G not handed out yet
+    int wi0 = int(blockIdx.x) * n_seg, wi_nxt;
+    if (!last_of_ticket(wi0)) {
+        wi_nxt = wi0 + 1;
+    } else {
+        wi_nxt = (int(blockIdx.x) + G) * n_seg;
+        static_ticket = false;
+    }
     RawQ<FMT> cur;
-    int it_next = int(blockIdx.x) < n_work ? item_at(blockIdx.x) : 0;
-    int it_next2 = int(blockIdx.x + gridDim.x) < n_work ? item_at(blockIdx.x + gridDim.x) : 0;
+    int it_next = wi0 < n_work ? item_at(wi0) : 0;
+    int it_next2 = wi_nxt < n_work ? item_at(wi_nxt) : 0;
     int blk_next2 = it_next2 >> 3, seg_next2 = it_next2 & 7;
-    if (int(blockIdx.x) < n_work) {
+    if (wi0 < n_work) {
         cur.load(item_samples(it_next), opaque_tid());
         q_phasor_store(q_phasor_fetch(shifts + (it_next >> 3), it_next & 7, twn, opaque_tid()), opaque_tid(), sc_ph);
     }
     __syncthreads();
-    // work distribution as in k_correlate: two static items per workgroup (their prefetches are in
-    // flight), every later one from a global cursor fetched two iterations ahead
     int* dyn_ctr = const_cast<int*>(work_count) + 1;
-    int wi_nxt = int(blockIdx.x + gridDim.x);
-    for (int wi = blockIdx.x, iter = 0; wi < n_work; ++iter) {
+    for (int wi = wi0, iter = 0; wi < n_work; ++iter) {
 #ifdef THR_DEV
         const bool tl_on = blockIdx.x == 0 && iter == 40 && cfg.timeline != nullptr;
 #endif
@@ -321,8 +335,14 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(2))) void k_
         const int t = opaque_tid();
         const ShiftParams* sp = shifts + b;
         // (the cursor's value is first touched behind pass 1: nothing waits for the atomic's round trip)
+        const bool need_ticket = last_of_ticket(wi_nxt);
         int wi_dyn = 0;
-        if (t == 0) wi_dyn = atomicAdd(dyn_ctr, 1);
+#ifdef THR_Q_STATIC   // dev A/B: tickets g, g + G, g + 2 G, ... (no cursor)
+        (void)dyn_ctr;
+        wi_dyn = (wi_nxt + 1) / n_seg - 1 - G;   // the ticket after T is T + G = 2 G + wi_dyn
+#else
+        if (t == 0 && need_ticket && !static_ticket) wi_dyn = atomicAdd(dyn_ctr, 1);
+#endif
         RawQ<FMT> nxt = cur;
         const bool more = wi_nxt < n_work;
         if (more) {
@@ -341,11 +361,14 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(2))) void k_
         }
         cur = nxt;
         THR_STAMP(2);
-        if (t == 0) *sc_dyn = 2 * int(gridDim.x) + wi_dyn;
+        if (t == 0)
+            *sc_dyn = !need_ticket ? wi_nxt + 1
+                                   : (static_ticket ? int(blockIdx.x) + G : 2 * G + wi_dyn) * n_seg;
+        if (need_ticket) static_ticket = false;
         THR_STAMP(3);
         __syncthreads();
         THR_STAMP(4);
-        const int wi_nxt2 = *sc_dyn;
+        const int wi_nxt2 = __builtin_amdgcn_readfirstlane(*sc_dyn);
         if (wi_nxt2 < n_work) {
             const int e = item_entry(wi_nxt2);
             blk_next2 = work_list[e];
@@ -400,15 +423,11 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(2))) void k_
         // correlate16k.hpp).  Lag n = n1 * 1024 + 8 t + j is q = n1 * 8 + j of the thread, ascending.
         const int w_lo = cfg.seg_lo[seg], w_hi = cfg.seg_hi[seg];
         const int m0 = t * QA;
-        // the thread's powers go to LDS as well -- into the first half of the 8-complex run of each row
-        // that ONLY this thread read in pass C and only it writes in the next pass 1: a private
-        // array with run-time indexing, for the peak's neighbours below
-        float* pwl = reinterpret_cast<float*>(lds + (m0 >> 5) * CHUNK + (m0 & 31));
+        float pw[QR * QA];   // (the whole-rows search leaves row 3 beyond lag 3073 unset: never read)
         float wmax;
         unsigned lag;
         const bool whole_rows = !GENERIC_ROWS && w_lo <= 1 && w_hi >= 3 * 1024 && w_hi <= 3 * 1024 + 1;
         if (whole_rows) {
-            float pw[3 * QA + 2];
             float tmax = -1.0f;
             static_for<3 * QA / 2 + 1>([&](auto Q) {
                 constexpr int q = 2 * decltype(Q)::value;
@@ -426,13 +445,8 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(2))) void k_
                 else
                     tmax = __builtin_fmaxf(tmax, __builtin_fmaxf(pw[q], pw[q + 1]));
             });
-            static_for<3>([&](auto K) {
-                constexpr int n1 = decltype(K)::value;
-                f4* dst = reinterpret_cast<f4*>(pwl + n1 * (2 * ROW));
-                dst[0] = f4{pw[n1 * 8], pw[n1 * 8 + 1], pw[n1 * 8 + 2], pw[n1 * 8 + 3]};
-                dst[1] = f4{pw[n1 * 8 + 4], pw[n1 * 8 + 5], pw[n1 * 8 + 6], pw[n1 * 8 + 7]};
-            });
-            *reinterpret_cast<float2*>(pwl + 3 * (2 * ROW)) = float2{pw[24], pw[25]};
+#pragma unroll
+            for (int q = 3 * QA + 2; q < QR * QA; ++q) pw[q] = 0.f;
             wmax = wave_max_f32(tmax);
             int first = 63;   // the thread's first lag (n1 * 8 + j) that holds the wave's maximum
             first = e24 == wmax ? 24 : first;
@@ -444,7 +458,7 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(2))) void k_
             lag = first == 63 ? 0xFFFFFFFFu : unsigned((first >> 3) * 1024 + m0 + (first & 7));
         } else {
             const unsigned win_w = unsigned(w_hi - w_lo);
-            float pw[QR * QA], ew[QR * QA];
+            float ew[QR * QA];
             float tmax = -1.0f;
             static_for<QR * QA / 2>([&](auto Q) {
                 constexpr int q = 2 * decltype(Q)::value;
@@ -455,12 +469,6 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(2))) void k_
                 ew[q] = unsigned(n - w_lo) < win_w ? pw[q] : -1.f;
                 ew[q + 1] = unsigned(n + 1 - w_lo) < win_w ? pw[q + 1] : -1.f;
                 tmax = __builtin_fmaxf(tmax, __builtin_fmaxf(ew[q], ew[q + 1]));
-            });
-            static_for<QR>([&](auto K) {
-                constexpr int n1 = decltype(K)::value;
-                f4* dst = reinterpret_cast<f4*>(pwl + n1 * (2 * ROW));
-                dst[0] = f4{pw[n1 * 8], pw[n1 * 8 + 1], pw[n1 * 8 + 2], pw[n1 * 8 + 3]};
-                dst[1] = f4{pw[n1 * 8 + 4], pw[n1 * 8 + 5], pw[n1 * 8 + 6], pw[n1 * 8 + 7]};
             });
             wmax = wave_max_f32(tmax);
             int first = 63;
@@ -479,15 +487,27 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(2))) void k_
         parity ^= 1;
         const int pk = int(0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu));
         CorrStats* cs = seg_stats + (size_t(b) * cfg.n_templates) * n_seg + seg;
-        // |corr[pk - 1 .. pk + 1]|^2 for the log-parabola: the thread that holds lag n reads it back
-        // from its private run (its own stores, in program order: no barrier)
+        // |corr[pk - 1 .. pk + 1]|^2 for the log-parabola.  pk is uniform in the workgroup, so WHICH of
+        // its 32 powers a thread would contribute, q = n1 * 8 + j of lag n = n1 * 1024 + 8 t + j, is
+        // uniform too: one scalar jump picks the register, the one thread that holds the lag stores it
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const int n = pk - 1 + d;
-            if (n >= 0 && n < QN && ((n & 1023) >> 3) == t)
-                cs->m2[d] = pwl[(n >> 10) * (2 * ROW) + (n & 7)];
-            else if (t == 0 && (n < 0 || n >= QN))
-                cs->m2[d] = 0.f;   // (a peak on lag 0 of the block: k_finish does not use it)
+            if (n < 0 || n >= QN) {
+                if (t == 0) cs->m2[d] = 0.f;   // (a peak on lag 0 of the block: k_finish does not use it)
+                continue;
+            }
+            const int q = __builtin_amdgcn_readfirstlane((n >> 10) * QA + (n & 7));
+            float val = 0.f;
+            switch (q) {
+#define THR_Q_CASE(Q) case Q: val = pw[Q]; break;
+                THR_Q_CASE(0) THR_Q_CASE(1) THR_Q_CASE(2) THR_Q_CASE(3) THR_Q_CASE(4) THR_Q_CASE(5) THR_Q_CASE(6) THR_Q_CASE(7)
+                THR_Q_CASE(8) THR_Q_CASE(9) THR_Q_CASE(10) THR_Q_CASE(11) THR_Q_CASE(12) THR_Q_CASE(13) THR_Q_CASE(14) THR_Q_CASE(15)
+                THR_Q_CASE(16) THR_Q_CASE(17) THR_Q_CASE(18) THR_Q_CASE(19) THR_Q_CASE(20) THR_Q_CASE(21) THR_Q_CASE(22) THR_Q_CASE(23)
+                THR_Q_CASE(24) THR_Q_CASE(25) THR_Q_CASE(26) THR_Q_CASE(27) THR_Q_CASE(28) THR_Q_CASE(29) THR_Q_CASE(30) THR_Q_CASE(31)
+#undef THR_Q_CASE
+            }
+            if (((n & 1023) >> 3) == t) cs->m2[d] = val;
         }
         if (t == 0) {
             cs->pm2 = __uint_as_float(unsigned(best >> 32));
