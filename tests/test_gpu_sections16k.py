@@ -62,9 +62,9 @@ def test_sectioned_records_equal_the_oracle_and_the_unsectioned_kernel(h, w, nse
     nb = len(pos)
     blocks, _ = synth.synth_blocks(rng, nb, N, tpl, (lo, hi), signal_frac=1.0, positions=pos,
                                    carrier_bins=(12.0, 100.0))
-    # a fifth of the blocks carry noise only (a carrier tone without the code reaches the correlate stage too)
+    # a fifth of the randomly placed blocks carry noise only (a carrier tone without the code reaches the correlate stage too)
     tone = np.exp(2j * np.pi * 40.3 * np.arange(N) / N) * 0.05
-    for i in range(0, nb, 5):
+    for i in range(2 * len(edge), nb, 5):
         z = rng.normal(0, 0.02, N) + 1j * rng.normal(0, 0.02, N) + tone
         blocks[i] = synth.quantise_iq(z)
     eng = F.Engine(N, h, tpl, THR, (7, 110), THR, max_batch=64)
