@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Rewrite the numbers of README.md's "Measured" table and DESIGN.md's section-6 table from a saved
+default run of bench.py (profiles/r05_bench_default_run.json), which tests/test_docs_match_records.py
+holds them to.    python scripts/fill_tables.py [record.json]"""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rec = json.load(open(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r05_bench_default_run.json")))
+summary = rec["summary"]
+legs = dict(rec["configs"], c2=dict(rec["roofline"], value=rec["value"]))
+
+
+def mega(v):
+    return "%.2f M" % (v / 1e6)
+
+
+def rewrite(path, fn):
+    out = []
+    for line in open(os.path.join(ROOT, path), encoding="utf-8"):
+        cells = [c.strip() for c in line.strip().strip("|").split("|")]
+        m = re.fullmatch(r"`(\w+)`", cells[0]) if cells else None
+        if m and m.group(1) in summary and len(cells) == 4 and re.search(r"\d M\b", line):
+            indent = line[:len(line) - len(line.lstrip())]
+            line = indent + "| " + " | ".join(fn(m.group(1), cells)) + " |\n"
+        out.append(line)
+    open(os.path.join(ROOT, path), "w", encoding="utf-8").write("".join(out))
+
+
+def readme(key, cells):
+    cells[2] = re.sub(r"\d+(?:\.\d+)? M\b", mega(summary[key]), cells[2], count=1)
+    return cells
+
+
+def design(key, cells):
+    cells[1] = re.sub(r"\d+(?:\.\d+)? M\b", mega(summary[key]), cells[1], count=1)
+    leg = legs.get(key)
+    if leg:
+        kern = {"k_correlate_4k": "`k_correlate_4k`", "k_correlate": "`k_correlate`", "k_correlate_seg": "`k_correlate_seg`",
+                "k_carrier": "`k_carrier_pruned`"}.get(leg["kernel"], "`%s`" % leg["kernel"])
+        tail = re.search(r"(\s*\([^)]*\))?\s*\d+\.\d+ ms", cells[2])
+        extra = (tail.group(1) or "") if tail else ""
+        cells[2] = "%s%s %.3f ms, %.3f, %.3f" % (kern, extra, leg["avg_launch_ms"], leg["frac"], leg["traffic_over_algorithmic"])
+        cells[3] = "%.3f" % leg["pipeline_frac"]
+    return cells
+
+
+rewrite("README.md", readme)
+rewrite("DESIGN.md", design)
+print("tables rewritten from", rec.get("config", {}).get("workload", "")[:60])

@@ -163,3 +163,15 @@ def test_raw_stream_framing_and_large_batches():
     _close(sa[:, 0], sb[:, 0], (sb[:, 0]["flags"] & F.FLAG_CORR) != 0)
     a.close()
     b.close()
+    # a history that is not a multiple of 8: the blocks of the stream start on 4-byte boundaries (raw-stream
+    # framing wants an even block_len - history_len), the sections' 16-byte sample fetches are unaligned
+    h = 4098
+    a = F.Engine(N, h, tpl, THR, (7, 110), THR, max_batch=64)
+    b = F.Engine(N, h, tpl, THR, (7, 110), THR, max_batch=64, path="unsectioned")
+    assert a.sections() == (4, 4096)
+    n2 = (N - h) * 40 + h
+    sa, sb = a.detect_stream(stream[:2 * n2]), b.detect_stream(stream[:2 * n2])
+    assert len(sa) == 40 and ((sb[:, 0]["flags"] & F.FLAG_CORR) != 0).sum() >= 30
+    _close(sa[:, 0], sb[:, 0], (sb[:, 0]["flags"] & F.FLAG_CORR) != 0)
+    a.close()
+    b.close()
