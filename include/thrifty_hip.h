@@ -540,7 +540,8 @@ const char* thr_kernel_name(int slot);
  *   launches take (csrc/correlate16k_geom.hpp): *rows_lo / *rows_hi = rows of 1024 lags compiled out
  *   below / above the unique window, or -1, -1 for the generic kernel (a window outside the table,
  *   a stddev threshold term, another block length or variant).  Decided by the same function the
- *   launcher calls. */
+ *   launcher calls.  (A block_len 16384 handle whose plain launches run sectioned -- thr_debug_sections
+ *   -- reports the entry its stage-dump launches of k_correlate take.) */
 int thr_debug_correlate_geom(thr_handle* h, int* rows_lo, int* rows_hi);
 /* thr_debug_sections: the overlap-save sections this handle's plain correlate launches run in:
  *   *n_sections (0: unsectioned) of *section_len samples (16384 for long blocks, 4096 for block_len

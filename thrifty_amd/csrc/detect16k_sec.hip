@@ -304,15 +304,19 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(2))) void k_
     // one per section (131072 same-address atomics per 1.5 ms launch) the kernel ran at the pace of
     // the cursor, whatever else was taken out of it.  The cursor is read by thread 0 at the top of
     // the iteration that needs it and handed round through LDS across the pass-1 barrier, two items
-    // ahead of its use.
+    // ahead of its use.  (A launch with fewer items than two per workgroup hands out single sections
+    // instead -- tk = 1 -- so that a small batch still spreads over the chip.)
     const int G = int(gridDim.x);
-    auto last_of_ticket = [&](int wi) -> bool { return n_seg == 4 ? ((wi + 1) & 3) == 0 : (wi + 1) % n_seg == 0; };
+    const int tk = n_work <= 2 * G ? 1 : n_seg;   // items per ticket
+    auto last_of_ticket = [&](int wi) -> bool {
+        return tk == 1 ? true : tk == 4 ? ((wi + 1) & 3) == 0 : (wi + 1) % tk == 0;
+    };
     bool static_ticket = true;   // ticket g + G not handed out yet
-    int wi0 = int(blockIdx.x) * n_seg, wi_nxt;
+    int wi0 = int(blockIdx.x) * tk, wi_nxt;
     if (!last_of_ticket(wi0)) {
         wi_nxt = wi0 + 1;
     } else {
-        wi_nxt = (int(blockIdx.x) + G) * n_seg;
+        wi_nxt = (int(blockIdx.x) + G) * tk;
         static_ticket = false;
     }
     RawQ<FMT> cur;
@@ -339,7 +343,7 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(2))) void k_
         int wi_dyn = 0;
 #ifdef THR_Q_STATIC   // dev A/B: tickets g, g + G, g + 2 G, ... (no cursor)
         (void)dyn_ctr;
-        wi_dyn = (wi_nxt + 1) / n_seg - 1 - G;   // the ticket after T is T + G = 2 G + wi_dyn
+        wi_dyn = (wi_nxt + 1) / tk - 1 - G;   // the ticket after T is T + G = 2 G + wi_dyn
 #else
         if (t == 0 && need_ticket && !static_ticket) wi_dyn = atomicAdd(dyn_ctr, 1);
 #endif
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(2))) void k_
         THR_STAMP(2);
         if (t == 0)
             *sc_dyn = !need_ticket ? wi_nxt + 1
-                                   : (static_ticket ? int(blockIdx.x) + G : 2 * G + wi_dyn) * n_seg;
+                                   : (static_ticket ? int(blockIdx.x) + G : 2 * G + wi_dyn) * tk;
         if (need_ticket) static_ticket = false;
         THR_STAMP(3);
         __syncthreads();
