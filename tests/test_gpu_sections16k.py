@@ -175,3 +175,19 @@ def test_raw_stream_framing_and_large_batches():
     _close(sa[:, 0], sb[:, 0], (sb[:, 0]["flags"] & F.FLAG_CORR) != 0)
     a.close()
     b.close()
+
+
+def test_random_sectioned_geometries_equal_the_unsectioned_kernel_and_the_oracle():
+    """A seeded slice of tests/tools/fuzz_sections.py (400 configurations / 279 109 blocks on the round-5
+    build: profiles/r05_soak.log): random history / template length with one to four sections, template
+    kind, carrier window, thresholds, input format and batch sizes on both sides of the kernel's
+    ticket switch -- exact fields equal the unsectioned kernel's and the oracle's."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import fuzz_sections
+    rng = np.random.default_rng(20260930)
+    seen = set()
+    for k in range(14):
+        status, desc = fuzz_sections.one(rng, k, F, onp, synth, soak_util, 16)
+        assert status == "ok", (desc, status)
+        seen.add(desc.rsplit("sections=", 1)[1])
+    assert len(seen) >= 3, seen

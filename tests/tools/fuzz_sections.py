@@ -1,0 +1,170 @@
+"""Dev/aux: randomised fuzz of the SECTIONED correlate stage of block_len 16384 (csrc/detect16k_sec.hip,
+k_correlate_4k) -- the path BASELINE configs[1] runs.  Every configuration draws a history / template
+length whose unique window thr_plan_sections covers with one to four 4096-sample sections, a template
+kind (Gold code, random +-1, random float), a carrier window, thresholds without a stddev term, u8 or
+complex64 input and a batch size from both sides of the kernel's ticket switch (a launch with at most
+two items per workgroup hands out single sections, a larger one whole blocks); bursts sit on the
+window's edges, on both sides of every seam between sections and at random lags, a few blocks carry a
+carrier tone without the code.  Checked per configuration:
+
+  * the handle reports the planned sections (thr_debug_sections);
+  * its records equal the unsectioned kernel's (path="unsectioned": k_correlate) -- flags, carrier
+    fields and SAMPLE INDEX exactly, correlation energy / noise to 3e-6, sub-sample offset to 5e-6;
+  * the whole-rows peak search equals the generic one (path="generic_rows") byte for byte;
+  * the first blocks equal the oracle's records (soak_util.compare: bin, verdicts, sample exact;
+    with a template of at least N / 24 samples -- a well-conditioned carrier fit -- offset 2e-5,
+    energy / noise 2e-5; BASELINE's tolerance for both is 1e-4).
+
+Usage: fuzz_sections.py [n_configs] [seed] [oracle_blocks_per_config]"""
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))                      # tests/ (soak_util)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))     # the repo root
+import numpy as np  # noqa: E402
+
+N = 16384
+SEC = 4096
+
+
+def draw_geometry(rng):
+    """(history, template length) whose plan has 1..4 sections: a section yields SEC - w + 1 exact
+    lags, the unique window is N - h lags wide."""
+    while True:
+        w = int(rng.choice([rng.integers(64, 400), rng.integers(400, 1100), 1023, 511, 1024, 1025]))
+        per = SEC - w + 1
+        nsec = int(rng.integers(1, 5))
+        # window width in ((nsec - 1) per, nsec per], history >= w - 1
+        width = int(rng.integers((nsec - 1) * per + 1, nsec * per + 1))
+        h = N - width
+        if h >= w - 1 and h < N - 2:
+            return h, w
+
+
+def one(rng, k, F, onp, synth, soak_util, n_oracle):
+    h, w = draw_geometry(rng)
+    kind = int(rng.integers(0, 3))
+    if kind == 0 and w in (63, 127, 255, 511, 1023):
+        tpl = synth.gold_template(int(np.log2(w + 1)), int(rng.integers(0, 5)))
+    elif kind == 1:
+        tpl = rng.normal(0, 1, w)
+        tpl /= np.max(np.abs(tpl))
+    else:
+        tpl = np.sign(rng.normal(0, 1, w))
+    cwin = [(7, 110), (7, 110), (0, -1), (-60, 60), (30, 300), (-200, -20)][int(rng.integers(0, 6))]
+    cthr = (float(rng.choice([0, 30.0])), float(rng.choice([8, 15])), 0.0)
+    xthr = (float(rng.choice([0, 10.0])), float(rng.choice([8, 15])), 0.0)
+    nb = int(rng.choice([7, 40, 300, 900, 2500]))
+    max_batch = int(rng.choice([64, 700, 4096]))
+    lo, hi = onp.unique_window(N, h, w)
+    desc = "h=%d w=%d kind=%d cwin=%s cthr=%s xthr=%s nb=%d max_batch=%d" % (h, w, kind, cwin, cthr, xthr, nb, max_batch)
+    secs = F.plan_sections(N, h, w)
+    if not 1 <= len(secs) <= 4:     # (section starts are aligned down: a plan may need one more than the lag count says)
+        e = F.Engine(N, h, tpl, cthr, cwin, xthr, max_batch=8)
+        got = e.sections()
+        e.close()
+        return ("ok" if got == (0, 0) else "SECTIONS %s for a plan of %d" % (got, len(secs))), desc + " sections=0"
+    edge = [lo, lo + 1, hi - 1, hi - 2]
+    for s in secs[1:]:
+        edge += [s["win_lo"] - 1, s["win_lo"]]
+    edge = [p for p in edge if lo <= p < hi]
+    pos = np.array((edge + list(rng.integers(lo, hi, max(0, nb - len(edge)))))[:nb])
+    if cwin == (0, -1):
+        cb = (-N / 4, N / 4)
+    else:
+        cb = (min(cwin) + 0.3, max(cwin) - 0.3)
+    blocks, truth = synth.synth_blocks(rng, nb, N, tpl, (lo, hi), signal_frac=1.0, positions=pos, carrier_bins=cb)
+    tone_bin = rng.uniform(cb[0], cb[1])
+    tone = np.exp(2j * np.pi * tone_bin * np.arange(N) / N) * 0.05
+    for i in range(len(edge) + 3, nb, 9):       # a carrier without the code reaches the correlate stage too
+        z = rng.normal(0, 0.02, N) + 1j * rng.normal(0, 0.02, N) + tone
+        blocks[i] = synth.quantise_iq(z)
+    c64 = rng.random() < 0.25 and nb <= 300
+    inp = ((blocks.astype(np.float32) - 127.4) / 128).view(np.complex64) if c64 else blocks
+    desc += " c64" if c64 else " u8"
+    idx = np.arange(nb) + int(rng.integers(0, 1000))
+    bad = []
+    eng = F.Engine(N, h, tpl, cthr, cwin, xthr, max_batch=max_batch)
+    uns = F.Engine(N, h, tpl, cthr, cwin, xthr, max_batch=max_batch, path="unsectioned")
+    gen = F.Engine(N, h, tpl, cthr, cwin, xthr, max_batch=max_batch, path="generic_rows")
+    try:
+        if eng.sections() != (len(secs), SEC):
+            return "SECTIONS %s, planned %d" % (eng.sections(), len(secs)), desc
+        rec = eng.detect(inp, idx)[:, 0]
+        ref = uns.detect(inp, idx)[:, 0]
+        if gen.detect(inp, idx)[:, 0].tobytes() != rec.tobytes():
+            bad.append("generic_rows records differ")
+        for f in ("flags", "block_idx", "template_id", "carrier_bin", "corr_sample"):
+            if not np.array_equal(rec[f], ref[f]):
+                j = int(np.nonzero(rec[f] != ref[f])[0][0])
+                bad.append("%s differs from unsectioned at block %d: %s vs %s (lag window [%d, %d))" % (
+                    f, j, rec[f][j], ref[f][j], lo, hi))
+        for f in ("carrier_offset", "carrier_energy", "carrier_noise"):
+            if not np.array_equal(rec[f], ref[f], equal_nan=True):
+                bad.append("%s differs from unsectioned" % f)
+        m = (ref["flags"] & F.FLAG_CARRIER) != 0
+        det = (ref["flags"] & F.FLAG_CORR) != 0
+        if not bad:
+            for f, tol in (("corr_energy", 3e-6), ("corr_noise", 3e-6)):
+                d = np.abs(rec[f][m] - ref[f][m]) / np.maximum(np.abs(ref[f][m]), 1e-30)
+                if d.size and d.max() > tol:
+                    bad.append("%s vs unsectioned: %.3g" % (f, d.max()))
+            d = np.abs(rec["corr_offset"][det] - ref["corr_offset"][det])
+            if d.size and d.max() > 5e-6:
+                bad.append("corr_offset vs unsectioned: %.3g" % d.max())
+        # the oracle on the first blocks (the edge and seam bursts come first)
+        no = min(nb, n_oracle)
+        rows = soak_util.run_oracle(blocks[:no], N, h, tpl, cthr, cwin, xthr, procs=min(16, max(1, no // 4)), chunk=8)
+        rows = [None if r is None else r for r in rows]
+        # soak_util numbers blocks from 0: the records carry idx, compare() does not read it
+        dc = cwin == (0, -1) or (min(cwin) <= 0 <= max(cwin))
+        mism, worst, ties = soak_util.compare(rec[:no], rows, blocks[:no], F.FLAG_CARRIER, F.FLAG_CORR,
+                                              only=truth["has_signal"][:no] if dc else None)
+        if any(mism.values()):
+            bad.append("oracle mismatches %s" % mism)
+        # (a template shorter than N / 24 puts the fit's seven points on a flat main lobe: the
+        # reference's own carrier offset moves under a one-ulp change of its inputs -- lmdif8.hpp,
+        # fuzz_parity.py's FUZZ_MIN_RATIO -- and the correlation's floats move with it; the carrier
+        # stage is the unsectioned path's, compared exactly above: exact fields only against the oracle)
+        if w >= N // 24 and (worst["offset"] > 2e-5 or worst["energy"] > 2e-5 or worst["noise"] > 2e-5):
+            bad.append("oracle worst %s" % worst)
+        if ties:
+            bad.append("carrier ties %s" % ties)
+    finally:
+        for e in (eng, uns, gen):
+            e.close()
+    return ("; ".join(bad) if bad else "ok"), desc + " sections=%d" % len(secs)
+
+
+def main():
+    count = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    n_oracle = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+    import soak_util
+    from oracle import thrifty_np as onp
+    from thrifty_amd import _native as F, synth
+    rng = np.random.default_rng(seed)
+    tally, by_sections, blocks = {}, {}, 0
+    t0 = time.time()
+    for k in range(count):
+        try:
+            status, desc = one(rng, k, F, onp, synth, soak_util, n_oracle)
+        except Exception as e:   # noqa
+            status, desc = "EXCEPTION %r" % (e,), "config %d" % k
+        key = "ok" if status == "ok" else "FAIL"
+        tally[key] = tally.get(key, 0) + 1
+        if key == "ok":
+            s = desc.rsplit("sections=", 1)[1]
+            by_sections[s] = by_sections.get(s, 0) + 1
+            blocks += int(desc.split("nb=")[1].split()[0])
+        else:
+            print("[%d] %s\n      %s" % (k, desc, status))
+    print("fuzz_sections: %s, by section count %s, %d blocks against the unsectioned kernel, in %.0f s"
+          % (tally, dict(sorted(by_sections.items())), blocks, time.time() - t0))
+    return 0 if set(tally) <= {"ok"} else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
