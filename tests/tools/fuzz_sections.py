@@ -116,8 +116,16 @@ def one(rng, k, F, onp, synth, soak_util, n_oracle):
                 bad.append("corr_offset vs unsectioned: %.3g" % d.max())
         # the oracle on the first blocks (the edge and seam bursts come first)
         no = min(nb, n_oracle)
-        rows = soak_util.run_oracle(blocks[:no], N, h, tpl, cthr, cwin, xthr, procs=min(16, max(1, no // 4)), chunk=8)
-        rows = [None if r is None else r for r in rows]
+        try:
+            rows = soak_util.run_oracle(blocks[:no], N, h, tpl, cthr, cwin, xthr, procs=min(16, max(1, no // 4)), chunk=8)
+        except RuntimeError as exc:
+            # SciPy's curve_fit gave up on a block ("Optimal parameters not found": lmdif info 5 .. 8 on the
+            # flat main lobe of a short template) -- the reference's detect loop dies there with this
+            # exception (carrier_sync.py:189, uncaught); the engine keeps lmdif's last iterate (DESIGN.md
+            # section 4).  Nothing to compare the floats with: the GPU-side checks above stand.
+            if "Optimal parameters not found" not in str(exc):
+                raise
+            return ("; ".join(bad) if bad else "ok"), desc + " reference-raises sections=%d" % len(secs)
         # soak_util numbers blocks from 0: the records carry idx, compare() does not read it
         dc = cwin == (0, -1) or (min(cwin) <= 0 <= max(cwin))
         mism, worst, ties = soak_util.compare(rec[:no], rows, blocks[:no], F.FLAG_CARRIER, F.FLAG_CORR,
@@ -146,7 +154,7 @@ def main():
     from oracle import thrifty_np as onp
     from thrifty_amd import _native as F, synth
     rng = np.random.default_rng(seed)
-    tally, by_sections, blocks = {}, {}, 0
+    tally, by_sections, blocks, ref_raises = {}, {}, 0, 0
     t0 = time.time()
     for k in range(count):
         try:
@@ -159,10 +167,13 @@ def main():
             s = desc.rsplit("sections=", 1)[1]
             by_sections[s] = by_sections.get(s, 0) + 1
             blocks += int(desc.split("nb=")[1].split()[0])
+            ref_raises += " reference-raises " in desc
         else:
             print("[%d] %s\n      %s" % (k, desc, status))
-    print("fuzz_sections: %s, by section count %s, %d blocks against the unsectioned kernel, in %.0f s"
-          % (tally, dict(sorted(by_sections.items())), blocks, time.time() - t0))
+    print("fuzz_sections: %s, by section count %s, %d blocks against the unsectioned kernel%s, in %.0f s"
+          % (tally, dict(sorted(by_sections.items())), blocks,
+             ", %d configurations on which the reference's curve_fit raises" % ref_raises if ref_raises else "",
+             time.time() - t0))
     return 0 if set(tally) <= {"ok"} else 1
 
 
