@@ -221,7 +221,7 @@ def _compute_view(kernel, n, n_templates, blocks_per_launch, avg_ms, n_sec=0):
     point = 6.0 * n
     if kernel == "k_correlate_4k":   # per block n_sec sections of 4096 points: shift, FFT, product, IFFT, |.|^2
         m = 4096.0
-        flop = n_sec * (6.0 * m + 5.0 * m * 12 + 6.0 * m + 5.0 * m * 12 + 3.0 * m)
+        flop = n_sec * (6.0 * m + 5.0 * m * 12 + n_templates * (6.0 * m + 5.0 * m * 12 + 3.0 * m))
     elif kernel in ("k_correlate", "k_correlate_sub", "k_correlate_seg"):  # shift, FFT#2, then per template: product, IFFT, |.|^2
         flop = point + fft + n_templates * (point + fft + 3.0 * n)
     elif kernel == "k_preshift":     # FFT#1, |X|^2, product, IFFT, |.|^2
@@ -481,7 +481,7 @@ class Leg(object):
         self.sectioned = self.n > 16384 and not pnum and bool(F.plan_sections(self.n, self.h, self.wlen))
         self.engs = [F.Engine(self.n, self.h, self.tpls, self.thresh[0], self.cwin, self.thresh[1], device_id=local,
                               max_batch=self.B, preshift_num=pnum) for _ in range(n_handles)]
-        # block_len 16384, ONE short template: the correlate slot times k_correlate_4k over the (block,
+        # block_len 16384, short template(s): the correlate slot times k_correlate_4k over the (block,
         # 4096-sample section) items (csrc/detect16k_sec.hip); the engine says whether it does
         self.sec4k = self.engs[0].sections()[1] == 4096
         self.n_sec = self.engs[0].sections()[0]

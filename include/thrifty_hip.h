@@ -45,7 +45,12 @@ extern "C" {
  *    (csrc/detect16k_sec.hip); thr_plan_sections answers for block_len 16384 too,
  *    THR_PATH_UNSECTIONED applies to it, + THR_PATH_UNSECTIONED_GENERIC_ROWS, thr_debug_sections
  *    (additions; records of such handles change in the last bits of their float fields only) */
-#define THR_ABI_VERSION 8
+/* 9: block_len 16384: SEVERAL short templates run the sectioned correlate stage too (one forward
+ *    transform per section, one product + inverse per template); + THR_FLAG_FIT_UNCONVERGED (the
+ *    carrier fit's MINPACK exit code), thr_get_path_info (which kernels a handle's launches take, and
+ *    why); thr_detect_offsets refuses non-finite offsets (additions; records of several-template
+ *    handles change in the last bits of their float fields only) */
+#define THR_ABI_VERSION 9
 
 /* status codes */
 #define THR_OK 0
@@ -61,6 +66,17 @@ extern "C" {
 #define THR_FLAG_INDEX_ERROR 4u  /* reference raises IndexError here: carrier bin
                                     + 3 >= block_len (carrier_sync.py:187)         */
 
+#define THR_FLAG_FIT_UNCONVERGED 16u /* the Dirichlet carrier fit ended with MINPACK lmdif exit code 5 .. 8
+                                    (600 evaluations, or a tolerance below machine precision): SciPy's
+                                    curve_fit raises RuntimeError("Optimal parameters not found: ...")
+                                    there and the reference does not catch it (carrier_sync.py:189), so
+                                    its detect loop dies on that block.  The record is complete -- shift,
+                                    FFT#2 and correlation ran with lmdif's last iterate -- and says so;
+                                    Detector(strict_fit=True) raises like the reference.  Degenerate
+                                    geometries only (templates far shorter than block_len / 24: the seven
+                                    fitted points sit on a flat main lobe), and there the exit code hangs
+                                    on the last digit of the seven magnitudes: the flagged blocks are the
+                                    reference's to within that noise, not block for block. */
 #define THR_FLAG_INT_OFFSET 8u   /* PreshiftDetector, cosine interpolator: the reference returned the
                                     Python int 0 (cos(omega) > 1, carrier_interpolators.py:87-88), so
                                     carrier_offset is 0 and prints as "0", not "0.0"                  */
@@ -543,6 +559,36 @@ const char* thr_kernel_name(int slot);
  *   launcher calls.  (A block_len 16384 handle whose plain launches run sectioned -- thr_debug_sections
  *   -- reports the entry its stage-dump launches of k_correlate take.) */
 int thr_debug_correlate_geom(thr_handle* h, int* rows_lo, int* rows_hi);
+/*
+ * thr_get_path_info: which kernels this handle's plain launches take, and why (no device work).
+ * A settings change that looks harmless can cost a sixth of the throughput -- a stddev term in
+ * corr_thresh, a history of 1100 instead of 4096 samples -- so the choice is reportable:
+ * `Detector.engine_path` and one logging.info line at construction come from here.
+ *   n_sections / section_len   the correlate stage's overlap-save sections (0, 0: unsectioned)
+ *   rows_lo / rows_hi          window-row specialisation of k_correlate / k_correlate_seg (-1: generic)
+ *   why_unsectioned            THR_WHY_*: 0 when sectioned, otherwise the FIRST reason that applies
+ *   carrier_kernel, correlate_kernel   kernel family names (as in profiles/ and bench.py)
+ *   text                       the same as one sentence
+ */
+#define THR_WHY_SECTIONED 0   /* the correlate stage runs in sections                                  */
+#define THR_WHY_PATH 1        /* the handle was created with an unsectioned / multi-pass kernel path   */
+#define THR_WHY_VARIANT 2     /* preshift / fastdet variant: ONE fused kernel per block                */
+#define THR_WHY_STDDEV 3      /* corr_thresh has a stddev term: its sums run over every kept lag       */
+#define THR_WHY_GEOMETRY 4    /* template / history: the unique window needs more sections than pay
+                                 (block_len 16384: more than four of 4096 samples) or than fit         */
+#define THR_WHY_BLOCK_LEN 5   /* this block length has no sectioned form (whole blocks sit in LDS, or
+                                 the generic multi-pass pipeline)                                      */
+typedef struct thr_path_info {
+    int32_t n_sections, section_len;
+    int32_t rows_lo, rows_hi;
+    int32_t why_unsectioned;
+    int32_t n_templates;
+    char carrier_kernel[48];
+    char correlate_kernel[48];
+    char text[256];
+} thr_path_info;
+int thr_get_path_info(thr_handle* h, thr_path_info* out);
+
 /* thr_debug_sections: the overlap-save sections this handle's plain correlate launches run in:
  *   *n_sections (0: unsectioned) of *section_len samples (16384 for long blocks, 4096 for block_len
  *   16384). */

@@ -1,7 +1,8 @@
 """Dev/aux: block_len 16384 with a short template -- the sectioned correlate stage (detect16k_sec.hip,
 4096-sample sections, the default) against the unsectioned kernel (path="unsectioned") on the same
 device-resident blocks: records compared field by field, per-kernel times from the engines' own HIP
-events.    python scripts/sec4k_probe.py [n_blocks] [history] [template_len]"""
+events.    python scripts/sec4k_probe.py [n_blocks] [history] [template_len] [n_templates]
+(n_templates > 1: Gold codes 2, 3, ... as bench.py's t4 leg; blocks carry template 0's burst)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -10,6 +11,7 @@ from thrifty_amd import _native as F, synth
 NB = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 W = int(sys.argv[3]) if len(sys.argv) > 3 else 1023
+NTPL = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 N = 16384
 
 def main():
@@ -18,14 +20,15 @@ def main():
     pad = H - W + 1
     win = (pad // 2, (N - W + 1) - (pad - pad // 2))
     seed, _ = synth.synth_blocks(rng, 256, N, tpl, win, carrier_bins=(10.0, 100.0))
+    tpls = tpl if NTPL == 1 else np.stack([synth.gold_template(10, 2 + i) for i in range(NTPL)]).astype(np.float64)
     dev = torch.device("cuda:0")
     data = torch.from_numpy(np.tile(seed, (NB // 256, 1))).to(dev)
     thr = (0, 15, 0)
     recs, rates = {}, {}
     paths = ("auto", "auto") if os.environ.get("SEC_ONLY") else ("unsectioned", "auto", "unsectioned", "auto")
     for path in paths:
-        out = torch.zeros(NB * 64, dtype=torch.uint8, device=dev)
-        eng = F.Engine(N, H, tpl, thr, (7, 110), thr, max_batch=NB, path=path)
+        out = torch.zeros(NB * 64 * NTPL, dtype=torch.uint8, device=dev)
+        eng = F.Engine(N, H, tpls, thr, (7, 110), thr, max_batch=NB, path=path)
         eng.detect_device(data.data_ptr(), F.THR_IN_U8, NB, out.data_ptr()); eng.sync()
         eng.profile_enable(1); eng.profile_read()
         reps = 12

@@ -1,7 +1,9 @@
 """A replaced carrier interpolator on the GPU engine: `Detector.sync.interpolator = fn`, what the
 reference's InterpolationDetector does (thrifty/experimental/detect_carrier_interpol.py:17-40 with
 the functions of carrier_interpolators.py:17-81).  The callable runs on the host between two engine
-passes (thr_detect_offsets).  Fixtures `interpol_c2_*` come from running the reference class."""
+passes (thr_detect_offsets).  Fixtures `interpol_c2_*` come from running the reference class; the
+callables assigned here are the ORACLE's restatements (oracle/thrifty_np.py) -- the product ships the
+hook, not the reference's interpolators."""
 import io
 
 import numpy as np
@@ -10,16 +12,21 @@ import pytest
 from thrifty_amd import _native as F
 from thrifty_amd import block_data
 from thrifty_amd.detect import Detector
-from thrifty_amd.experimental import carrier_interpolators
-from thrifty_amd.experimental.detect_carrier_interpol import InterpolationDetector
+from oracle import thrifty_np as onp
 
 from test_gpu_detector_api import card_text, settings_of
 
 pytestmark = pytest.mark.gpu
 
-METHODS = {"none": "none", "parabolic": "parabolic", "gaussian": "gaussian", "cosine": "cosine",
-           "parabole_fit6": lambda st: carrier_interpolators.make_parabole_fit(6),
-           "corr_parabolic4": lambda st: carrier_interpolators.make_corr_parabolic(4, st.block_len, st.carrier_len)}
+METHODS = {"none": lambda st: onp.no_offset, "parabolic": lambda st: onp.parabolic_offset,
+           "gaussian": lambda st: onp.gaussian_offset, "cosine": lambda st: onp.cosine_offset,
+           "parabole_fit6": lambda st: onp.parabole_fit_offset(6),
+           "corr_parabolic4": lambda st: onp.corr_parabolic_offset(4, st.block_len, st.carrier_len)}
+
+
+def host_dirichlet(st):
+    """The engine's own fit restated on the host (carrier_sync.py:150-196: curve_fit on seven magnitudes)."""
+    return lambda mag, peak: onp.dirichlet_fit(mag, peak, st.block_len, st.carrier_len)[1]
 
 
 @pytest.mark.parametrize("name", sorted(METHODS))
@@ -27,9 +34,9 @@ def test_interpolation_detector_matches_the_references(golden, name):
     g = golden("interpol_c2_" + name)
     src = golden(str(g["src"]))
     st = settings_of(src)
-    method = METHODS[name] if isinstance(METHODS[name], str) else METHODS[name](st)
     items = [(1000.0 + i, int(src["block_idx"][i]), src["blocks"][i]) for i in range(len(src["blocks"]))]
-    det = InterpolationDetector(st, iter(items), rxid=int(src["rxid"]), method=method, batch_size=7)
+    det = Detector(st, iter(items), rxid=int(src["rxid"]), batch_size=7)
+    det.sync.interpolator = METHODS[name](st)
     assert det._host_interp
     got = list(det)
     assert len(got) == len(items)
@@ -63,17 +70,16 @@ def test_interpolation_detector_matches_the_references(golden, name):
 
 
 def test_the_engines_own_fit_restated_on_the_host_gives_the_engines_records(golden):
-    """make_dirichlet (SciPy curve_fit on seven magnitudes) assigned as the interpolator is the
-    default detector computed the slow way: same bins, samples and verdicts, offsets to the
-    tolerance of the device fit; and the named default takes the fast path."""
+    """SciPy's curve_fit on seven magnitudes assigned as the interpolator is the default detector
+    computed the slow way: same bins, samples and verdicts, offsets to the tolerance of the device fit."""
     g = golden("c2")
     st = settings_of(g)
     items = [(1000.0 + i, int(g["block_idx"][i]), g["blocks"][i]) for i in range(len(g["blocks"]))]
-    fast = InterpolationDetector(st, iter(items), rxid=0, method="dirichlet")
+    fast = Detector(st, iter(items), rxid=0)
     assert not fast._host_interp
     want = list(fast)
     slow = Detector(st, iter(items), rxid=0, batch_size=5)
-    slow.sync.interpolator = carrier_interpolators.make_dirichlet(st.block_len, st.carrier_len)
+    slow.sync.interpolator = host_dirichlet(st)
     assert slow._host_interp and slow.sync.interpolator is not None
     got = list(slow)
     assert len(got) == len(want)
@@ -107,7 +113,7 @@ def test_an_exception_of_the_callable_belongs_to_its_block_and_file_readers_stil
         assert fft_mag.dtype == np.float32 and fft_mag.shape == (16384,)
         if len(calls) == 6:
             raise IndexError("index 16385 is out of bounds for axis 0 with size 16384")
-        return carrier_interpolators.parabolic(fft_mag, peak)
+        return onp.parabolic_offset(fft_mag, peak)
 
     with open(path, "rb") as f:
         det = Detector(st, block_data.CardStream(f, 16384), rxid=0, batch_size=4)    # a mapped file, device ingest ...
@@ -125,7 +131,7 @@ def test_an_exception_of_the_callable_belongs_to_its_block_and_file_readers_stil
     assert [res.block for _, res in out] == [int(b) for b in g["block_idx"][:len(out)]]
     # record iteration and the library loop are not offered in this mode
     det2 = Detector(st, io.BytesIO(b""), rxid=0)
-    det2.sync.interpolator = carrier_interpolators.none
+    det2.sync.interpolator = onp.no_offset
     with pytest.raises(TypeError, match="replaced interpolator"):
         next(det2.iter_detected_records())
     with pytest.raises(NotImplementedError):
@@ -133,7 +139,7 @@ def test_an_exception_of_the_callable_belongs_to_its_block_and_file_readers_stil
     # the variants interpolate inside their fused kernels
     from thrifty_amd.experimental.detect_preshift import PreshiftDetector
     with pytest.raises(NotImplementedError):
-        PreshiftDetector(st, None).sync.interpolator = carrier_interpolators.none
+        PreshiftDetector(st, None).sync.interpolator = onp.no_offset
     with pytest.raises(TypeError):
         Detector(st, None).sync.interpolator = 3
 
@@ -164,35 +170,27 @@ def test_detect_offsets_entry_point(golden):
         assert a[keep].tobytes() == r[keep].tobytes(), name
 
 
-@pytest.mark.parametrize("method,quiet", [("parabolic", True), ("cosine", False), ("dirichlet", True)])
-def test_the_references_command_line(golden, tmp_path, monkeypatch, capsys, method, quiet):
-    """`python -m thrifty_amd.experimental.detect_carrier_interpol --method M rx.card -o rx.toad`
-    (reference detect_carrier_interpol.py:43-59): a replaced interpolator takes the per-block loop
-    even under --quiet; the default `dirichlet` is the engine's own fit and takes the library loop."""
-    from thrifty_amd.experimental import detect_carrier_interpol as mod
-    from test_gpu_detector_api import assert_toad_close
-    src = golden("c2")
-    np.save(tmp_path / "template.npy", src["template"])
-    (tmp_path / "detector.cfg").write_text(
-        "rxid: 0\nsample_rate: 2.4M\nblock_size: 16384\nblock_history: 4096\n"
-        "carrier_window: 7 - 110\ncarrier_threshold: 15 * snr\ncorr_threshold: 15*snr\n"
-        "template: %s\n" % (tmp_path / "template.npy"))
-    (tmp_path / "rx.card").write_text(card_text(src))
-    argv = ["detect_carrier_interpol", str(tmp_path / "rx.card"), "-o", str(tmp_path / "rx.toad"),
-            "-c", str(tmp_path / "detector.cfg"), "--method", method] + (["--quiet"] if quiet else [])
-    monkeypatch.setattr("sys.argv", argv)
-    mod._main()
-    lines = (tmp_path / "rx.toad").read_text().strip().split("\n")
-    want = str(src["toad"] if method == "dirichlet" else golden("interpol_c2_" + method)["toad"])
-    if method == "dirichlet":
-        assert_toad_close(lines, want)
-    else:
-        ref = want.split("\n")
-        assert len(lines) == len(ref)
-        for a, b in zip(lines, ref):
-            fa, fb = a.split(), b.split()
-            assert fa[:3] == fb[:3] and fa[4] == fb[4] and fa[8] == fb[8]
-            np.testing.assert_allclose(float(fa[9]), float(fb[9]), atol=5e-5)
-            np.testing.assert_allclose([float(v) for v in fa[5:8]], [float(v) for v in fb[5:8]], rtol=1e-4, atol=1e-4)
-    out = capsys.readouterr().out
-    assert (out.strip() == "") == quiet                 # the per-block summary lines unless --quiet
+def test_a_non_finite_offset_of_the_callable_is_the_blocks_error(golden):
+    """A callable that returns nan / inf (gaussian on a zero magnitude: log(0)): the reference's
+    shifter raises on that block (int(round(nan)), carrier_sync.py:241-245); here the blocks before
+    it come out, then ValueError -- and thr_detect_offsets itself refuses such an array."""
+    g = golden("c2")
+    st = settings_of(g)
+    items = [(1000.0 + i, int(g["block_idx"][i]), g["blocks"][i]) for i in range(len(g["blocks"]))]
+    calls = []
+
+    def broken(fft_mag, peak):
+        calls.append(peak)
+        return float("nan") if len(calls) == 4 else 0.25
+
+    det = Detector(st, iter(items), rxid=0, batch_size=6)
+    det.sync.interpolator = broken
+    out = []
+    with pytest.raises(ValueError, match="not finite"):
+        for item in det:
+            out.append(item)
+    carriers = np.flatnonzero(g["carrier_det"])
+    assert len(out) == carriers[3]
+    eng = F.Engine(16384, 4096, g["template"], (0, 15, 0), (7, 110), (0, 15, 0), max_batch=8)
+    with pytest.raises(F.NativeError, match="not finite"):
+        eng.detect_offsets(g["blocks"][:3], np.array([0.0, np.inf, 0.0]))

@@ -99,25 +99,118 @@ def test_sectioned_records_equal_the_oracle_and_the_unsectioned_kernel(h, w, nse
 
 
 def test_what_keeps_the_unsectioned_kernel():
+    """...and that the handle SAYS so (thr_get_path_info -> Engine.path_info(), Detector.engine_path):
+    a stddev term or an odd history costs a sixth of the throughput without any other sign."""
     tpl = synth.gold_template(10, 2)
     tpl4 = np.stack([synth.gold_template(10, g) for g in (2, 3, 4, 5)])
-    for kw, want in [(dict(), (4, 4096)),
-                     (dict(path="unsectioned"), (0, 0)),
-                     (dict(path="unsectioned_generic_rows"), (0, 0)),
-                     (dict(path="multipass"), (0, 0))]:
+    for kw, want, why in [(dict(), (4, 4096), "sectioned"),
+                          (dict(path="unsectioned"), (0, 0), "path"),
+                          (dict(path="unsectioned_generic_rows"), (0, 0), "path"),
+                          (dict(path="multipass"), (0, 0), "path")]:
         e = F.Engine(N, 4096, tpl, THR, (7, 110), THR, max_batch=8, **kw)
         assert e.sections() == want, kw
+        info = e.path_info()
+        assert info["why_unsectioned"] == why and (info["n_sections"], info["section_len"]) == want, info
         e.close()
-    for args in [(N, 4096, tpl4, THR, (7, 110), THR),                      # several templates
-                 (N, 4096, tpl, THR, (7, 110), (0, 15, 0.5)),              # a stddev term over every kept lag
-                 (N, 4920, np.sign(np.random.default_rng(1).normal(0, 1, 4914)), THR, (7, 110), THR),   # a long template
-                 (N, 1100, tpl, THR, (7, 110), THR)]:                      # a window of five sections
+    # several templates run sectioned too (ABI 9)
+    e = F.Engine(N, 4096, tpl4, THR, (7, 110), THR, max_batch=8)
+    info = e.path_info()
+    assert e.sections() == (4, 4096) and info["n_templates"] == 4 and info["correlate_kernel"] == "k_correlate_4k"
+    assert info["carrier_kernel"] == "k_carrier_pruned" and "4 sections of 4096" in info["text"]
+    e.close()
+    long_tpl = np.sign(np.random.default_rng(1).normal(0, 1, 4914))
+    for args, why, rows in [((N, 4096, tpl, THR, (7, 110), (0, 15, 0.5)), "stddev", (-1, -1)),   # sums over every kept lag
+                            ((N, 4920, long_tpl, THR, (7, 110), THR), "geometry", (0, 4)),        # a template longer than a section
+                            ((N, 1100, tpl, THR, (7, 110), THR), "geometry", (0, 1)),             # a window of five sections
+                            ((8192, 2048, tpl, THR, (7, 110), THR), "block_len", (-1, -1)),       # whole blocks sit in LDS
+                            ((65536, 4096, long_tpl[:4094], THR, (7, 110), THR), "sectioned", (0, 3))]:
         e = F.Engine(*args, max_batch=8)
-        assert e.sections() == (0, 0)
+        info = e.path_info()
+        assert info["why_unsectioned"] == why, (args[:2], info)
+        assert info["rows"] == rows, (args[:2], info)
+        if why != "sectioned":
+            assert e.sections() == (0, 0) and "unsectioned: " in info["text"]
+        else:
+            assert e.sections() == (5, 16384) and info["correlate_kernel"] == "k_correlate_seg"
         e.close()
     e = F.Engine(N, 4096, tpl, THR, (7, 110), THR, max_batch=8, preshift_num=64)
-    assert e.sections() == (0, 0)
+    assert e.sections() == (0, 0) and e.path_info()["why_unsectioned"] == "variant"
+    assert e.path_info()["correlate_kernel"] == "k_preshift"
     e.close()
+    # the drop-in class carries it and logs it once
+    import logging
+    from thrifty_amd.detect import Detector, DetectorSettings
+    records = []
+    handler = logging.Handler()
+    handler.emit = records.append
+    log = logging.getLogger("thrifty_amd.detect")
+    log.addHandler(handler)
+    old = log.level
+    log.setLevel(logging.INFO)
+    try:
+        det = Detector(DetectorSettings(N, 4096, 1023, THR, (7, 110), tpl, (0, 15, 0.5)), None)
+    finally:
+        log.removeHandler(handler)
+        log.setLevel(old)
+    assert det.engine_path["why_unsectioned"] == "stddev"
+    assert len(records) == 1 and "stddev term" in records[0].getMessage()
+    det.close()
+
+
+@pytest.mark.parametrize("n_tpl", [2, 4])
+def test_several_templates_sectioned_against_unsectioned_and_oracle(n_tpl):
+    """BASELINE configs[4]: one forward transform per section, one product + inverse per template
+    (k_correlate_4k<MULTI>).  Every template's burst in turn, peaks on the seams and the window edges."""
+    rng = np.random.default_rng(60 + n_tpl)
+    tpls = np.stack([synth.gold_template(10, 2 + i) for i in range(n_tpl)]).astype(np.float64)
+    h = 4096
+    lo, hi = onp.unique_window(N, h, 1023)
+    plan = F.plan_sections(N, h, 1023)
+    seams = [s["win_lo"] for s in plan[1:]]
+    pos = [lo, hi - 1] + [p for s in seams for p in (s - 1, s)] + list(rng.integers(lo, hi, 40))
+    nb = len(pos)
+    blocks = np.empty((nb, 2 * N), dtype=np.uint8)
+    for i, p in enumerate(pos):       # block i carries template i % n_tpl
+        b, _ = synth.synth_blocks(rng, 1, N, tpls[i % n_tpl], (lo, hi), positions=np.array([p]), carrier_bins=(12.0, 100.0))
+        blocks[i] = b[0]
+    eng = F.Engine(N, h, tpls, THR, (7, 110), THR, max_batch=64)
+    uns = F.Engine(N, h, tpls, THR, (7, 110), THR, max_batch=64, path="unsectioned")
+    gen = F.Engine(N, h, tpls, THR, (7, 110), THR, max_batch=64, path="generic_rows")
+    assert eng.sections() == (4, 4096) and uns.sections() == (0, 0)
+    rec = eng.detect(blocks, np.arange(nb))
+    ref = uns.detect(blocks, np.arange(nb))
+    assert rec.shape == (nb, n_tpl)
+    assert gen.detect(blocks, np.arange(nb)).tobytes() == rec.tobytes()
+    for t in range(n_tpl):
+        det = (ref[:, t]["flags"] & F.FLAG_CORR) != 0
+        _close(rec[:, t], ref[:, t], det)
+        assert np.array_equal(rec[:, t]["template_id"], np.full(nb, t))
+        # the template a block carries is detected at the position it was put
+        mine = np.arange(nb) % n_tpl == t
+        assert np.all(det[mine]) and np.array_equal(rec[:, t]["corr_sample"][mine], np.array(pos)[mine])
+    orc = onp.OracleDetector(N, h, tpls, THR, (7, 110), THR)
+    for i in range(nb):
+        want = orc.detect_u8(i, blocks[i])
+        for t in range(n_tpl):
+            r, w = rec[i, t], want[t]
+            assert bool(r["flags"] & F.FLAG_CORR) == w.detected and r["carrier_bin"] == w.carrier.bin
+            assert r["corr_sample"] == w.corr.sample
+            assert abs(r["corr_energy"] - w.corr.energy) <= 2e-5 * w.corr.energy
+            if w.detected:
+                assert abs(r["corr_offset"] - w.corr.offset) <= 5e-6
+    # complex64 input and a 1500-block batch (whole-block tickets) against the unsectioned kernel
+    big = np.tile(blocks, (1500 // nb + 1, 1))[:1500]
+    e2 = F.Engine(N, h, tpls, THR, (7, 110), THR, max_batch=1500)
+    u2 = F.Engine(N, h, tpls, THR, (7, 110), THR, max_batch=1500, path="unsectioned")
+    a, b = e2.detect(big, np.arange(1500)), u2.detect(big, np.arange(1500))
+    for t in range(n_tpl):
+        _close(a[:, t], b[:, t], (b[:, t]["flags"] & F.FLAG_CORR) != 0)
+    c64 = ((blocks[:16].astype(np.float32) - 127.4) / 128).view(np.complex64)
+    for t in range(n_tpl):
+        rc, ru = eng.detect(c64, np.arange(16))[:, t], uns.detect(c64, np.arange(16))[:, t]
+        _close(rc, ru, (ru["flags"] & F.FLAG_CORR) != 0)
+    for e in (eng, uns, gen, e2, u2):
+        e.close()
 
 
 def test_stage_dumps_come_from_the_unsectioned_kernel_and_agree():

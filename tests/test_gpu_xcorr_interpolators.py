@@ -10,13 +10,29 @@ import pytest
 
 from thrifty_amd import _native as F
 from thrifty_amd.detect import Detector
-from thrifty_amd.experimental import carrier_interpolators, xcorr_interpolators
-from thrifty_amd.experimental.detect_xcorr_interpol import InterpolationDetector
+from oracle import thrifty_np as onp
 
 from test_gpu_detector_api import card_text, settings_of
 from test_oracle_golden import XCORR_CASES
 
 pytestmark = pytest.mark.gpu
+
+# the callables assigned here are the ORACLE's restatements: the product ships the hook
+# (`soa_estimate.interpolate = fn`), not the reference's interpolators
+
+
+def host_interpolate(det, src, method):
+    """What the reference's class assigns for `method` (detect_xcorr_interpol.py:36-62), from the oracle;
+    its callables take (corr_mag, peak_idx, xhat), the hook hands out the first two and keeps the
+    block's shifted spectrum in soa_estimate.last_fft."""
+    if method == "gaussian":
+        return None                              # the engine's own log-parabola: nothing to assign
+    fn = {"none": onp.xcorr_none, "parabolic": onp.xcorr_parabolic, "cosine": onp.xcorr_cosine,
+          "autocorr": lambda: onp.xcorr_autocorr(src["template"]),
+          "maximise": lambda: onp.xcorr_maximise(src["template"])}[method]
+    if method in ("autocorr", "maximise"):
+        fn = fn()
+    return lambda corr_mag, peak: fn(corr_mag, peak, det.soa_estimate.last_fft)
 
 
 def items_of(src):
@@ -27,7 +43,10 @@ def items_of(src):
 def test_interpolation_detector_matches_the_references(golden, src_name, method):
     g, src = golden("xcorr_%s_%s" % (src_name, method)), golden(src_name)
     st = settings_of(src)
-    det = InterpolationDetector(st, iter(items_of(src)), rxid=int(src["rxid"]), method=method, batch_size=5)
+    det = Detector(st, iter(items_of(src)), rxid=int(src["rxid"]), batch_size=5)
+    fn = host_interpolate(det, src, method)
+    if fn is not None:
+        det.soa_estimate.interpolate = fn
     assert det._host_soa == (method != "gaussian")          # `gaussian` is the engine's own: the fast path
     got = list(det)
     assert len(got) == len(src["blocks"])
@@ -66,7 +85,7 @@ def test_interpolation_detector_matches_the_references(golden, src_name, method)
 
 
 def test_the_engines_own_interpolator_restated_on_the_host_gives_the_engines_records(golden):
-    """xcorr_interpolators.gaussian assigned as the interpolator is the default detector computed
+    """The log-parabola (soa_estimator.py:159-170) assigned as the interpolator is the default detector computed
     the slow way -- the same offsets to float32 rounding, everything else equal."""
     src = golden("c2")
     st = settings_of(src)
@@ -76,7 +95,7 @@ def test_the_engines_own_interpolator_restated_on_the_host_gives_the_engines_rec
 
     def gaussian(corr_mag, peak):
         seen.append((corr_mag.dtype, corr_mag.shape, peak, slow.soa_estimate.last_fft.shape))
-        return xcorr_interpolators.gaussian(corr_mag, peak)
+        return onp.xcorr_gaussian(corr_mag, peak)
 
     slow.soa_estimate.interpolate = gaussian
     assert slow._host_soa and not slow._host_interp and slow.soa_estimate.interpolate is gaussian
@@ -101,12 +120,11 @@ def test_both_stages_replaced_follow_the_oracle(golden):
     """`sync.interpolator` AND `soa_estimate.interpolate` replaced: the correlation the second
     callable sees is the one of the block shifted by the first callable's offset
     (thr_debug_stage_offsets)."""
-    from oracle import thrifty_np as onp
     src = golden("c2")
     st = settings_of(src)
     det = Detector(st, iter(items_of(src)), rxid=0, batch_size=6)
-    det.sync.interpolator = carrier_interpolators.parabolic
-    det.soa_estimate.interpolate = xcorr_interpolators.cosine
+    det.sync.interpolator = onp.parabolic_offset
+    det.soa_estimate.interpolate = onp.xcorr_cosine
     assert det._host_interp and det._host_soa
     got = list(det)
     orc = onp.OracleDetector(16384, int(src["history_len"]), src["template"], tuple(src["carrier_thresh"]),
@@ -148,7 +166,7 @@ def test_an_exception_of_the_callable_belongs_to_its_block_and_the_modes_it_excl
         calls.append(peak)
         if len(calls) == 4:
             raise FloatingPointError("no vertex")
-        return xcorr_interpolators.parabolic(corr_mag, peak)
+        return onp.xcorr_parabolic(corr_mag, peak)
 
     det = Detector(st, iter(items_of(src)), rxid=0, batch_size=8)
     det.soa_estimate.interpolate = picky
@@ -160,13 +178,8 @@ def test_an_exception_of_the_callable_belongs_to_its_block_and_the_modes_it_excl
     assert len(out) == hits[3]                       # every block before the fourth detection came out
     with pytest.raises(StopIteration):
         next(det)
-    # an integer template: the reference's autocorr scales an integer array in place, NumPy refuses
-    # (xcorr_interpolators.py:68) -- the same happens here, at the first detected block
-    det = InterpolationDetector(st, iter(items_of(src)), rxid=0, method="autocorr")
-    with pytest.raises(TypeError):
-        list(det)
     det2 = Detector(st, io.BytesIO(b""), rxid=0)
-    det2.soa_estimate.interpolate = xcorr_interpolators.none
+    det2.soa_estimate.interpolate = onp.xcorr_none
     with pytest.raises(TypeError, match="replaced interpolator"):
         next(det2.iter_detected_records())
     with pytest.raises(NotImplementedError):
@@ -174,43 +187,8 @@ def test_an_exception_of_the_callable_belongs_to_its_block_and_the_modes_it_excl
     from thrifty_amd.experimental.detect_preshift import PreshiftDetector
     pre = PreshiftDetector(st, None)
     with pytest.raises(NotImplementedError):
-        pre.soa_estimate.interpolate = xcorr_interpolators.none
+        pre.soa_estimate.interpolate = onp.xcorr_none
     with pytest.raises(TypeError):
         Detector(st, None).soa_estimate.interpolate = 0.25
     with pytest.raises(NotImplementedError):
         Detector(st, None).soa_estimate.interpolate(np.ones(8), 3)   # the engine's own has no host form
-    with pytest.raises(KeyError):
-        InterpolationDetector(st, None, method="spline")
-
-
-@pytest.mark.parametrize("method,quiet", [("parabolic", True), ("maximise", False), ("gaussian", True)])
-def test_the_references_command_line(golden, tmp_path, monkeypatch, capsys, method, quiet):
-    """`python -m thrifty_amd.experimental.detect_xcorr_interpol --method M rx.card -o rx.toad`
-    (reference detect_xcorr_interpol.py:65-80): a replaced interpolator takes the per-block loop even
-    under --quiet; the default `gaussian` is the engine's own and takes the library loop."""
-    from thrifty_amd.experimental import detect_xcorr_interpol as mod
-    from test_gpu_detector_api import assert_toad_close
-    src = golden("c2")
-    np.save(tmp_path / "template.npy", src["template"])
-    (tmp_path / "detector.cfg").write_text(
-        "rxid: 0\nsample_rate: 2.4M\nblock_size: 16384\nblock_history: 4096\n"
-        "carrier_window: 7 - 110\ncarrier_threshold: 15 * snr\ncorr_threshold: 15*snr\n"
-        "template: %s\n" % (tmp_path / "template.npy"))
-    (tmp_path / "rx.card").write_text(card_text(src))
-    argv = ["detect_xcorr_interpol", str(tmp_path / "rx.card"), "-o", str(tmp_path / "rx.toad"),
-            "-c", str(tmp_path / "detector.cfg"), "--method", method] + (["--quiet"] if quiet else [])
-    monkeypatch.setattr("sys.argv", argv)
-    mod._main()
-    lines = (tmp_path / "rx.toad").read_text().strip().split("\n")
-    if method == "gaussian":
-        assert_toad_close(lines, str(src["toad"]))
-    else:
-        ref = str(golden("xcorr_c2_" + method)["toad"]).split("\n")
-        assert len(lines) == len(ref)
-        for a, b in zip(lines, ref):
-            fa, fb = a.split(), b.split()
-            assert fa[:3] == fb[:3] and fa[4] == fb[4] and fa[8] == fb[8]
-            np.testing.assert_allclose(float(fa[5]), float(fb[5]), atol=1e-3 if method == "maximise" else 1e-4)
-            np.testing.assert_allclose(float(fa[3]), float(fb[3]), atol=1.2e-3)
-    out = capsys.readouterr().out
-    assert (out.strip() == "") == quiet

@@ -21,9 +21,10 @@ FLAG_CARRIER = 1
 FLAG_CORR = 2
 FLAG_INDEX_ERROR = 4
 FLAG_INT_OFFSET = 8
+FLAG_FIT_UNCONVERGED = 16
 N_KERNEL_SLOTS = 5
 
-ABI_VERSION = 8     # THR_ABI_VERSION of include/thrifty_hip.h
+ABI_VERSION = 9     # THR_ABI_VERSION of include/thrifty_hip.h
 
 EXPORTS = [
     "thr_abi_version", "thr_last_error", "thr_create", "thr_destroy", "thr_detect",
@@ -32,7 +33,7 @@ EXPORTS = [
     "thr_debug_stage", "thr_debug_stage_offsets", "thr_identify", "thr_frame_card",
     "thr_submit", "thr_submit_card", "thr_submit_stream", "thr_collect", "thr_inputs_consumed", "thr_poll",
     "thr_set_stream_default", "thr_format_toad",
-    "thr_run_card", "thr_run_stream", "thr_get_settings", "thr_input_window_ex", "thr_input_window_release", "thr_detect_offsets", "thr_set_wait_mode", "thr_debug_window", "thr_debug_window_times", "thr_debug_correlate_geom", "thr_debug_sections", "thr_debug_pipe_times",
+    "thr_run_card", "thr_run_stream", "thr_get_settings", "thr_input_window_ex", "thr_input_window_release", "thr_detect_offsets", "thr_set_wait_mode", "thr_debug_window", "thr_debug_window_times", "thr_debug_correlate_geom", "thr_debug_sections", "thr_debug_pipe_times", "thr_get_path_info",
 ]
 ERR_ARG, ERR_DEVICE, ERR_STATE, ERR_INDEX = -1, -2, -3, -4       # THR_ERR_*
 VARIANT_DEFAULT, VARIANT_PRESHIFT, VARIANT_FASTDET = 0, 1, 2      # THR_VARIANT_*
@@ -51,6 +52,18 @@ class ThrSettings(C.Structure):
         ("carrier_thresh", C.c_double * 3), ("corr_thresh", C.c_double * 3),
         ("device_id", C.c_int32), ("max_batch", C.c_int32),
     ]
+
+
+class ThrPathInfo(C.Structure):
+    _fields_ = [
+        ("n_sections", C.c_int32), ("section_len", C.c_int32), ("rows_lo", C.c_int32), ("rows_hi", C.c_int32),
+        ("why_unsectioned", C.c_int32), ("n_templates", C.c_int32),
+        ("carrier_kernel", C.c_char * 48), ("correlate_kernel", C.c_char * 48), ("text", C.c_char * 256),
+    ]
+
+
+# THR_WHY_*
+WHY_UNSECTIONED = ("sectioned", "path", "variant", "stddev", "geometry", "block_len")
 
 
 class ThrRunOpts(C.Structure):
@@ -610,6 +623,17 @@ class Engine(object):
         self._lib.thr_debug_correlate_geom.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         _check(self._lib, self._lib.thr_debug_correlate_geom(self._h, C.byref(lo), C.byref(hi)))
         return lo.value, hi.value
+
+    def path_info(self):
+        """thr_get_path_info -> dict: which kernels this handle's plain launches take and why
+        (`why_unsectioned` is one of WHY_UNSECTIONED; `text` says the same as one sentence)."""
+        info = ThrPathInfo()
+        self._lib.thr_get_path_info.argtypes = [C.c_void_p, C.POINTER(ThrPathInfo)]
+        _check(self._lib, self._lib.thr_get_path_info(self._h, C.byref(info)))
+        return {"n_sections": info.n_sections, "section_len": info.section_len,
+                "rows": (info.rows_lo, info.rows_hi), "why_unsectioned": WHY_UNSECTIONED[info.why_unsectioned],
+                "n_templates": info.n_templates, "carrier_kernel": info.carrier_kernel.decode(),
+                "correlate_kernel": info.correlate_kernel.decode(), "text": info.text.decode()}
 
     def sections(self):
         """thr_debug_sections -> (n_sections, section_len) of this handle's plain correlate launches

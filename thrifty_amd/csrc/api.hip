@@ -357,8 +357,11 @@ struct thr_handle {
     float4* d_tspec16k = nullptr;   // sectioned: templates zero-padded to 16384, k_correlate's layout
     thr::CorrStats* d_seg_stats = nullptr;   // sectioned: [long_batch][T][n_seg]
     bool sec4k = false;             // block_len 16384, short template: correlate stage as 4096-sample sections (detect16k_sec.hip)
-    float4* d_tspec4k = nullptr;    // sec4k: the template zero-padded to 4096, the short-block kernels' layout
+    float4* d_tspec4k = nullptr;    // sec4k: the templates zero-padded to 4096, the short-block kernels' layout
+    float4* d_ctab_pair = nullptr;  // sec4k, several templates: C[32][32] as [j][c] = (C[2j][c], C[2j+1][c])
+    float4* d_park = nullptr;       // sec4k, several templates: spectrum scratch (thr::park_bytes_4k; may stay null)
     int path = 0;                   // THR_PATH_* the handle was created with
+    int why_unsectioned = 0;        // THR_WHY_* (thr_get_path_info)
     int gen_batch = 0;       // generic path: blocks per internal sub-batch
     float2* d_gen_scratch = nullptr;  // generic path: 3 * gen_batch * N complex
     float2* d_tspec_nat = nullptr;    // generic path: conj(FFT(template))/N, natural order
@@ -664,18 +667,34 @@ int build_constants(thr_handle* h) {
         // 4096-sample sections of a 16384-sample block: conj(FFT(template zero-padded to 4096)) / 4096,
         // thread column c = row * 32 + k2 holds bins row + 4 k2 + 128 k3 (the short-block layout, R1 = 4)
         const int m = 4096, r1 = 4, tb = 128;
-        std::vector<float2> s4(m);
-        std::vector<std::complex<double>> buf(m, 0.0);
-        for (int i = 0; i < w; ++i) buf[i] = h->cfg.templates[i];
-        host_fft(buf);
-        for (int c = 0; c < tb; ++c)
-            for (int k3 = 0; k3 < 32; ++k3) {
-                const int k = (c >> 5) + r1 * (c & 31) + tb * k3;
-                const std::complex<double> cc = std::conj(buf[k]) / double(m);
-                s4[((k3 >> 1) * tb + c) * 2 + (k3 & 1)] = float2{float(cc.real()), float(cc.imag())};
-            }
+        std::vector<float2> s4(size_t(nt) * m);
+        for (int t = 0; t < nt; ++t) {
+            std::vector<std::complex<double>> buf(m, 0.0);
+            for (int i = 0; i < w; ++i) buf[i] = h->cfg.templates[size_t(t) * w + i];
+            host_fft(buf);
+            float2* out = s4.data() + size_t(t) * m;
+            for (int c = 0; c < tb; ++c)
+                for (int k3 = 0; k3 < 32; ++k3) {
+                    const int k = (c >> 5) + r1 * (c & 31) + tb * k3;
+                    const std::complex<double> cc = std::conj(buf[k]) / double(m);
+                    out[((k3 >> 1) * tb + c) * 2 + (k3 & 1)] = float2{float(cc.real()), float(cc.imag())};
+                }
+        }
         HIP_TRY(hipMalloc(&h->d_tspec4k, s4.size() * sizeof(float2)));
         HIP_TRY(hipMemcpy(h->d_tspec4k, s4.data(), s4.size() * sizeof(float2), hipMemcpyHostToDevice));
+        if (nt > 1) {
+            // the C table in pairs, for the kernel form that re-reads its twiddle column every pass
+            std::vector<float2> cp(1024);
+            for (int j = 0; j < 16; ++j)
+                for (int c = 0; c < 32; ++c) {
+                    cp[(j * 32 + c) * 2] = tab[(2 * j) * 32 + c];
+                    cp[(j * 32 + c) * 2 + 1] = tab[(2 * j + 1) * 32 + c];
+                }
+            HIP_TRY(hipMalloc(&h->d_ctab_pair, cp.size() * sizeof(float2)));
+            HIP_TRY(hipMemcpy(h->d_ctab_pair, cp.data(), cp.size() * sizeof(float2), hipMemcpyHostToDevice));
+            const size_t pb = thr::park_bytes_4k(4 * h->n_cu);
+            if (pb) HIP_TRY(hipMalloc(&h->d_park, pb));
+        }
     }
     float2* d_spec = nullptr;
     HIP_TRY(hipMalloc(&d_spec, spec.size() * sizeof(float2)));
@@ -941,6 +960,7 @@ int run_batch_fast(thr_handle* h, const void* d_samples_all, int format,
             if (sec)
                 HIP_TRY(thr::launch_correlate_4k(format, d_samples, h->dev, h->d_tables, h->d_twn, h->d_tspec4k,
                                                  h->d_shifts, h->d_work_list, h->d_work_count, h->d_seg_stats,
+                                                 h->d_ctab_pair, h->d_park,
                                                  int(std::min<long long>((long long)n_blocks * h->dev.n_seg,
                                                                          4ll * h->n_cu)),
                                                  h->stream));
@@ -1306,6 +1326,62 @@ int thr_debug_sections(thr_handle* h, int* n_sections, int* section_len) try {
     return thr::on_exception("thr_debug_sections");
 }
 
+int thr_get_path_info(thr_handle* h, thr_path_info* out) try {
+    if (!h || !out) return fail(THR_ERR_ARG, "thr_get_path_info: null argument");
+    std::memset(out, 0, sizeof(*out));
+    out->n_templates = h->cfg.n_templates;
+    out->n_sections = (h->seg || h->sec4k) ? h->dev.n_seg : 0;
+    out->section_len = h->sec4k ? 4096 : h->seg ? 16384 : 0;
+    out->why_unsectioned = h->why_unsectioned;
+    out->rows_lo = out->rows_hi = -1;
+    const int n = h->cfg.block_len;
+    const char* car;
+    const char* cor;
+    if (h->preshift_num && h->fast) {
+        car = cor = "k_preshift";
+    } else if (h->fast) {
+        car = h->dev.car_prune == 1 ? "k_carrier_pruned" : h->dev.car_prune == 2 ? "k_carrier_pruned (pre-shifted window)"
+                                                                                  : "k_carrier";
+        cor = h->sec4k ? "k_correlate_4k" : "k_correlate";
+        if (!h->sec4k) thr::correlate_geom_16k(h->dev, &out->rows_lo, &out->rows_hi);
+    } else if (h->lng && !h->preshift_num) {
+        car = h->dev.car_prune == 1 ? "k_carrier_dit+k_select_dit" : "k_carrier_sub+k_select";
+        cor = h->seg ? "k_correlate_seg" : "k_correlate_sub";
+        if (h->seg) thr::correlate_geom_seg(h->dev, &out->rows_lo, &out->rows_hi);
+    } else if (h->small) {
+        car = "k_carrier_small";
+        cor = "k_correlate_small";
+    } else {
+        car = "g_* (multi-pass)";
+        cor = "g_* (multi-pass)";
+    }
+    std::snprintf(out->carrier_kernel, sizeof(out->carrier_kernel), "%s", car);
+    std::snprintf(out->correlate_kernel, sizeof(out->correlate_kernel), "%s", cor);
+    static const char* const why[] = {
+        "",
+        "the handle was created with an unsectioned / multi-pass kernel path",
+        "preshift / fastdet variant: one fused kernel per block",
+        "corr_thresh has a stddev term, whose sums run over every kept lag",
+        "the unique window of this history / template length needs more sections than pay",
+        "this block length has no sectioned form"};
+    if (out->n_sections)
+        std::snprintf(out->text, sizeof(out->text),
+                      "block_len %d, %d template(s): carrier stage %s, correlate stage %s in %d sections of %d samples",
+                      n, h->cfg.n_templates, car, cor, out->n_sections, out->section_len);
+    else if (out->rows_lo >= 0)
+        std::snprintf(out->text, sizeof(out->text),
+                      "block_len %d, %d template(s): carrier stage %s, correlate stage %s (window rows %d, %d), "
+                      "unsectioned: %s",
+                      n, h->cfg.n_templates, car, cor, out->rows_lo, out->rows_hi, why[h->why_unsectioned]);
+    else
+        std::snprintf(out->text, sizeof(out->text),
+                      "block_len %d, %d template(s): carrier stage %s, correlate stage %s, unsectioned: %s", n,
+                      h->cfg.n_templates, car, cor, why[h->why_unsectioned]);
+    return THR_OK;
+} catch (...) {
+    return thr::on_exception("thr_get_path_info");
+}
+
 int thr_debug_pipe_times(thr_handle* h, double out[16]) try {
     if (!h || !out) return fail(THR_ERR_ARG, "thr_debug_pipe_times: null argument");
     for (int i = 0; i < 8; ++i) {
@@ -1511,9 +1587,16 @@ static int create_body(thr_handle*& h, const thr_settings* s, int preshift_num, 
         if (!h->seg) d.n_seg = 0;
         // block_len 16384, one short template, no stddev term: the correlate stage as 4096-sample
         // sections (detect16k_sec.hip); stage dumps and every other launch keep k_correlate
-        h->sec4k = h->fast && !preshift_num && d.variant == 0 && s->n_templates == 1 && !d.cor_want_std &&
+        h->sec4k = h->fast && !preshift_num && d.variant == 0 && !d.cor_want_std &&
                    !unsectioned && plan_sections_4k(d, s->template_len);
         if (!h->seg && !h->sec4k) d.n_seg = 0;
+        // why not sectioned: the first reason that applies (thr_get_path_info)
+        h->why_unsectioned = (h->seg || h->sec4k)                       ? THR_WHY_SECTIONED
+                             : (multipass || unsectioned)               ? THR_WHY_PATH
+                             : (preshift_num || d.variant != 0)         ? THR_WHY_VARIANT
+                             : !(h->fast || h->lng)                     ? THR_WHY_BLOCK_LEN
+                             : (h->fast && d.cor_want_std)              ? THR_WHY_STDDEV
+                                                                        : THR_WHY_GEOMETRY;
 
         h->cfg.templates = s->templates;
         rc = build_constants(h);
@@ -1582,7 +1665,8 @@ static int create_body(thr_handle*& h, const thr_settings* s, int preshift_num, 
         CREATE_TRY(hipMalloc(&h->d_stats, mb * sizeof(thr::CarStats)));
         CREATE_TRY(hipMalloc(&h->d_shifts, mb * sizeof(thr::ShiftParams)));
         CREATE_TRY(hipMalloc(&h->d_corr_stats, mb * s->n_templates * sizeof(thr::CorrStats)));
-        if (h->sec4k) CREATE_TRY(hipMalloc(&h->d_seg_stats, mb * size_t(d.n_seg) * sizeof(thr::CorrStats)));
+        if (h->sec4k)
+            CREATE_TRY(hipMalloc(&h->d_seg_stats, mb * s->n_templates * size_t(d.n_seg) * sizeof(thr::CorrStats)));
         CREATE_TRY(hipMalloc(&h->d_work_list, mb * sizeof(int)));
         CREATE_TRY(hipMalloc(&h->d_work_count, 4 * sizeof(int)));  // [0] work count, [1] dynamic cursor
         CREATE_TRY(hipMemset(h->d_work_count, 0, 4 * sizeof(int)));  // re-armed by k_finish
@@ -1628,7 +1712,7 @@ void thr_destroy(thr_handle* h) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
     }
-    void* bufs[] = {h->d_tables, h->d_twn, h->d_tspec, h->d_stats, h->d_shifts, h->d_corr_stats, h->d_gen_scratch, h->d_tspec_nat, h->d_bank, h->d_gtw, h->d_tspec16k, h->d_tspec4k, h->d_seg_stats, h->d_win_pow, h->d_partial, h->d_dsub, h->d_work_list,
+    void* bufs[] = {h->d_tables, h->d_twn, h->d_tspec, h->d_stats, h->d_shifts, h->d_corr_stats, h->d_gen_scratch, h->d_tspec_nat, h->d_bank, h->d_gtw, h->d_tspec16k, h->d_tspec4k, h->d_ctab_pair, h->d_park, h->d_seg_stats, h->d_win_pow, h->d_partial, h->d_dsub, h->d_work_list,
                     h->d_work_count, h->d_xhat_scratch, h->d_ncompact, h->d_compact_tiles, h->d_in, h->d_idx, h->d_rec, h->d_forced};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -2422,6 +2506,11 @@ int thr_detect_offsets(thr_handle* h, const void* samples, int format, const int
     if (h->preshift_num) return fail(THR_ERR_ARG, "thr_detect_offsets: the default detector only (this variant "
                                                   "interpolates inside its fused kernel)");
     if (n_blocks == 0) return THR_OK;
+    // (k_fit splits the shift into integer and fractional parts: a NaN or infinite offset has neither.
+    // The reference's shifter raises on such a block -- int(round(nan)), carrier_sync.py:241-245)
+    for (size_t i = 0; i < n_blocks; ++i)
+        if (!std::isfinite(carrier_offset[i]))
+            return fail(THR_ERR_ARG, "thr_detect_offsets: carrier_offset[%zu] is not finite", i);
     HIP_TRY(hipSetDevice(h->device));
     if (h->hp.async_open != 0)
         return fail(THR_ERR_STATE, "thr_detect_offsets: %d submitted batch(es) not collected yet", h->hp.async_open);

@@ -338,9 +338,14 @@ __global__ __launch_bounds__(64) void k_fit(int n_blocks, DevCfg cfg,
         flags |= THR_FLAG_CARRIER;
         if (forced_offset != nullptr)
             offset = forced_offset[b];
-        else
+        else {
+            int info = 0;
             offset = lmdif_dirichlet8(st->nb[j < 7 ? j : 6], st->nb[3], j, double(n),
-                                      double(cfg.carrier_len));
+                                      double(cfg.carrier_len), &info);
+            // curve_fit raises RuntimeError for these exit codes and the reference does not catch it
+            // (carrier_sync.py:189); the record keeps lmdif's last iterate and says so
+            if (info >= 5) flags |= THR_FLAG_FIT_UNCONVERGED;
+        }
 #ifdef THR_DEBUG_FIT
         {
             double lo = offset, hi = offset;

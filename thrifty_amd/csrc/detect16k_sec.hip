@@ -38,8 +38,19 @@
 // A work item is (carrier-positive block, section); it writes the windowed first-max of the lags it
 // OWNS (cfg.seg_lo / seg_hi, section coordinates) to seg_stats[block][section] and k_finish keeps
 // the first section holding the block's largest power (np.argmax: lowest lag) -- the machinery of
-// the long blocks' sections (detect_seg.hip).  One template, no stddev term, no
-// stage dumps: every other launch of a 16384-sample block keeps k_correlate (api.hip chooses).
+// the long blocks' sections (detect_seg.hip).  No stddev term, no stage dumps:
+// every other launch of a 16384-sample block keeps k_correlate (api.hip chooses).
+//
+// SEVERAL TEMPLATES (BASELINE configs[4]; one SoaEstimator per template, soa_estimator.py:78-102):
+// the section is transformed ONCE and its spectrum multiplied with each template's in turn --
+// 1 + T transforms of 4096 points per item.  The spectrum (64 VGPRs) and the twiddle column (62)
+// do not both fit beside a pass's working set at two waves per SIMD, and a third 32 KiB array in LDS
+// costs a resident workgroup.  Two forms, a compile-time choice (Q_MULTI_FORM, A/B in profiles/README.md):
+//   1  the SPECTRUM stays in registers and the twiddle column is re-read for every pass that uses it
+//      (passes 2 and A) from an 8 KiB pair table in global memory -- every workgroup of a CU reads the
+//      same 8 KiB all the time: it stays in the CU's vector L1;
+//   2  the twiddle COLUMN stays in registers and the spectrum is parked in a 32 KiB scratch slot of the
+//      workgroup in global memory (written once per item, read back T - 1 times while it is still in L2).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -64,6 +75,10 @@ constexpr int QDATA = QR * ROW;   // LDS image, complex
 // dynamic work cursor, [192, 192 + 98 x 8) the next item's shift-phasor factors and pass-1 twiddle steps
 constexpr int Q_DYN = 128, Q_PH = 192, Q_NPH = 98;
 constexpr size_t QLDS = size_t(QDATA) * sizeof(cpx) + 1024;   // 35 840 B: four workgroups per CU
+#ifndef THR_Q_MULTI_FORM
+#define THR_Q_MULTI_FORM 1
+#endif
+constexpr int Q_MULTI_FORM = THR_Q_MULTI_FORM;   // several templates: 1 spectrum in registers, 2 spectrum in scratch
 
 // ---------------------------------------------------------------- sample source
 // thread t holds, of each of the section's four sub-sequences n1, the eight adjacent samples
@@ -182,6 +197,119 @@ __device__ __forceinline__ void q_passA(cpx* lds, cpx* z, const cpx (&cw)[R2]) {
     });
 }
 
+// Several templates, form 1: the same two passes with the thread's twiddle column READ for the pass
+// instead of held.  ctp[j][c] = (C[2 j][c], C[2 j + 1][c]), c = t & 31: 8 KiB that every workgroup of the
+// CU reads in every pass 2 and pass A (both half-waves of a wave the same 512 bytes per load).
+template <int H>
+__device__ __forceinline__ void q_cw_half(const f4* __restrict__ ctp, f4 (&w)[R2 / 4]) {
+    const char* p = reinterpret_cast<const char*>(ctp);
+    const unsigned off = unsigned(opaque_tid() & 31) * 16u;   // (uniform base + 32-bit lane offset: saddr form)
+    static_for<R2 / 4>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        w[j] = *reinterpret_cast<const f4*>(p + (off + unsigned((H * (R2 / 4) + j) * 512)));
+    });
+}
+
+__device__ __forceinline__ void q_pass2_ld(cpx* lds, const f4* __restrict__ ctp) {
+    const int t = opaque_tid();
+    cpx* base = lds + (t >> 5) * ROW + (t & 31);
+    f4 w0[R2 / 4], w1[R2 / 4];   // requested in front of the butterfly, used behind it
+    q_cw_half<0>(ctp, w0);
+    q_cw_half<1>(ctp, w1);
+    cpx v[R2];
+#pragma unroll
+    for (int n2 = 0; n2 < R2; ++n2) v[n2] = lds_b64(base + n2 * CHUNK);
+    dft_reg<R2, -1>(v);
+    static_for<R2 / 2>([&](auto K) {
+        constexpr int j = decltype(K)::value, k2 = 2 * j;
+        const f4 w = j < R2 / 4 ? w0[j % (R2 / 4)] : w1[j % (R2 / 4)];
+        cpx y0 = v[brev(k2, R2)], y1 = v[brev(k2 + 1, R2)];
+        if constexpr (k2 != 0)
+            cmul2(y0, cpx{w.x, w.y}, y1, cpx{w.z, w.w}, y0, y1);
+        else
+            y1 = cmul(y1, cpx{w.z, w.w});
+        base[k2 * CHUNK] = y0;
+        base[(k2 + 1) * CHUNK] = y1;
+    });
+}
+
+// (the spectrum stays live beside this pass: the column comes in two halves, the first requested in
+// front of the butterfly, the second behind it -- when the butterfly's temporaries are free again --
+// and used after the first)
+#ifndef THR_Q_HALF2_LATE
+#define THR_Q_HALF2_LATE 0   // dev A/B: 1 = request the second half only when the first has been used
+#endif
+__device__ __forceinline__ void q_passA_ld(cpx* lds, cpx* z, const f4* __restrict__ ctp) {
+    const int t = opaque_tid();
+    cpx v[R3];
+    static_for<R3>([&](auto K) {
+        constexpr int k3 = decltype(K)::value;
+        v[k3] = z[brev(k3, R3)];
+    });
+    f4 w[R2 / 4], w2[R2 / 4];
+    q_cw_half<0>(ctp, w);
+    dft_reg<R3, +1>(v);
+    if constexpr (!THR_Q_HALF2_LATE) {
+        __builtin_amdgcn_sched_barrier(0);
+        q_cw_half<1>(ctp, w2);
+    }
+    f4* dst = reinterpret_cast<f4*>(lds + (t >> 5) * ROW + (t & 31) * CHUNK);
+    static_for<2>([&](auto H) {
+        constexpr int h = decltype(H)::value;
+        static_for<R3 / 4>([&](auto J) {
+            constexpr int jj = decltype(J)::value, j = h * (R3 / 4) + jj;
+            const f4 ww = h == 0 ? w[jj] : w2[jj];
+            cpx y0 = v[brev(2 * j, R3)], y1 = v[brev(2 * j + 1, R3)];
+            if constexpr (j != 0)
+                cmulc2(y0, cpx{ww.x, ww.y}, y1, cpx{ww.z, ww.w}, y0, y1);
+            else
+                y1 = cmulc(y1, cpx{ww.z, ww.w});
+            dst[j] = f4{y0.x, y0.y, y1.x, y1.y};
+        });
+        if constexpr (h == 0 && THR_Q_HALF2_LATE) {
+            __builtin_amdgcn_sched_barrier(0);
+            q_cw_half<1>(ctp, w2);
+        }
+    });
+}
+
+// Pass B beside a live spectrum: inv_passB<true, true> of passes_w8.hpp (table twiddles in two halves)
+// with the second half requested behind the butterfly instead of behind the first half's use
+__device__ __forceinline__ void q_passB_ld(cpx* lds, const cpx* __restrict__ gtw, int tw_row) {
+    const int t = opaque_tid();
+    const int k1 = t >> 5, n3 = t & 31;
+    cpx* base = lds + k1 * ROW + n3;
+    cpx v[R2];
+#pragma unroll
+    for (int k2 = 0; k2 < R2; ++k2) v[k2] = lds_b64(base + k2 * CHUNK);
+    const cpx* tw = gtw + tw_row * 1024 + n3;
+    cpx w[R2 / 2], w2[R2 / 2];
+#pragma unroll
+    for (int n2 = 0; n2 < R2 / 2; ++n2) w[n2] = tw[n2 * 32];
+    dft_reg<R2, +1>(v);
+    if constexpr (!THR_Q_HALF2_LATE) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n2 = 0; n2 < R2 / 2; ++n2) w2[n2] = tw[(n2 + R2 / 2) * 32];
+    }
+    static_for<2>([&](auto H) {
+        constexpr int h = decltype(H)::value;
+        static_for<R2 / 4>([&](auto K) {
+            constexpr int n2 = h * (R2 / 2) + 2 * decltype(K)::value;
+            constexpr int i = n2 - h * (R2 / 2);
+            cpx y0, y1;
+            cmulc2(v[brev(n2, R2)], h == 0 ? w[i] : w2[i], v[brev(n2 + 1, R2)], h == 0 ? w[i + 1] : w2[i + 1], y0, y1);
+            base[n2 * CHUNK] = y0;
+            base[(n2 + 1) * CHUNK] = y1;
+        });
+        if constexpr (h == 0 && THR_Q_HALF2_LATE) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n2 = 0; n2 < R2 / 2; ++n2) w2[n2] = tw[(n2 + R2 / 2) * 32];
+        }
+    });
+}
+
 // Pass C (radix 4 over k1, the thread's 8 columns), registers out: c[n1 * 8 + j] = corr[n1 * 1024 + 8 t + j]
 __device__ __forceinline__ void q_passC(const cpx* lds, int t, cpx* c) {
     const int m0 = t * QA;
@@ -249,12 +377,14 @@ __device__ __forceinline__ void q_phasor_store(const QPhasor& r, int t, cpx* sc_
 // (owned lags [0 or 1, 3072 or 3073): every section of BASELINE's geometry, every section but the
 // last of any 1023-sample template) takes a peak search without the tests -- one uniform branch per item.
 // =========================================================================
-template <int FMT, bool GENERIC_ROWS>
+// MULTI: 0 one template; 1 / 2 several, the spectrum in registers / in the workgroup's scratch slot
+// (Q_MULTI_FORM above).  ctp: the pair table of form 1; park: the scratch slots of form 2, 32 KiB each.
+template <int FMT, bool GENERIC_ROWS, int MULTI>
 __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(2))) void k_correlate_4k(
     const void* __restrict__ samples, DevCfg cfg, const cpx* __restrict__ ctab,
     const cpx* __restrict__ twn, const f4* __restrict__ tspec, const ShiftParams* __restrict__ shifts,
     const int* __restrict__ work_list, const int* __restrict__ work_count,
-    CorrStats* __restrict__ seg_stats) {
+    CorrStats* __restrict__ seg_stats, const f4* __restrict__ ctp, f4* __restrict__ park) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cpx* lds = reinterpret_cast<cpx*>(smem_raw);
     unsigned char* sc_red = reinterpret_cast<unsigned char*>(lds + QDATA);
@@ -270,12 +400,14 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(2))) void k_
 
     // the thread's column of C = W_1024^(a b): the twiddles of passes 2 and A of every item
     cpx cw[R2];
-    {
+    if constexpr (MULTI != 1) {
         const int c = opaque_tid() & 31;
         cw[0] = cpx{1.f, 0.f};
 #pragma unroll
         for (int k = 1; k < R2; ++k) cw[k] = ctab[k * 32 + c];
     }
+    f4* const slot = MULTI == 2 ? park + size_t(blockIdx.x) * (QN / 2) + opaque_tid() : nullptr;
+    const int n_tpl = MULTI ? cfg.n_templates : 1;
 
     // W_4096^(k1 m0) of the thread's first column m0 = 8 t: row 4 k1 of the W_16384 table
     cpx bk[QR];
@@ -329,6 +461,21 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(2))) void k_
     }
     __syncthreads();
     int* dyn_ctr = const_cast<int*>(work_count) + 1;
+    // the template spectrum of the thread's 32 bins k = row + 4 k2 + 128 k3 (16 x float4 from L2).  One
+    // template: requested in every item two passes ahead of the product.  Several: template tpl + 1 is
+    // requested in template tpl's turn, behind its peak search -- and the FIRST template's slice for the
+    // next item in the last template's turn, so every request is unconditional (a conditional one would
+    // keep the old slice's 64 registers alive through the whole turn).
+    f4 tq[R3 / 2];
+    auto request_tq = [&](int tpl) {
+        const char* ts = reinterpret_cast<const char*>(tspec + size_t(tpl) * (QN / 2));
+        const unsigned off = unsigned(opaque_tid()) * 16u;
+        static_for<R3 / 2>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            tq[j] = *reinterpret_cast<const f4*>(ts + (off + unsigned(j * (QT * 16))));
+        });
+    };
+    if constexpr (MULTI != 0) request_tq(0);
     for (int wi = wi0, iter = 0; wi < n_work; ++iter) {
 #ifdef THR_DEV
         const bool tl_on = blockIdx.x == 0 && iter == 40 && cfg.timeline != nullptr;
@@ -383,39 +530,44 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(2))) void k_
         // the next item's phasor factors: this item's were read before the barrier above, the new
         // ones are read after the two barriers that follow
         if (more) q_phasor_store(ph, t, sc_ph);
-        // the template spectrum of the thread's 32 bins k = row + 4 k2 + 128 k3 (16 x float4 from L2):
-        // requested here, two passes ahead of the product
-        f4 tq[R3 / 2];
-        {
-            const char* ts = reinterpret_cast<const char*>(tspec);
-            const unsigned off = unsigned(opaque_tid()) * 16u;
-            static_for<R3 / 2>([&](auto J) {
-                constexpr int j = decltype(J)::value;
-                tq[j] = *reinterpret_cast<const f4*>(ts + (off + unsigned(j * (QT * 16))));
-            });
-        }
+        if constexpr (MULTI == 0) request_tq(0);   // here: two passes ahead of the product
         // rows 2w, 2w + 1 belong to wave w through passes 2, 3, A and B: no barriers
-        q_pass2(lds, cw);
+        if constexpr (MULTI == 1)
+            q_pass2_ld(lds, ctp);
+        else
+            q_pass2(lds, cw);
         __builtin_amdgcn_sched_barrier(0);
         THR_STAMP(5);
+        // X^ conj(T^) / 4096 of the first template; with several, the product for template tpl + 1 is
+        // formed at the bottom of template tpl's turn (z is what the loop carries)
+        cpx z[R3];
         cpx xh[R3];
         fwd_pass3(lds, xh);
         THR_STAMP(6);
-
-        // X^ conj(T^) / 4096
-        {
-            cpx z[R3];
+        if constexpr (MULTI == 2) {   // park the spectrum: the pairs the template's float4 j multiplies
             static_for<R3 / 2>([&](auto J) {
                 constexpr int j = decltype(J)::value;
-                const f4 q = tq[j];
-                cmul2(xh[brev(2 * j, R3)], cpx{q.x, q.y}, xh[brev(2 * j + 1, R3)], cpx{q.z, q.w},
-                      z[brev(2 * j, R3)], z[brev(2 * j + 1, R3)]);
+                slot[j * QT] = f4{xh[brev(2 * j, R3)].x, xh[brev(2 * j, R3)].y, xh[brev(2 * j + 1, R3)].x,
+                                  xh[brev(2 * j + 1, R3)].y};
             });
-            q_passA(lds, z, cw);
         }
+        static_for<R3 / 2>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            const f4 q = tq[j];
+            cmul2(xh[brev(2 * j, R3)], cpx{q.x, q.y}, xh[brev(2 * j + 1, R3)], cpx{q.z, q.w},
+                  z[brev(2 * j, R3)], z[brev(2 * j + 1, R3)]);
+        });
+      for (int tpl = 0;;) {
+        if constexpr (MULTI == 1)
+            q_passA_ld(lds, z, ctp);
+        else
+            q_passA(lds, z, cw);
         __builtin_amdgcn_sched_barrier(0);
         THR_STAMP(7);
-        inv_passB<true>(lds, gtw, (opaque_tid() >> 5) * (16 / QR));
+        if constexpr (MULTI == 1)
+            q_passB_ld(lds, gtw, (opaque_tid() >> 5) * (16 / QR));
+        else
+            inv_passB<true>(lds, gtw, (opaque_tid() >> 5) * (16 / QR));
         THR_STAMP(8);
         __syncthreads();
         THR_STAMP(9);
@@ -486,14 +638,28 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(2))) void k_
         unsigned long long best =
             wmax < 0.f ? 0ull : ((unsigned long long)__float_as_uint(wmax) << 32) | (0xFFFFFFFFu - wlag);
         THR_STAMP(11);
+        // form 2: the parked spectrum comes back in two halves -- the first requested here, under the
+        // reduction, the second when the powers are dead
+        f4 xs0[R3 / 4], xs1[R3 / 4];
+        if constexpr (MULTI != 0) {
+            // the next spectrum slice (the correlation's 64 registers are free again), used behind the
+            // reduction and the neighbours
+            __builtin_amdgcn_sched_barrier(0);   // (not above the correlation's arithmetic)
+            request_tq(tpl + 1 < n_tpl ? tpl + 1 : 0);
+#ifndef THR_Q_XS_LATE
+            if constexpr (MULTI == 2)
+                static_for<R3 / 4>([&](auto J) { xs0[decltype(J)::value] = slot[decltype(J)::value * QT]; });
+#endif
+        }
         block_reduce_wave_keys<QT / 64>(best, sc_red, parity);
         THR_STAMP(12);
         parity ^= 1;
         const int pk = int(0xFFFFFFFFu - unsigned(best & 0xFFFFFFFFu));
-        CorrStats* cs = seg_stats + (size_t(b) * cfg.n_templates) * n_seg + seg;
+        CorrStats* cs = seg_stats + (size_t(b) * cfg.n_templates + tpl) * n_seg + seg;
         // |corr[pk - 1 .. pk + 1]|^2 for the log-parabola.  pk is uniform in the workgroup, so WHICH of
         // its 32 powers a thread would contribute, q = n1 * 8 + j of lag n = n1 * 1024 + 8 t + j, is
         // uniform too: one scalar jump picks the register, the one thread that holds the lag stores it
+#ifndef THR_Q_NO_NEIGH
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const int n = pk - 1 + d;
@@ -513,6 +679,7 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(2))) void k_
             }
             if (((n & 1023) >> 3) == t) cs->m2[d] = val;
         }
+#endif
         if (t == 0) {
             cs->pm2 = __uint_as_float(unsigned(best >> 32));
             cs->pk = pk;
@@ -520,34 +687,62 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(2))) void k_
             cs->sum_mag2 = 0.f;
         }
         THR_STAMP(13);
+        if (++tpl >= n_tpl) break;
+        if constexpr (MULTI == 2) {   // X^ conj(T^) / 4096 of the next template
+#ifdef THR_Q_XS_LATE
+            static_for<R3 / 4>([&](auto J) { xs0[decltype(J)::value] = slot[decltype(J)::value * QT]; });
+#endif
+            static_for<R3 / 4>([&](auto J) { xs1[decltype(J)::value] = slot[(R3 / 4 + decltype(J)::value) * QT]; });
+            static_for<R3 / 2>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                const f4 q = tq[j];
+                const f4 x = j < R3 / 4 ? xs0[j % (R3 / 4)] : xs1[j % (R3 / 4)];
+                cmul2(cpx{x.x, x.y}, cpx{q.x, q.y}, cpx{x.z, x.w}, cpx{q.z, q.w},
+                      z[brev(2 * j, R3)], z[brev(2 * j + 1, R3)]);
+            });
+        } else {
+            static_for<R3 / 2>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                const f4 q = tq[j];
+                cmul2(xh[brev(2 * j, R3)], cpx{q.x, q.y}, xh[brev(2 * j + 1, R3)], cpx{q.z, q.w},
+                      z[brev(2 * j, R3)], z[brev(2 * j + 1, R3)]);
+            });
+        }
+      }   // templates
     }
 }
 
 typedef void (*correlate4k_fn)(const void*, DevCfg, const cpx*, const cpx*, const f4*, const ShiftParams*,
-                               const int*, const int*, CorrStats*);
+                               const int*, const int*, CorrStats*, const f4*, f4*);
 
 template <int FMT>
 correlate4k_fn pick_4k(const DevCfg& cfg) {
-    return cfg.no_row_geom ? &k_correlate_4k<FMT, true> : &k_correlate_4k<FMT, false>;
+    if (cfg.n_templates > 1)
+        return cfg.no_row_geom ? &k_correlate_4k<FMT, true, Q_MULTI_FORM> : &k_correlate_4k<FMT, false, Q_MULTI_FORM>;
+    return cfg.no_row_geom ? &k_correlate_4k<FMT, true, 0> : &k_correlate_4k<FMT, false, 0>;
 }
 
 }  // namespace
 
 size_t lds_bytes_4k() { return QLDS; }
+// several templates: bytes of the spectrum scratch for `grid` workgroups (0: this build keeps the spectrum in registers)
+size_t park_bytes_4k(int grid) { return Q_MULTI_FORM == 2 ? size_t(grid) * QN * sizeof(cpx) : 0; }
 
-// seg_stats: [block of the batch][section]; tspec4k: conj(FFT(template zero-padded to 4096)) / 4096
-// in the short-block kernels' lane-coalesced order (api.hip, build_constants)
+// seg_stats: [block of the batch][template][section]; tspec4k: per template conj(FFT(template zero-padded
+// to 4096)) / 4096 in the short-block kernels' lane-coalesced order; ctab_pair: C[32][32] as
+// [j][c] = (C[2 j][c], C[2 j + 1][c]) (api.hip, build_constants); park: park_bytes_4k(grid) of scratch
 hipError_t launch_correlate_4k(int fmt, const void* samples, const DevCfg& cfg, const float2* tables,
                                const float2* twn, const float4* tspec4k, const ShiftParams* shifts,
                                const int* work_list, const int* work_count, CorrStats* seg_stats,
-                               int grid, hipStream_t stream) {
+                               const float4* ctab_pair, float4* park, int grid, hipStream_t stream) {
     correlate4k_fn fn = fmt == THR_IN_U8 ? pick_4k<THR_IN_U8>(cfg) : pick_4k<THR_IN_C64>(cfg);
 #ifdef THR_Q_GRIDCAP   // dev A/B: resident workgroups
     grid = std::min(grid, THR_Q_GRIDCAP);
 #endif
     hipLaunchKernelGGL(fn, dim3(grid), dim3(QT), QLDS, stream, samples, cfg,
                        reinterpret_cast<const cpx*>(tables), reinterpret_cast<const cpx*>(twn),
-                       reinterpret_cast<const f4*>(tspec4k), shifts, work_list, work_count, seg_stats);
+                       reinterpret_cast<const f4*>(tspec4k), shifts, work_list, work_count, seg_stats,
+                       reinterpret_cast<const f4*>(ctab_pair), reinterpret_cast<f4*>(park));
     return hipGetLastError();
 }
 

@@ -131,14 +131,16 @@ hipError_t launch_correlate_seg(int fmt, const void* samples, const DevCfg& cfg,
                                 const int* work_list, const int* work_count, CorrStats* seg_stats,
                                 int grid, hipStream_t stream);
 
-// detect16k_sec.hip (block_len 16384, ONE short template, no stddev term: the correlate stage as up
+// detect16k_sec.hip (block_len 16384, short templates, no stddev term: the correlate stage as up
 // to four overlap-save sections of 4096 samples, a 128-thread workgroup each; seg_stats:
-// [block][section]; tspec4k = the template zero-padded to 4096, the short-block kernels' layout)
+// [block][template][section]; tspec4k = the templates zero-padded to 4096, the short-block kernels'
+// layout; ctab_pair / park: several templates only)
 size_t lds_bytes_4k();
+size_t park_bytes_4k(int grid);
 hipError_t launch_correlate_4k(int fmt, const void* samples, const DevCfg& cfg, const float2* tables,
                                const float2* twn, const float4* tspec4k, const ShiftParams* shifts,
                                const int* work_list, const int* work_count, CorrStats* seg_stats,
-                               int grid, hipStream_t stream);
+                               const float4* ctab_pair, float4* park, int grid, hipStream_t stream);
 
 // detect_long.hip (block_len = 2 or 4 x 16384: R0 LDS-resident sub-transforms per block)
 bool long_supported(int block_len);

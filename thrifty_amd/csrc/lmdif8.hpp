@@ -256,7 +256,10 @@ __device__ __forceinline__ void lmpar2(double r00, double r01, double r11, int p
 // curve_fit(model, x = -3..3, y, p0 = (y[3], 0)) -> fitted offset.  `j` = this lane's point.
 // (Everything indexed by the column permutation is a V2 / an explicit pair: no private arrays
 // with run-time indices, which would live in scratch memory.)
-__device__ inline double lmdif_dirichlet8(float yj, float y_peak, int j, double n, double w) {
+// *info_out (optional): MINPACK's exit code -- 1 .. 4 converged; 5 (600 evaluations) .. 8 are what
+// curve_fit turns into RuntimeError("Optimal parameters not found") (scipy/optimize/_minpack_py.py)
+__device__ inline double lmdif_dirichlet8(float yj, float y_peak, int j, double n, double w,
+                                          int* info_out = nullptr) {
 #pragma clang fp contract(off)
     using namespace lm;
     const double ftol = 1.49012e-8, xtol = 1.49012e-8, factor = 100.0;
@@ -420,6 +423,7 @@ __device__ inline double lmdif_dirichlet8(float yj, float y_peak, int j, double 
         } while (ratio < 1e-4);
         if (info != 0) break;
     }
+    if (info_out != nullptr) *info_out = info;
     return x.b;
 }
 

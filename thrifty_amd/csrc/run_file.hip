@@ -22,6 +22,7 @@
 #include <condition_variable>
 #include <cstring>
 #include <deque>
+#include <exception>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -140,7 +141,10 @@ struct Runner {
                 queued.pop_front();
             }
             Batch& b = ring[size_t(s)];
-            if (fmt_rc == THR_OK && !stop.load()) {
+            // (this is a std::thread: an exception that left it -- std::bad_alloc from the three vectors
+            // below -- would end the whole process in std::terminate.  It ends the RUN instead; the slot
+            // goes back either way, so the caller's thread never blocks in take_free())
+            if (fmt_rc == THR_OK && !stop.load()) try {
                 const auto t0 = Clock::now();
                 keep.clear();
                 keep_ts.clear();
@@ -195,6 +199,14 @@ struct Runner {
                     st.detections += keep.size();
                 }
                 if (end != n || fmt_rc != THR_OK) stop.store(true);
+            } catch (const std::exception& e) {
+                fmt_rc = THR_ERR_STATE;
+                fmt_err = std::string("thr_run: the text thread failed: ") + e.what();
+                stop.store(true);
+            } catch (...) {
+                fmt_rc = THR_ERR_STATE;
+                fmt_err = "thr_run: the text thread failed (unknown exception)";
+                stop.store(true);
             }
             give_free(s);
         }

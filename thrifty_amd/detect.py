@@ -11,6 +11,7 @@ and re-hydrates records in input order.  There is no CPU fallback.
 from __future__ import annotations
 
 import argparse
+import logging
 import sys
 import time
 from collections import deque, namedtuple
@@ -27,6 +28,8 @@ DetectorSettings = namedtuple("DetectorSettings", [
     "block_len", "history_len", "carrier_len", "carrier_thresh", "carrier_window",
     "template", "corr_thresh"])
 
+
+_LOG = logging.getLogger("thrifty_amd.detect")
 
 _SLOW_SOURCE_S = 0.002   # inter-arrival time above which a LIVE source ends the batch being filled
 _UNKNOWN_FILL_S = 0.05   # a source that does not say whether it is live: longest time spent FILLING one batch
@@ -194,6 +197,7 @@ class Detector(object):
     _multi = False            # MultiTemplateDetector: settings.template is [n_templates, len]
     _host_interp = False      # `sync.interpolator` has been assigned: the two-pass slow path
     _host_soa = False         # `soa_estimate.interpolate` has been assigned: the correlation comes to the host
+    strict_fit = False        # True: a block flagged THR_FLAG_FIT_UNCONVERGED ends the iteration with RuntimeError
 
     @property
     def _host_path(self):
@@ -203,7 +207,8 @@ class Detector(object):
 
     def __init__(self, settings, blocks=None, rxid=-1, yield_data=False, batch_size=None,
                  device_id=0, _preshift_num=0, _fastdet=False, max_wait=None, max_fill=None,
-                 pin_input=True, _interpolator="parabolic", _path="auto", populate_threads=0, low_cpu=False):
+                 pin_input=True, _interpolator="parabolic", _path="auto", populate_threads=0, low_cpu=False,
+                 strict_fit=False):
         """Batching a classic `(timestamp, idx, block)` iterator must not hold results back the way
         the reference's per-block loop never did.  What ends the batch being filled (what has
         arrived is processed instead of waiting for a full batch) depends on what the source says
@@ -222,7 +227,16 @@ class Detector(object):
         `populate_threads`: the library threads that map its pages ahead of the locking (0 = the
         library's default; a rank of a sharded run passes parallel.populate_threads(world));
         `low_cpu`: wait for batches by asking and napping instead of polling (thr_set_wait_mode: about
-        half a CPU less per detector, what a rank takes when the node's CPUs are short)."""
+        half a CPU less per detector, what a rank takes when the node's CPUs are short).
+        `strict_fit`: the reference's loop dies with RuntimeError("Optimal parameters not found: ...")
+        on a block whose Dirichlet fit SciPy's curve_fit gives up on (carrier_sync.py:189, uncaught --
+        degenerate geometries only: templates far shorter than block_len / 24).  The engine's fit is
+        the same MINPACK routine and flags such a block (THR_FLAG_FIT_UNCONVERGED); by default the
+        block still gets its record (from the fit's last iterate), with strict_fit=True the iteration
+        ends there with RuntimeError after the results before it, like the reference's.  Whether the
+        fit runs out of evaluations hangs on the last digit of seven float32 magnitudes, so the flagged
+        blocks are the reference's up to that noise -- not guaranteed block for block."""
+        self.strict_fit = bool(strict_fit)
         if batch_size is None:      # ~64 MiB of u8 samples per engine batch (the staging chunk size)
             batch_size = max(64, min(65536, (64 << 20) // (2 * int(settings.block_len))))
             if yield_data:          # every block of a batch holds two N-point stage dumps in _ready
@@ -258,6 +272,10 @@ class Detector(object):
             fastdet=_fastdet, interpolator=_interpolator, path=_path)
         if low_cpu:
             self._engine.set_wait_mode(True)
+        # which kernels this handle's launches take, and why (thr_get_path_info): a stddev term, a
+        # long template or an odd history silently costs the sectioned correlate stage -- say so once
+        self.engine_path = self._engine.path_info()
+        _LOG.info("engine path: %s", self.engine_path["text"])
         # a mapped input file becomes the engine's input window: a library thread page-locks it a
         # bounded distance ahead of the chunk copies, which are then asynchronous DMA out of the
         # page cache -- this thread frames the next batch and formats the previous one meanwhile
@@ -304,6 +322,8 @@ class Detector(object):
             # the reference indexes fft_mag[peak_idx + reach] without wrapping (carrier_sync.py:187)
             raise IndexError("index {} is out of bounds for axis 0 with size {}".format(
                 max(int(rec["carrier_bin"]) + self._fit_reach, n), n))
+        if self.strict_fit and flags & _native.FLAG_FIT_UNCONVERGED:
+            raise self._fit_error()
         has_carrier = bool(flags & _native.FLAG_CARRIER)
         carrier = toads_data.CarrierSyncInfo(
             int(rec["carrier_bin"]),
@@ -326,13 +346,13 @@ class Detector(object):
         (carrier_sync.py:187) ends the list with a `_Deferred` exception: the results of the
         blocks before it are still handed out, as the reference's per-block loop does."""
         flags = recs["flags"]
-        bad = np.flatnonzero(flags & _native.FLAG_INDEX_ERROR)
+        bad = np.flatnonzero(flags & self._fatal_flags)
         if len(bad):
             k = int(bad[0])
             out = self._results(stamps[:k], idxs[:k], recs[:k])
             try:
                 self._result(stamps[k], int(idxs[k]), recs[k])
-            except IndexError as exc:
+            except (IndexError, RuntimeError) as exc:
                 out.append(_Deferred(exc))
             return out
         fl = flags.tolist()
@@ -358,6 +378,17 @@ class Detector(object):
             out.append((det, Res(stamps[i], bi, self.new_len * bi + cor.sample + cor.offset,
                                  Car(cbin[i], coff[i], cen[i], cno[i]), cor, self.rxid)))
         return out
+
+    @property
+    def _fatal_flags(self):
+        """Record flags on which the reference's per-block loop dies (the iteration ends there)."""
+        return _native.FLAG_INDEX_ERROR | (_native.FLAG_FIT_UNCONVERGED if self.strict_fit else 0)
+
+    @staticmethod
+    def _fit_error():
+        # scipy/optimize/_minpack_py.py: `raise RuntimeError("Optimal parameters not found: " + errmsg)`
+        return RuntimeError("Optimal parameters not found: the Dirichlet carrier fit did not converge "
+                            "(MINPACK lmdif exit code 5..8)")
 
     def _run(self, arr, idx):
         """Records [B, n_templates] of the blocks in `arr`, now.  While the iterator has a batch
@@ -421,6 +452,12 @@ class Detector(object):
                     error, n_ok = exc, i
                     break
             offsets = np.array([float(v) for v in vals[:n_ok]])
+            wild = np.flatnonzero(~np.isfinite(offsets))
+            if len(wild):       # the reference's shifter raises on such a block (int(round(nan)), carrier_sync.py:241-245)
+                n_ok = int(wild[0])
+                error = ValueError("sync.interpolator returned %r for block %d: the carrier offset is not finite"
+                                   % (vals[n_ok], int(idx[n_ok])))
+                offsets = offsets[:n_ok]
         out = []
         if n_ok:
             recs = (self._engine.detect_offsets(arr[:n_ok], offsets, idx[:n_ok]) if offsets is not None
@@ -632,7 +669,7 @@ class Detector(object):
         stamps, idxs, recs = got
         groups = None
         if self.only_detections:
-            keep = np.flatnonzero(recs["flags"] & (_native.FLAG_CORR | _native.FLAG_INDEX_ERROR))
+            keep = np.flatnonzero(recs["flags"] & (_native.FLAG_CORR | self._fatal_flags))
             if len(keep) != len(recs):
                 stamps, idxs, recs, groups = [stamps[i] for i in keep], idxs[keep], recs[keep], keep
         self._ready.extend(self._package(self._results(stamps, idxs, recs), groups))
@@ -659,7 +696,7 @@ class Detector(object):
             if got is None:
                 continue
             stamps, idxs, recs = got
-            bad = np.flatnonzero(recs["flags"] & _native.FLAG_INDEX_ERROR)
+            bad = np.flatnonzero(recs["flags"] & self._fatal_flags)
             stop = int(bad[0]) if len(bad) else len(recs)
             keep = np.flatnonzero(recs["flags"][:stop] & _native.FLAG_CORR)
             if len(keep):
@@ -674,8 +711,10 @@ class Detector(object):
         """True if the REST of the input can be handed to thr_run_card / thr_run_stream in one call:
         a mapped file behind a batch reader, nothing in flight or handed out yet."""
         reader = self._card if self._card is not None else self._raw
+        # (strict_fit ends the run on a flag the library loop does not look at: the Python loop then)
         return (reader is not None and reader.mapped and not self.yield_data and not self._ahead
-                and not self._ready and not self._exhausted and self._read_error is None)
+                and not self._ready and not self._exhausted and self._read_error is None
+                and not self.strict_fit)
 
     def _index_error(self, carrier_bin):
         n = self.settings.block_len
@@ -864,12 +903,13 @@ class MultiTemplateDetector(Detector):
     _multi = True
 
     def __init__(self, settings, blocks=None, rxid=-1, yield_data=False, batch_size=None,
-                 device_id=0, max_wait=None, populate_threads=0, low_cpu=False):
+                 device_id=0, max_wait=None, populate_threads=0, low_cpu=False, strict_fit=False):
         if yield_data:
             raise TypeError("stage dumps (yield_data) are a single-template facility")
         super(MultiTemplateDetector, self).__init__(settings, blocks, rxid=rxid, batch_size=batch_size,
                                                     device_id=device_id, max_wait=max_wait,
-                                                    populate_threads=populate_threads, low_cpu=low_cpu)
+                                                    populate_threads=populate_threads, low_cpu=low_cpu,
+                                                    strict_fit=strict_fit)
         self.n_templates = int(np.asarray(settings.template).shape[0])
 
     def _flat(self, stamps, idxs, recs):
