@@ -348,6 +348,26 @@ def card_to_toad_leg(n_card):
                 stats["construct_s"], stats["write_toad_s"] = t1 - t0, dt - (t1 - t0)
             return dt, stats
 
+    def iterate_file(path, reader, serialize):
+        """The reference's operator loop itself (detect.py:217-223): `for detected, result in
+        Detector(settings, card_reader(f))` -- one (detected, DetectionResult) per input block; with
+        `serialize` every detection's .toad line too (EVERY block of this dense file: the worst case
+        -- a receiver's capture holds a few detections per second).  -> (seconds incl.
+        construction, blocks, detections, .toad lines)"""
+        with open(path, "rb") as f:
+            t0 = time.perf_counter()
+            det = Detector(st, reader(f), rxid=0)
+            n_blocks, hits, lines = 0, 0, []
+            for detected, result in det:
+                n_blocks += 1
+                if detected:
+                    hits += 1
+                    if serialize:
+                        lines.append(result.serialize())
+            dt = time.perf_counter() - t0
+            det.close()
+            return dt, n_blocks, hits, lines
+
     out = {"config": "BASELINE configs[0]: example detector.cfg settings (block 16384, history %d, %d-sample "
                      "template, window bins %d..%d) on a synthetic .card stream" % (h, len(tpl), cwin[0], cwin[1]),
            "cpu_blocks_per_s": n_cpu / t_cpu, "cpu_blocks": n_cpu, "cpu_cores": 1}
@@ -385,6 +405,17 @@ def card_to_toad_leg(n_card):
                                     ".toad text formatted and written by a library thread), file on disk"
                                     % (text_bytes / 1e9),
                     "detections_cpu": len(cpu_out), "detections_gpu": len(gpu_out)})
+        # --- the object-building iteration over the same file: every block a (detected, DetectionResult)
+        iterate_file(card, lambda f: block_data.CardStream(f, n), False)                       # (warm-up pass)
+        t_it, n_it, hits_it, _ = iterate_file(card, lambda f: block_data.CardStream(f, n), False)
+        t_its, _, _, it_lines = iterate_file(card, lambda f: block_data.CardStream(f, n), True)
+        out.update({"iter_blocks_per_s": n_it / t_it, "iter_blocks": n_it, "iter_detections": hits_it,
+                    "iter_serialize_blocks_per_s": n_it / t_its,
+                    "iter_text_equals_write_toad": it_lines == gpu_out,
+                    "iter_includes": "Detector construction, `for detected, result in Detector(settings, "
+                                     "CardStream(f))` over the same file: one (detected, DetectionResult) per "
+                                     "block (built a batch at a time by thrifty_amd._fastresults); "
+                                     "iter_serialize: plus result.serialize() for every detection, here every block"})
         same = [a.split()[:3] + [a.split()[4], a.split()[8]] for a in gpu_out[:len(cpu_out)]] == \
                [b.split()[:3] + [b.split()[4], b.split()[8]] for b in cpu_out]
         out["outputs_agree"] = bool(same)       # rxid, time, block, sample, carrier bin of the first lines
@@ -402,6 +433,13 @@ def card_to_toad_leg(n_card):
         run_file(rawp, lambda f: block_data.RawStream(f, n, h), os.path.join(tmpd, "warm2.toad"))
         t_raw, rstats = run_file(rawp, lambda f: block_data.RawStream(f, n, h), os.path.join(tmpd, "raw.toad"))
         rloop = (rstats or {}).get("calls", [{}])[-1]
+        iterate_file(rawp, lambda f: block_data.RawStream(f, n, h), False)
+        t_rit, n_rit, _, _ = iterate_file(rawp, lambda f: block_data.RawStream(f, n, h), False)
+        t_rits, _, _, rit_lines = iterate_file(rawp, lambda f: block_data.RawStream(f, n, h), True)
+        raw_text = open(os.path.join(tmpd, "raw.toad"), "rb").read().decode("ascii").split("\n")[:-1]
+        out.update({"raw_iter_blocks_per_s": n_rit / t_rit, "raw_iter_blocks": n_rit,
+                    "raw_iter_serialize_blocks_per_s": n_rit / t_rits,
+                    "raw_iter_text_equals_write_toad": rit_lines == raw_text})
         out.update({"raw_gpu_loop_stats": {k: rloop.get(k) for k in ("batches", "total_s", "frame_s", "submit_s", "wait_s",
                                                                      "format_s", "write_s", "window", "submit_phases")},
                     "raw_gpu_blocks_per_s": (rstats or {}).get("blocks", 0) / t_raw,
@@ -1005,12 +1043,16 @@ def main():
                 ct = card_to_toad_leg(args.card_blocks)
                 detail["card_to_toad"] = ct
                 for k in ("cpu_blocks_per_s", "gpu_blocks_per_s", "gpu_blocks", "gpu_loop_blocks_per_s",
-                          "raw_gpu_blocks_per_s", "outputs_agree"):
+                          "raw_gpu_blocks_per_s", "outputs_agree", "iter_blocks_per_s", "raw_iter_blocks_per_s",
+                          "iter_serialize_blocks_per_s", "iter_text_equals_write_toad"):
                     if k in ct:
                         cb["card_to_toad_" + k] = ct[k]
                 summary["card_to_toad"] = ct["gpu_blocks_per_s"]
                 if "raw_gpu_blocks_per_s" in ct:
                     summary["raw_to_toad"] = ct["raw_gpu_blocks_per_s"]
+                # the reference's own `for detected, result in Detector(...)` loop over the same files
+                summary["detector_iter"] = ct["iter_blocks_per_s"]
+                summary["detector_iter_raw"] = ct["raw_iter_blocks_per_s"]
         # flat, last: the one place where every leg's blocks/s stands side by side (the driver keeps
         # the tail of stdout)
         line["summary"] = {k: round(v) for k, v in summary.items()}

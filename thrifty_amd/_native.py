@@ -249,6 +249,17 @@ def format_toad(recs, timestamps, new_len, rxid=None, with_txid=False, carrier_o
     return buf[:used.value].tobytes()
 
 
+def format_toad_address():
+    """Address of thr_format_toad in the loaded library (0: no library) -- handed to
+    thrifty_amd._fastresults, which links nothing, so that DetectionResult.serialize() of an engine
+    record is the library's own text."""
+    try:
+        lib = load_library()
+    except Exception:       # noqa: BLE001 -- host-only use without the library: Python formatting
+        return 0
+    return C.cast(lib.thr_format_toad, C.c_void_p).value or 0
+
+
 class Ticket(object):
     """An open thr_submit*(): the records array the library will fill and the inputs it may
     still be reading (kept alive here)."""

@@ -22,6 +22,27 @@ PER_FILE_FLAGS = {"detect16k_carrier.hip": ["-mllvm", "-amdgpu-sched-strategy=ma
                   "detect16k_sec.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]}
 
 
+# host glue in C (CPython API, no device code): the batch constructor of the per-block result objects
+FAST_SRC = os.path.join(CSRC, "fastresults.c")
+FAST_LIB = os.path.join(HERE, "_fastresults.so")
+
+
+def build_fastresults(force=False, verbose=False):
+    """gcc -> thrifty_amd/_fastresults.so (imported as thrifty_amd._fastresults)."""
+    import sysconfig
+    if not force and os.path.exists(FAST_LIB) and os.path.getmtime(FAST_LIB) > max(
+            os.path.getmtime(FAST_SRC), os.path.getmtime(os.path.abspath(__file__))):
+        return FAST_LIB
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        raise RuntimeError("no C compiler: thrifty_amd._fastresults cannot be built")
+    cmd = [cc, "-O2", "-fPIC", "-shared", "-Wall", "-I" + sysconfig.get_paths()["include"], FAST_SRC, "-o", FAST_LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return FAST_LIB
+
+
 def _hipcc():
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
@@ -56,7 +77,8 @@ def needs_build():
 
 
 def build_native(force=False, verbose=False):
-    """Compile every HIP source for gfx950 and link libthriftyhip.so."""
+    """Compile every HIP source for gfx950 and link libthriftyhip.so (and the C result builder)."""
+    build_fastresults(force=force, verbose=verbose)
     if not force and not needs_build():
         return LIB
     # -fno-slp-vectorize: the kernels are hand-vectorised with ext-vector float2;

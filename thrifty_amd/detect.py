@@ -20,6 +20,10 @@ from types import SimpleNamespace
 import numpy as np
 
 from thrifty_amd import _native, toads_data, util
+try:
+    from thrifty_amd import _fastresults
+except ImportError as _exc:      # pragma: no cover -- a tree that was never built
+    raise ImportError("thrifty_amd._fastresults is not built: run `python -m thrifty_amd.build` (%s)" % _exc)
 from thrifty_amd.block_data import CardStream, RawStream, block_reader, card_reader
 from thrifty_amd.setting_parsers import normalize_freq_range
 from thrifty_amd.settings import load_args
@@ -355,29 +359,23 @@ class Detector(object):
             except (IndexError, RuntimeError) as exc:
                 out.append(_Deferred(exc))
             return out
-        fl = flags.tolist()
-        cbin = recs["carrier_bin"].tolist()
-        coff = (recs["carrier_offset"].tolist() if self._offset_type is float
-                else recs["carrier_offset"].astype(self._offset_type))
-        if np.any(flags & _native.FLAG_INT_OFFSET):       # (the reference's interpolator returned the int 0)
-            coff = [0 if f & _native.FLAG_INT_OFFSET else v for f, v in zip(fl, coff)]
-        cen, cno = recs["carrier_energy"], recs["carrier_noise"]     # stay np.float32
-        samp = recs["corr_sample"].tolist()
-        soff = recs["corr_offset"].tolist()
-        en = recs["corr_energy"].astype(np.float64).tolist()
-        no = recs["corr_noise"].astype(np.float64).tolist()
-        out = []
-        Car, Cor, Res = toads_data.CarrierSyncInfo, toads_data.CorrDetectionInfo, toads_data.DetectionResult
-        for i in range(len(fl)):
-            f, bi = fl[i], int(idxs[i])
-            if not f & _native.FLAG_CARRIER:
-                out.append((False, Res(stamps[i], bi, None, Car(cbin[i], 0, cen[i], cno[i]), None, self.rxid)))
-                continue
-            det = bool(f & _native.FLAG_CORR)
-            cor = Cor(samp[i], soff[i] if det else 0, en[i], no[i])
-            out.append((det, Res(stamps[i], bi, self.new_len * bi + cor.sample + cor.offset,
-                                 Car(cbin[i], coff[i], cen[i], cno[i]), cor, self.rxid)))
-        return out
+        # one C call per batch (csrc/fastresults.c): a result keeps its 64-byte record and makes each
+        # attribute -- the namedtuples, soa, the np.float32 energies -- when it is first read
+        recs = np.ascontiguousarray(recs)
+        if not np.array_equal(recs["block_idx"], idxs):     # (the engine echoes the index it was given)
+            recs = recs.copy()
+            recs["block_idx"] = idxs
+        return _fastresults.build(self._result_context(), recs, stamps)
+
+    def _result_context(self):
+        ctx = getattr(self, "_ctx", None)
+        key = (self.new_len, self.rxid, self._offset_type, self._multi)
+        if ctx is None or ctx[0] != key:
+            ctx = self._ctx = (key, _fastresults.Context(
+                int(self.new_len), self.rxid, self._offset_type, np.float32, toads_data.CarrierSyncInfo,
+                toads_data.CorrDetectionInfo, toads_data.DetectionResult, bool(self._multi),
+                _native.format_toad_address(), _offset_mode(self._offset_type)))
+        return ctx[1]
 
     @property
     def _fatal_flags(self):
@@ -882,7 +880,26 @@ class Detector(object):
         return False
 
     def __iter__(self):
-        return self
+        """Iterating hands out what next() does, a batch's results straight from the batch (a generator
+        over `_ready`: one interpreter call per BATCH instead of two per block -- `for detected, result
+        in Detector(...)` is the reference's operator loop, detect.py:217); next(detector) between two
+        steps of the loop takes from the same queue, in order."""
+        if self.blocks is None and not self._ready:
+            raise TypeError("Detector was constructed without a block source")
+        return self._iterate()
+
+    def _iterate(self):
+        ready = self._ready
+        while True:
+            while ready:
+                item = ready.popleft()
+                if isinstance(item, _Deferred):
+                    ready.appendleft(item)
+                    self.next()             # raises it, with next()'s bookkeeping
+                yield item
+            if not self._more():
+                return
+            self._refill()
 
     def __next__(self):
         return self.next()
@@ -917,12 +934,7 @@ class MultiTemplateDetector(Detector):
         return (np.repeat(np.asarray(stamps, dtype=np.float64), t).tolist(), np.repeat(idxs, t),
                 recs.reshape(-1))
 
-    def _results(self, stamps, idxs, recs):
-        out = super(MultiTemplateDetector, self)._results(stamps, idxs, recs)
-        for item, txid in zip(out, recs["template_id"].tolist()):
-            if not isinstance(item, _Deferred):
-                item[1].txid = txid
-        return out
+    # (`txid` = the record's template index: set by the result builder, csrc/fastresults.c)
 
     def _package(self, results, groups):
         """Flat [block][template] results -> one list per block (`groups`: the flat positions

@@ -18,21 +18,39 @@ CorrDetectionInfo = namedtuple("CorrDetectionInfo", ["sample", "offset", "energy
 _LINE = "{t:.6f} {b} {s:.8f} {ps} {po} {pe} {pn} {cb} {co} {ce} {cn}"
 
 
-class DetectionResult(object):
-    """One block's verdict: timestamp, block index, SoA and both info tuples."""
+try:
+    # the C base of DetectionResult (csrc/fastresults.c): the seven attributes, and a constructor
+    # Detector uses to make a whole batch of results from the engine's records in one call
+    from thrifty_amd._fastresults import ResultBase as _ResultBase
+except ImportError:        # library not built (python -m thrifty_amd.build): the same object in Python
+    class _ResultBase(object):
+        __slots__ = ("timestamp", "block", "soa", "carrier_info", "corr_info", "rxid", "txid")
 
-    __slots__ = ("timestamp", "block", "soa", "carrier_info", "corr_info", "rxid", "txid")
+        def __init__(self, timestamp, block, soa, carrier_info, corr_info, rxid=None, txid=None):
+            self.timestamp = timestamp
+            self.block = block
+            self.soa = soa
+            self.carrier_info = carrier_info
+            self.corr_info = corr_info
+            self.rxid = rxid
+            self.txid = txid
 
-    def __init__(self, timestamp, block, soa, carrier_info, corr_info, rxid=None, txid=None):
-        self.timestamp = timestamp
-        self.block = block
-        self.soa = soa
-        self.carrier_info = carrier_info
-        self.corr_info = corr_info
-        self.rxid = rxid
-        self.txid = txid
+
+class DetectionResult(_ResultBase):
+    """One block's verdict: timestamp, block index, SoA and both info tuples
+    (`DetectionResult(timestamp, block, soa, carrier_info, corr_info, rxid=None, txid=None)`,
+    reference toads_data.py:22-45)."""
+
+    __slots__ = ()
 
     def serialize(self):
+        # (a result the detector built from an engine record, untouched since: the engine library's
+        # line for that record -- the same text, formatted in C)
+        fast = getattr(self, "_serialize_fast", None)
+        if fast is not None:
+            text = fast()
+            if text is not None:
+                return text
         cor, car = self.corr_info, self.carrier_info
         text = _LINE.format(t=self.timestamp, b=self.block, s=self.soa,
                             ps=cor.sample, po=cor.offset, pe=cor.energy, pn=cor.noise,
