@@ -78,7 +78,7 @@ CONFIGS = {
 # reference's DEFAULT carrier window, settings.py:75-80 '0--1' = every bin, which takes the
 # full-spectrum carrier kernel instead of the pruned one)
 LEGS = {"c3": dict(name="c3", T=1, mix="dense", batch=16384, resident=2 * 16384),
-        "t4": dict(name="c2", T=4, mix="dense", batch=16384, resident=4 * 16384),
+        "t4": dict(name="c2", T=4, mix="dense", batch=32768, resident=2 * 32768),
         "sparse": dict(name="c2", T=1, mix="sparse", batch=32768, resident=4 * 32768),
         "fullwin": dict(name="c2", T=1, mix="dense", batch=32768, resident=4 * 32768, window=(0, -1)),
         "c3t4": dict(name="c3", T=4, mix="dense", batch=4096, resident=2 * 4096),

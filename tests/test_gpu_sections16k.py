@@ -278,9 +278,11 @@ def test_random_sectioned_geometries_equal_the_unsectioned_kernel_and_the_oracle
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
     import fuzz_sections
     rng = np.random.default_rng(20260930)
-    seen = set()
+    seen, templates = set(), set()
     for k in range(14):
         status, desc = fuzz_sections.one(rng, k, F, onp, synth, soak_util, 16)
         assert status == "ok", (desc, status)
         seen.add(desc.rsplit("sections=", 1)[1])
+        templates.add(desc.split(" T=")[1].split()[0])
     assert len(seen) >= 3, seen
+    assert templates & {"2", "4"} and "1" in templates, templates      # one template and several

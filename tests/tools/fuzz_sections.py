@@ -9,7 +9,7 @@ carrier tone without the code.  Checked per configuration:
 
   * the handle reports the planned sections (thr_debug_sections);
   * its records equal the unsectioned kernel's (path="unsectioned": k_correlate) -- flags, carrier
-    fields and SAMPLE INDEX exactly, correlation energy / noise to 3e-6, sub-sample offset to 5e-6;
+    fields and SAMPLE INDEX exactly, correlation energy / noise to 3e-6, sub-sample offset to 3e-5;
   * the whole-rows peak search equals the generic one (path="generic_rows") byte for byte;
   * the first blocks equal the oracle's records (soak_util.compare: bin, verdicts, sample exact;
     with a template of at least N / 24 samples -- a well-conditioned carrier fit -- offset 2e-5,
@@ -58,11 +58,15 @@ def one(rng, k, F, onp, synth, soak_util, n_oracle):
     xthr = (float(rng.choice([0, 10.0])), float(rng.choice([8, 15])), 0.0)
     nb = int(rng.choice([7, 40, 300, 900, 2500]))
     max_batch = int(rng.choice([64, 700, 4096]))
+    # several templates (ABI 9: one forward transform per section, a product + inverse per template):
+    # template 0 is the one the bursts carry and the oracle checks; the others are random codes
+    n_tpl = int(rng.choice([1, 1, 2, 4]))
+    tpls = tpl if n_tpl == 1 else np.stack([tpl] + [np.sign(rng.normal(0, 1, w)) for _ in range(n_tpl - 1)]).astype(np.float64)
     lo, hi = onp.unique_window(N, h, w)
-    desc = "h=%d w=%d kind=%d cwin=%s cthr=%s xthr=%s nb=%d max_batch=%d" % (h, w, kind, cwin, cthr, xthr, nb, max_batch)
+    desc = "h=%d w=%d kind=%d T=%d cwin=%s cthr=%s xthr=%s nb=%d max_batch=%d" % (h, w, kind, n_tpl, cwin, cthr, xthr, nb, max_batch)
     secs = F.plan_sections(N, h, w)
     if not 1 <= len(secs) <= 4:     # (section starts are aligned down: a plan may need one more than the lag count says)
-        e = F.Engine(N, h, tpl, cthr, cwin, xthr, max_batch=8)
+        e = F.Engine(N, h, tpls, cthr, cwin, xthr, max_batch=8)
         got = e.sections()
         e.close()
         return ("ok" if got == (0, 0) else "SECTIONS %s for a plan of %d" % (got, len(secs))), desc + " sections=0"
@@ -86,16 +90,18 @@ def one(rng, k, F, onp, synth, soak_util, n_oracle):
     desc += " c64" if c64 else " u8"
     idx = np.arange(nb) + int(rng.integers(0, 1000))
     bad = []
-    eng = F.Engine(N, h, tpl, cthr, cwin, xthr, max_batch=max_batch)
-    uns = F.Engine(N, h, tpl, cthr, cwin, xthr, max_batch=max_batch, path="unsectioned")
-    gen = F.Engine(N, h, tpl, cthr, cwin, xthr, max_batch=max_batch, path="generic_rows")
+    eng = F.Engine(N, h, tpls, cthr, cwin, xthr, max_batch=max_batch)
+    uns = F.Engine(N, h, tpls, cthr, cwin, xthr, max_batch=max_batch, path="unsectioned")
+    gen = F.Engine(N, h, tpls, cthr, cwin, xthr, max_batch=max_batch, path="generic_rows")
     try:
         if eng.sections() != (len(secs), SEC):
             return "SECTIONS %s, planned %d" % (eng.sections(), len(secs)), desc
-        rec = eng.detect(inp, idx)[:, 0]
-        ref = uns.detect(inp, idx)[:, 0]
-        if gen.detect(inp, idx)[:, 0].tobytes() != rec.tobytes():
+        # (records [block][template] flattened: every template's record is compared with the
+        # unsectioned kernel's; the oracle below reads template 0's)
+        rec_all, ref_all = eng.detect(inp, idx), uns.detect(inp, idx)
+        if gen.detect(inp, idx).tobytes() != rec_all.tobytes():
             bad.append("generic_rows records differ")
+        rec, ref = rec_all.reshape(-1), ref_all.reshape(-1)
         for f in ("flags", "block_idx", "template_id", "carrier_bin", "corr_sample"):
             if not np.array_equal(rec[f], ref[f]):
                 j = int(np.nonzero(rec[f] != ref[f])[0][0])
@@ -111,8 +117,11 @@ def one(rng, k, F, onp, synth, soak_util, n_oracle):
                 d = np.abs(rec[f][m] - ref[f][m]) / np.maximum(np.abs(ref[f][m]), 1e-30)
                 if d.size and d.max() > tol:
                     bad.append("%s vs unsectioned: %.3g" % (f, d.max()))
+            # (the log-parabola divides by 2 ln b - ln a - ln c: on a peak barely above its neighbours --
+            # a detection at the threshold -- float32 rounding of the three powers is amplified; 4 of 400
+            # configurations of seed 7 reach 1e-5 .. 2e-5, BASELINE's tolerance is 1e-4)
             d = np.abs(rec["corr_offset"][det] - ref["corr_offset"][det])
-            if d.size and d.max() > 5e-6:
+            if d.size and d.max() > 3e-5:
                 bad.append("corr_offset vs unsectioned: %.3g" % d.max())
         # the oracle on the first blocks (the edge and seam bursts come first)
         no = min(nb, n_oracle)
@@ -128,7 +137,7 @@ def one(rng, k, F, onp, synth, soak_util, n_oracle):
             return ("; ".join(bad) if bad else "ok"), desc + " reference-raises sections=%d" % len(secs)
         # soak_util numbers blocks from 0: the records carry idx, compare() does not read it
         dc = cwin == (0, -1) or (min(cwin) <= 0 <= max(cwin))
-        mism, worst, ties = soak_util.compare(rec[:no], rows, blocks[:no], F.FLAG_CARRIER, F.FLAG_CORR,
+        mism, worst, ties = soak_util.compare(rec_all[:no, 0], rows, blocks[:no], F.FLAG_CARRIER, F.FLAG_CORR,
                                               only=truth["has_signal"][:no] if dc else None)
         if any(mism.values()):
             bad.append("oracle mismatches %s" % mism)
