@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Rewrite the numbers of README.md's "Measured" table and DESIGN.md's section-6 table from a saved
-default run of bench.py (profiles/r05_bench_default_run.json), which tests/test_docs_match_records.py
+default run of bench.py (profiles/r06_bench_default_run.json), which tests/test_docs_match_records.py
 holds them to.    python scripts/fill_tables.py [record.json]"""
 import json
 import os
@@ -8,7 +8,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rec = json.load(open(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r05_bench_default_run.json")))
+rec = json.load(open(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r06_bench_default_run.json")))
 summary = rec["summary"]
 legs = dict(rec["configs"], c2=dict(rec["roofline"], value=rec["value"]))
 
@@ -29,8 +29,21 @@ def rewrite(path, fn):
     open(os.path.join(ROOT, path), "w", encoding="utf-8").write("".join(out))
 
 
+def driver_summary():
+    path = os.path.join(ROOT, "BENCH_r05.json")
+    if not os.path.exists(path):
+        return {}
+    m = re.search(r'"summary": (\{[^}]*\})', json.load(open(path))["run"]["stdout_tail"])
+    return json.loads(m.group(1)) if m else {}
+
+
+theirs = driver_summary()
+
+
 def readme(key, cells):
     cells[2] = re.sub(r"\d+(?:\.\d+)? M\b", mega(summary[key]), cells[2], count=1)
+    if key in theirs:
+        cells[3] = re.sub(r"\d+(?:\.\d+)? M\b", mega(theirs[key]), cells[3], count=1)
     return cells
 
 
@@ -40,6 +53,7 @@ def design(key, cells):
     if leg:
         kern = {"k_correlate_4k": "`k_correlate_4k`", "k_correlate": "`k_correlate`", "k_correlate_seg": "`k_correlate_seg`",
                 "k_carrier": "`k_carrier_pruned`"}.get(leg["kernel"], "`%s`" % leg["kernel"])
+        cells[2] = re.sub(r"^`\w+`", "", cells[2]).strip()
         tail = re.search(r"(\s*\([^)]*\))?\s*\d+\.\d+ ms", cells[2])
         extra = (tail.group(1) or "") if tail else ""
         cells[2] = "%s%s %.3f ms, %.3f, %.3f" % (kern, extra, leg["avg_launch_ms"], leg["frac"], leg["traffic_over_algorithmic"])

@@ -471,7 +471,7 @@ class Engine(object):
         buf = np.frombuffer(text, dtype=np.uint8)
         off = np.ascontiguousarray(np.asarray(payload_off, dtype=np.int64))
         nb = off.shape[0]
-        out = np.zeros((nb, self.n_templates), dtype=RECORD_DTYPE)
+        out = self._records_out(nb)
         idx_p = None
         if block_idx is not None:
             idx = np.ascontiguousarray(np.asarray(block_idx, dtype=np.int64))
@@ -488,7 +488,7 @@ class Engine(object):
         buf = np.frombuffer(stream, dtype=np.uint8)
         stride = 2 * (self.block_len - self.history_len)
         nb = 0 if buf.size < 2 * self.block_len else (buf.size - 2 * self.block_len) // stride + 1
-        out = np.zeros((nb, self.n_templates), dtype=RECORD_DTYPE)
+        out = self._records_out(nb)
         got = C.c_size_t(0)
         _check(self._lib, self._lib.thr_detect_stream(self._h, buf.ctypes.data, buf.size,
                                                       int(first_block_idx), out.ctypes.data, nb,
@@ -497,6 +497,29 @@ class Engine(object):
         return out
 
     # ---- asynchronous host path: submit a batch, collect its records later --
+    # Record arrays of the ticket interface.  A batch's array is 128 KiB and up -- glibc serves that by
+    # mmap, and every mmap / munmap / first-touch fault of a process whose input window is page-locking
+    # a file waits for the address-space lock the lockers hold for milliseconds at a time (the iteration
+    # over a .card file ran anywhere between 0.66 and 1.05 M blocks/s).  A caller that is done with a
+    # collected array hands it back (`recycle`) and the next submit reuses its pages.
+    def _records_out(self, nb):
+        pool = self.__dict__.setdefault("_out_pool", {})
+        spare = pool.get(nb)
+        if spare:
+            return spare.pop()
+        return np.zeros((nb, self.n_templates), dtype=RECORD_DTYPE)
+
+    def recycle(self, records):
+        """Hand a collected record array back for reuse by a later submit*() (the caller keeps no view of it)."""
+        base = records
+        while isinstance(getattr(base, "base", None), np.ndarray):
+            base = base.base
+        if (isinstance(base, np.ndarray) and base.dtype == RECORD_DTYPE and base.ndim == 2
+                and base.shape[1] == self.n_templates and base.flags.c_contiguous and base.flags.owndata):
+            spare = self.__dict__.setdefault("_out_pool", {}).setdefault(base.shape[0], [])
+            if len(spare) < MAX_IN_FLIGHT + 2:
+                spare.append(base)
+
     def _idx_ptr(self, block_idx, nb):
         if block_idx is None:
             return None, None
@@ -509,7 +532,7 @@ class Engine(object):
         once; `collect(ticket)` -> records [B, n_templates].  Up to MAX_IN_FLIGHT may be open."""
         a, fmt = self._as_input(blocks)
         nb = a.shape[0]
-        out = np.zeros((nb, self.n_templates), dtype=RECORD_DTYPE)
+        out = self._records_out(nb)
         idx, idx_p = self._idx_ptr(block_idx, nb)
         t = C.c_uint64(0)
         _check(self._lib, self._lib.thr_submit(self._h, a.ctypes.data, fmt, idx_p, nb, out.ctypes.data,
@@ -521,7 +544,7 @@ class Engine(object):
         buf = np.frombuffer(text, dtype=np.uint8)
         off = np.ascontiguousarray(np.asarray(payload_off, dtype=np.int64))
         nb = off.shape[0]
-        out = np.zeros((nb, self.n_templates), dtype=RECORD_DTYPE)
+        out = self._records_out(nb)
         idx, idx_p = self._idx_ptr(block_idx, nb)
         t = C.c_uint64(0)
         _check(self._lib, self._lib.thr_submit_card(self._h, buf.ctypes.data, buf.size, off.ctypes.data,
@@ -535,7 +558,7 @@ class Engine(object):
         buf = np.frombuffer(stream, dtype=np.uint8)
         stride = 2 * (self.block_len - self.history_len)
         nb = 0 if buf.size < 2 * self.block_len else (buf.size - 2 * self.block_len) // stride + 1
-        out = np.zeros((nb, self.n_templates), dtype=RECORD_DTYPE)
+        out = self._records_out(nb)
         got, t = C.c_size_t(0), C.c_uint64(0)
         _check(self._lib, self._lib.thr_submit_stream(self._h, buf.ctypes.data, buf.size,
                                                       int(first_block_idx), out.ctypes.data, nb,

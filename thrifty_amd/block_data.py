@@ -49,17 +49,23 @@ def complex_to_raw(array):
 
 
 def _fixed_chunks(stream, nbytes):
-    """Yield exactly-`nbytes` chunks; a short tail is dropped (as the reference does)."""
-    pending = b""
+    """Yield exactly-`nbytes` chunks; a short tail is dropped (as the reference does).  One
+    preallocated buffer per chunk, filled in place (a pipe delivers a chunk in pieces)."""
+    fill = getattr(stream, "readinto", None)
     while True:
-        buf = stream.read(nbytes - len(pending))
-        if not buf:
-            return
-        pending += buf
-        if len(pending) < nbytes:
-            continue
-        yield np.frombuffer(pending, dtype=np.uint8)
-        pending = b""
+        chunk = np.empty(nbytes, dtype=np.uint8)
+        have = 0
+        while have < nbytes:
+            if fill is not None:
+                got = fill(memoryview(chunk)[have:]) or 0
+            else:
+                piece = stream.read(nbytes - have)
+                got = len(piece)
+                chunk[have:have + got] = np.frombuffer(piece, dtype=np.uint8)
+            if got == 0:
+                return
+            have += got
+        yield chunk
 
 
 def is_live(stream):
@@ -125,20 +131,27 @@ def card_reader(stream):
     return _BlockIterator(_card_reader(stream), is_live(stream))
 
 
-def _card_reader(stream):
-    while True:
-        line = stream.readline()
-        if len(line) == 0:
+def _is_data_line(text):
+    """Not a comment (`#`), a blank line or one of the capture tool's banner lines."""
+    return text[0] not in "#\n\r" and not text.startswith(_SKIP_PREFIXES)
+
+
+def _lines(stream):
+    """Lines of `stream` as str until readline() returns nothing (text or binary streams)."""
+    for ln in iter(stream.readline, None):
+        if not ln:
             return
-        if isinstance(line, bytes):
-            line = line.decode("ascii")
-        if line[0] in "#\n\r":
-            continue
-        if line.startswith(_SKIP_PREFIXES):
-            continue
-        timestamp, idx, encoded = line.rstrip("\r\n").split(" ")
-        raw = np.frombuffer(base64.b64decode(encoded), dtype=np.uint8)
-        yield float(timestamp), int(idx), IQBlock(raw_to_complex(raw), raw)
+        yield ln.decode("ascii") if isinstance(ln, bytes) else ln
+
+
+def _card_reader(stream):
+    for text in filter(_is_data_line, _lines(stream)):
+        header = text.rstrip("\r\n").split(" ")
+        if len(header) != 3:
+            raise ValueError("not enough values to unpack (expected 3, got %d)" % len(header)
+                             if len(header) < 3 else "too many values to unpack (expected 3)")
+        raw = np.frombuffer(base64.b64decode(header[2]), dtype=np.uint8)
+        yield float(header[0]), int(header[1]), IQBlock(raw_to_complex(raw), raw)
 
 
 def _map_regular_file(stream):

@@ -78,12 +78,10 @@ class _SyncStage(object):
     _DEVICE_FIT = object()      # `interpolator` not assigned: the engine's own Dirichlet fit (k_fit)
 
     def __init__(self, det, settings):
-        self._det = det
-        self.thresh_coeffs = settings.carrier_thresh
-        self.window = settings.carrier_window
-        self.weights = None
-        self._last = None       # (id of the shifted_fft handed out, record, corr) of the latest block
-        self._interpolator = self._DEVICE_FIT
+        self._det, self.weights = det, None
+        self.thresh_coeffs, self.window = settings.carrier_thresh, settings.carrier_window
+        # _last: (the shifted_fft handed out, record, corr) of the latest block
+        self._last, self._interpolator = None, self._DEVICE_FIT
 
     @property
     def interpolator(self):
@@ -671,6 +669,13 @@ class Detector(object):
             if len(keep) != len(recs):
                 stamps, idxs, recs, groups = [stamps[i] for i in keep], idxs[keep], recs[keep], keep
         self._ready.extend(self._package(self._results(stamps, idxs, recs), groups))
+        self._recycle(got[2])        # (the results hold their own copies of the records)
+
+    def _recycle(self, recs):
+        """A collected record array nobody reads any more goes back to the engine's pool (Engine.recycle)."""
+        give = getattr(self._engine, "recycle", None)
+        if give is not None:
+            give(recs)
 
     def _more(self):
         more = not self._exhausted or bool(self._ahead) or self._read_error is not None
@@ -698,11 +703,14 @@ class Detector(object):
             stop = int(bad[0]) if len(bad) else len(recs)
             keep = np.flatnonzero(recs["flags"][:stop] & _native.FLAG_CORR)
             if len(keep):
-                yield np.asarray(stamps, dtype=np.float64)[keep], recs[keep]
+                yield np.asarray(stamps, dtype=np.float64)[keep], recs[keep]      # (copies)
+            if len(bad):
+                bad_stamp, bad_idx, bad_rec = stamps[stop], int(idxs[stop]), recs[stop].copy()
+            self._recycle(recs)
             if len(bad):
                 self._exhausted = True
                 self._drop_ahead()
-                self._result(stamps[stop], int(idxs[stop]), recs[stop])   # raises
+                self._result(bad_stamp, bad_idx, bad_rec)   # raises
 
     # ---------------------------------------------------- the loop inside the library
     def _library_loop_ready(self):
@@ -990,22 +998,23 @@ class SummaryLineFormatter(object):
         self.block_len = block_len
         self.add_dt = add_dt
 
+    _CARRIER = ("blk={blk}; carrier: {det} @ {freq:.3f} kHz / {idx:>3.0f}:{offset:+.2f}, "
+                "SNR = {ampl:>4.0f} / {noise:>2.0f} = {snr:>5.2f} dB")
+    _CORR = "; corr: {det} @ {idx:>4}{offset:+.3f}{dt}, SNR = {ampl:>4.0f}/{noise:>2.0f} = {snr:>5.2f} dB"
+
+    @staticmethod
+    def _stage(fmt, mark, info, **extra):
+        """One stage's half of the line: its verdict mark, its four-field info tuple and its SNR."""
+        return fmt.format(det=mark, idx=info[0], offset=info[1], ampl=info[2], noise=info[3],
+                          snr=util.snr(info[2], info[3]), **extra)
+
     def __call__(self, detected, result):
-        car = result.carrier_info
         has_carrier = result.corr_info is not None
-        text = ("blk={blk}; carrier: {det} @ {freq:.3f} kHz / {idx:>3.0f}:{offset:+.2f}, "
-                "SNR = {ampl:>4.0f} / {noise:>2.0f} = {snr:>5.2f} dB").format(
-            blk=result.block, det="yes" if has_carrier else "no ",
-            freq=_carrier_freq(car, self.block_len, self.sample_rate) / 1e3, idx=car.bin,
-            offset=car.offset, ampl=car.energy, noise=car.noise,
-            snr=util.snr(car.energy, car.noise))
+        parts = [self._stage(self._CARRIER, "yes" if has_carrier else "no ", result.carrier_info, blk=result.block,
+                             freq=_carrier_freq(result.carrier_info, self.block_len, self.sample_rate) / 1e3)]
         if has_carrier:
-            cor = result.corr_info
-            text += ("; corr: {det} @ {idx:>4}{offset:+.3f}{dt}, "
-                     "SNR = {ampl:>4.0f}/{noise:>2.0f} = {snr:>5.2f} dB").format(
-                det="yes" if detected else "no ", idx=cor.sample, offset=cor.offset, dt="",
-                ampl=cor.energy, noise=cor.noise, snr=util.snr(cor.energy, cor.noise))
-        return text
+            parts.append(self._stage(self._CORR, "yes" if detected else "no ", result.corr_info, dt=""))
+        return "".join(parts)
 
 
 def _strip_output_args(argv):

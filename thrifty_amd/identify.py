@@ -91,14 +91,8 @@ def integrate(detections, freqmap=None):
 
 
 def load_toad_files(toad_globs):
-    filenames = []
-    for pattern in toad_globs:
-        filenames.extend(glob.glob(pattern))
-    detections = []
-    for filename in filenames:
-        with open(filename, "r") as file_:
-            detections.extend(toads_data.load_toad(file_))
-    return detections, filenames
+    filenames = [name for pattern in toad_globs for name in glob.glob(pattern)]
+    return [det for name in filenames for det in toads_data.load_toad(name)], filenames
 
 
 def load_freqmap(file_):
@@ -106,39 +100,37 @@ def load_freqmap(file_):
     (identify.py:184-215) -> {rxid: {txid: (lo + offset, hi + offset)}}."""
     if file_ is None:
         return None
-    tx_ranges, rx_offset = {}, {}
-    for key, value in parse_kvconfig(file_).items():
-        if key[0] == "@":
-            rx_offset[int(key[1:])] = float(value)
-        else:
-            lo, hi = [float(x.strip()) for x in value.split("-")]
-            tx_ranges[int(key)] = (lo, hi)
-    return {rx: {tx: (lo + off, hi + off) for tx, (lo, hi) in tx_ranges.items()}
-            for rx, off in rx_offset.items()}
+    entries = parse_kvconfig(file_)
+    offsets = {int(k[1:]): float(v) for k, v in entries.items() if k.startswith("@")}
+    nominal = {int(k): tuple(float(x) for x in v.split("-")) for k, v in entries.items() if not k.startswith("@")}
+    return {rx: {tx: (lo + off, hi + off) for tx, (lo, hi) in nominal.items()} for rx, off in offsets.items()}
+
+
+_REMOVED = "Removed {} duplicates / unidentified transmisisons from {} detections."     # (the reference's sentence, sic)
 
 
 def generate_toads(output, toad_globs, freqmap):
     detections, filenames = load_toad_files(toad_globs)
-    output.write("# source_files: [%s]\n" % (" ".join(filenames)))
-    filtered = integrate(detections, freqmap)
-    print("Removed {} duplicates / unidentified transmisisons from {} detections.".format(
-        len(detections) - len(filtered), len(detections)))
-    for detection in filtered:
-        output.write(detection.serialize() + "\n")
+    kept = integrate(detections, freqmap)
+    output.write("".join(["# source_files: [%s]\n" % " ".join(filenames)] + [d.serialize() + "\n" for d in kept]))
+    print(_REMOVED.format(len(detections) - len(kept), len(detections)))
+
+
+_CLI = (
+    (("toad_file",), dict(type=str, nargs="*", default=["*.toad"], help="toad file(s) from receivers [default: *.toad]")),
+    (("-o", "--output"), dict(type=argparse.FileType("w"), default="data.toads", help="output file [default: data.toads]")),
+    (("-m", "--map"), dict(type=argparse.FileType("r"),
+                           help="schema for mapping DFT index to transmitter ID [default: auto-detect]")),
+)
 
 
 def _main(argv=None):
-    parser = argparse.ArgumentParser(description=__doc__,
-                                     formatter_class=argparse.RawDescriptionHelpFormatter)
-    parser.add_argument("toad_file", type=str, nargs="*", default=["*.toad"],
-                        help="toad file(s) from receivers [default: *.toad]")
-    parser.add_argument("-o", "--output", type=argparse.FileType("w"), default="data.toads",
-                        help="output file [default: data.toads]")
-    parser.add_argument("-m", "--map", type=argparse.FileType("r"),
-                        help="schema for mapping DFT index to transmitter ID [default: auto-detect]")
+    parser = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    for flags, options in _CLI:
+        parser.add_argument(*flags, **options)
     args = parser.parse_args(argv)
-    generate_toads(args.output, args.toad_file, load_freqmap(args.map))
-    args.output.flush()
+    with args.output as out:
+        generate_toads(out, args.toad_file, load_freqmap(args.map))
 
 
 if __name__ == "__main__":

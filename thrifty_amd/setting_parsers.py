@@ -20,11 +20,8 @@ SI_PREFIXES = {"y": 1e-24, "z": 1e-21, "a": 1e-18, "f": 1e-15, "p": 1e-12, "n": 
 def metric_float(string):
     """'2.4M' -> 2400000.0, '3.4m' -> 0.0034, '123.4' -> 123.4."""
     text = string.strip()
-    scale = 1
-    if text and text[-1] in SI_PREFIXES:
-        scale = SI_PREFIXES[text[-1]]
-        text = text[:-1]
-    return float(text) * scale
+    scale = SI_PREFIXES.get(text[-1:])
+    return float(text) if scale is None else float(text[:-1]) * scale
 
 
 def freq_range(string):

@@ -79,75 +79,78 @@ class Namespace(dict):
 
 
 def parse_kvconfig(config_file):
-    out = {}
-    for line_no, line in enumerate(config_file, 1):
-        if isinstance(line, bytes):
-            line = line.decode()
-        line = line.split(CONFIG_COMMENT_CHAR, 1)[0]
-        if not line.strip():
-            continue
-        if CONFIG_DELIMITER not in line:
+    """`key: value` lines -> dict; `#` starts a comment, blank lines are skipped, a line without the
+    delimiter is a ConfigSyntaxError naming it."""
+    def fields(numbered):
+        line_no, raw = numbered
+        text = (raw.decode() if isinstance(raw, bytes) else raw).partition(CONFIG_COMMENT_CHAR)[0]
+        key, delimiter, value = text.partition(CONFIG_DELIMITER)
+        if text.strip() and not delimiter:
             raise ConfigSyntaxError(line_no, "No delimiter found")
-        key, value = line.split(CONFIG_DELIMITER, 1)
-        out[key.strip()] = value.strip()
-    return out
+        return (key.strip(), value.strip()) if delimiter else None
+
+    return dict(filter(None, map(fields, enumerate(config_file, 1))))
+
+
+def _table(definitions):
+    return DEFINITIONS if definitions is None else definitions
+
+
+def _require_known(keys, table, what):
+    for key in keys:
+        if key not in table:
+            raise SettingKeyError("Unknown {}: {}".format(what, key))
 
 
 def add_argparse_arguments(parser, keys, definitions=None):
-    definitions = DEFINITIONS if definitions is None else definitions
-    for key in keys:
-        if key not in definitions:
-            raise SettingKeyError("Unknown key: {}".format(key))
-        d = definitions[key]
-        if d.args:
-            text = str(d.description)
-            if d.default is not None:
-                text += " [default: {}]".format(d.default)
-            parser.add_argument(*d.args, dest=key, type=str, help=text)
+    table = _table(definitions)
+    _require_known(keys, table, "key")
+    for key, d in ((k, table[k]) for k in keys if table[k].args):
+        suffix = "" if d.default is None else " [default: {}]".format(d.default)
+        parser.add_argument(*d.args, dest=key, type=str, help=str(d.description) + suffix)
 
 
 def load(args=None, config_file=None, definitions=None):
     """defaults <- config file <- explicit args; every value parsed by its definition."""
-    definitions = DEFINITIONS if definitions is None else definitions
-    strings = {k: d.default for k, d in definitions.items() if d.default is not None}
-    for source, what in ((parse_kvconfig(config_file) if config_file is not None else None, "setting"),
-                         (args, "setting")):
-        if source is None:
-            continue
-        for key in source:
-            if key not in definitions:
-                raise SettingKeyError("Unknown {}: {}".format(what, key))
-        strings.update(source)
-    return {k: (definitions[k].parser(v) if isinstance(v, str) else v) for k, v in strings.items()}
+    table = _table(definitions)
+    layers = [{k: d.default for k, d in table.items() if d.default is not None},
+              parse_kvconfig(config_file) if config_file is not None else {},
+              args or {}]
+    for layer in layers[1:]:
+        _require_known(layer, table, "setting")
+    merged = {k: v for layer in layers for k, v in layer.items()}
+    return {k: (table[k].parser(v) if isinstance(v, str) else v) for k, v in merged.items()}
+
+
+def _open_config(path):
+    """The config file of a run: an explicit -c PATH, else ./detector.cfg if there is one, else None."""
+    if path is not None:
+        logging.info("Loaded config file from %s", path)
+        return open(path)
+    try:
+        handle = open(DEFAULT_CONFIG_PATH)
+    except IOError:
+        logging.warning("No config file found. Using default values.")
+        return None
+    logging.info("Loaded default config file from %s", DEFAULT_CONFIG_PATH)
+    return handle
 
 
 def load_args(parser, keys, argv=None, definitions=None):
     """Add -v/-c and the settings' own flags to `parser`, parse, load the config
     (explicit -c, else ./detector.cfg if present), return (settings, extra_args)."""
-    definitions = DEFINITIONS if definitions is None else definitions
+    table = _table(definitions)
     parser.add_argument("-v", "--verbose", help="Increase output verbosity", action="store_true")
     parser.add_argument("-c", "--config", dest=CONFIG_DEST, type=str, default=None,
                         help="Config file to load settings from [default: {}]".format(DEFAULT_CONFIG_PATH))
-    add_argparse_arguments(parser, keys, definitions=definitions)
-    args = vars(parser.parse_args(argv))
-    if args["verbose"]:
-        logging.basicConfig(level=logging.DEBUG)
-    config_file = None
-    path = args.pop(CONFIG_DEST)
-    if path is None:
-        try:
-            config_file = open(DEFAULT_CONFIG_PATH)
-            logging.info("Loaded default config file from %s", DEFAULT_CONFIG_PATH)
-        except IOError:
-            logging.warning("No config file found. Using default values.")
-    else:
-        config_file = open(path)
-        logging.info("Loaded config file from %s", path)
+    add_argparse_arguments(parser, keys, definitions=table)
+    parsed = vars(parser.parse_args(argv))
+    logging.basicConfig(level=logging.DEBUG) if parsed["verbose"] else None
+    config_file = _open_config(parsed.pop(CONFIG_DEST))
     try:
-        chosen = {k: v for k, v in args.items() if k in keys and v is not None}
-        values = load(chosen, config_file, definitions)
+        values = load({k: parsed[k] for k in keys if parsed.get(k) is not None}, config_file, table)
     finally:
-        if config_file is not None:
-            config_file.close()
-    return (Namespace({k: v for k, v in values.items() if k in keys}),
-            Namespace({k: v for k, v in args.items() if k not in keys}))
+        config_file.close() if config_file is not None else None
+    own = set(keys)
+    return (Namespace({k: v for k, v in values.items() if k in own}),
+            Namespace({k: v for k, v in parsed.items() if k not in own}))

@@ -15,7 +15,6 @@ import numpy as np
 CarrierSyncInfo = namedtuple("CarrierSyncInfo", ["bin", "offset", "energy", "noise"])
 CorrDetectionInfo = namedtuple("CorrDetectionInfo", ["sample", "offset", "energy", "noise"])
 
-_LINE = "{t:.6f} {b} {s:.8f} {ps} {po} {pe} {pn} {cb} {co} {ce} {cn}"
 
 
 try:
@@ -27,13 +26,8 @@ except ImportError:        # library not built (python -m thrifty_amd.build): th
         __slots__ = ("timestamp", "block", "soa", "carrier_info", "corr_info", "rxid", "txid")
 
         def __init__(self, timestamp, block, soa, carrier_info, corr_info, rxid=None, txid=None):
-            self.timestamp = timestamp
-            self.block = block
-            self.soa = soa
-            self.carrier_info = carrier_info
-            self.corr_info = corr_info
-            self.rxid = rxid
-            self.txid = txid
+            for name, value in zip(self.__slots__, (timestamp, block, soa, carrier_info, corr_info, rxid, txid)):
+                setattr(self, name, value)
 
 
 class DetectionResult(_ResultBase):
@@ -51,24 +45,22 @@ class DetectionResult(_ResultBase):
             text = fast()
             if text is not None:
                 return text
-        cor, car = self.corr_info, self.carrier_info
-        text = _LINE.format(t=self.timestamp, b=self.block, s=self.soa,
-                            ps=cor.sample, po=cor.offset, pe=cor.energy, pn=cor.noise,
-                            cb=car.bin, co=car.offset, ce=car.energy, cn=car.noise)
-        ids = [str(v) for v in (self.rxid, self.txid) if v is not None]
-        return " ".join(ids + [text])
+        columns = ["%d" % v for v in (self.rxid, self.txid) if v is not None]
+        columns += ["%.6f" % self.timestamp, "%d" % self.block, "%.8f" % self.soa]
+        columns += map("{}".format, tuple(self.corr_info) + tuple(self.carrier_info))
+        return " ".join(columns)
 
     @classmethod
     def deserialize(cls, string, with_rxid=False, with_txid=False):
+        n_ids = bool(with_rxid) + bool(with_txid)
         parts = string.split()
-        if len(parts) < 11 + bool(with_rxid) + bool(with_txid):
+        if len(parts) < n_ids + 11:
             return None
-        rxid = int(parts.pop(0)) if with_rxid else None
-        txid = int(parts.pop(0)) if with_txid else None
-        t, b, s, ps, po, pe, pn, cb, co, ce, cn = (float(p) for p in parts[:11])
-        return cls(timestamp=t, block=int(b), soa=s,
-                   carrier_info=CarrierSyncInfo(int(cb), co, ce, cn),
-                   corr_info=CorrDetectionInfo(int(ps), po, pe, pn), rxid=rxid, txid=txid)
+        ids = iter([int(p) for p in parts[:n_ids]])
+        num = [float(p) for p in parts[n_ids:n_ids + 11]]
+        return cls(num[0], int(num[1]), num[2], CarrierSyncInfo(int(num[7]), *num[8:11]),
+                   CorrDetectionInfo(int(num[3]), *num[4:7]),
+                   rxid=next(ids) if with_rxid else None, txid=next(ids) if with_txid else None)
 
     def __repr__(self):
         return "DetectionResult(block=%r, soa=%r, carrier=%r, corr=%r)" % (
@@ -115,26 +107,22 @@ def toad_lines(recs, timestamps, new_len, rxid=None, txid=None, carrier_offset_t
     return [head + " ".join(row) for row in zip(*cols)]
 
 
+def _parsed_lines(lines, with_rxid, with_txid):
+    """(line number, DetectionResult or None) of every line that is not a comment."""
+    for lineno, line in enumerate(lines, 1):
+        text = line.decode() if isinstance(line, bytes) else line
+        if text[:1] not in ("", "#"):
+            yield lineno, DetectionResult.deserialize(text, with_rxid=with_rxid, with_txid=with_txid)
+
+
 def _read(stream, with_rxid, with_txid):
-    own = isinstance(stream, str)
-    if own:
-        stream = open(stream, "r")
-    try:
-        out = []
-        for lineno, line in enumerate(stream, 1):
-            if isinstance(line, bytes):
-                line = line.decode()
-            if not line or line[0] == "#":
-                continue
-            rec = DetectionResult.deserialize(line, with_rxid=with_rxid, with_txid=with_txid)
-            if rec is None:
-                print("WARNING: skipped line #{}: line's formatting is invalid".format(lineno))
-                continue
-            out.append(rec)
-        return out
-    finally:
-        if own:
-            stream.close()
+    if isinstance(stream, str):
+        with open(stream, "r") as handle:
+            return _read(handle, with_rxid, with_txid)
+    parsed = list(_parsed_lines(stream, with_rxid, with_txid))
+    for lineno in (n for n, rec in parsed if rec is None):
+        print("WARNING: skipped line #{}: line's formatting is invalid".format(lineno))
+    return [rec for _, rec in parsed if rec is not None]
 
 
 def load_toad(stream):
