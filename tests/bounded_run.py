@@ -2,9 +2,10 @@
 where the child sits instead of only killing it: the child and its descendants run in their own
 process group under PYTHONFAULTHANDLER; at the deadline the group gets SIGABRT (every Python in it
 prints the stack of each of its threads), then SIGKILL, and what they printed is kept in
-gpurun_out/hang_<label>.log.  The launch is then repeated ONCE -- one run of the suite in round 5 lost
-a rank under torch.distributed.run + RCCL without a trace, and a second start
-tells a stuck box from a broken build; the repetition is reported as a warning, never silently."""
+gpurun_out/hang_<label>.log.  A hang FAILS the test.  One run of the suite in round 5 lost a rank
+under torch.distributed.run + RCCL without a trace (HISTORY.md section 5): `retry=True` -- the
+multi-rank launches only -- or THR_TEST_RETRY_HANGS=1 repeats such a launch ONCE, with a warning; a
+deadlock in the library's own threads (input window, text thread) must never pass on a second start."""
 import os
 import signal
 import subprocess
@@ -41,8 +42,9 @@ def _once(cmd, env, cwd, timeout):
             timeout, " ".join(cmd), (out or "")[-4000:], (err or "")[-12000:])
 
 
-def run(cmd, env=None, cwd=ROOT, timeout=300, label="child"):
-    """-> Result(returncode, stdout, stderr).  Raises AssertionError if the child is silent twice."""
+def run(cmd, env=None, cwd=ROOT, timeout=300, label="child", retry=False):
+    """-> Result(returncode, stdout, stderr).  Raises AssertionError if the child is silent (with
+    `retry` or THR_TEST_RETRY_HANGS=1: silent twice)."""
     res, hang = _once(cmd, env, cwd, timeout)
     if res is not None:
         return res
@@ -53,6 +55,8 @@ def run(cmd, env=None, cwd=ROOT, timeout=300, label="child"):
             f.write(hang)
     except OSError:
         log = "(not written)"
+    if not (retry or os.environ.get("THR_TEST_RETRY_HANGS") == "1"):
+        raise AssertionError("%s: child process hung, stacks in %s\n%s" % (label, log, hang[-6000:]))
     warnings.warn("%s: child process hung, stacks in %s; started once more" % (label, log))
     res, again = _once(cmd, env, cwd, timeout)
     assert res is not None, "hung twice:\n" + hang[-6000:] + "\n==== second start\n" + again[-3000:]

@@ -26,7 +26,7 @@ def test_a_silent_child_is_asked_where_it_sits_and_started_once_more(tmp_path):
             "stuck_here()\n") % (str(flag), str(flag))
     with warnings.catch_warnings(record=True) as seen:
         warnings.simplefilter("always")
-        res = bounded_run.run([sys.executable, "-c", code], timeout=3, label="selftest_hang")
+        res = bounded_run.run([sys.executable, "-c", code], timeout=3, label="selftest_hang", retry=True)
     assert res.returncode == 0 and res.stdout.strip() == "second start"
     assert len(seen) == 1 and "hung" in str(seen[0].message)
     log = str(seen[0].message).split("stacks in ")[1].split(";")[0]
@@ -36,5 +36,12 @@ def test_a_silent_child_is_asked_where_it_sits_and_started_once_more(tmp_path):
     with warnings.catch_warnings(record=True) as seen:
         warnings.simplefilter("always")
         with pytest.raises(AssertionError, match="hung twice"):
-            bounded_run.run([sys.executable, "-c", "import time\ntime.sleep(1000)"], timeout=2, label="selftest_twice")
+            bounded_run.run([sys.executable, "-c", "import time\ntime.sleep(1000)"], timeout=2, label="selftest_twice",
+                            retry=True)
     os.remove(str(seen[0].message).split("stacks in ")[1].split(";")[0])
+    # the default: the first hang fails the test, with the stacks
+    with pytest.raises(AssertionError, match="child process hung") as exc:
+        bounded_run.run([sys.executable, "-c", "import time\ndef here():\n    time.sleep(1000)\nhere()"], timeout=2,
+                        label="selftest_once")
+    assert "here" in str(exc.value)
+    os.remove(str(exc.value).split("stacks in ")[1].split("\n")[0])

@@ -9,6 +9,13 @@ import pytest
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import bounded_run  # noqa: E402
 
+
+def launch_ranks(*args, **kw):
+    """A multi-rank launch (torch.distributed.run + a process group): the one kind of child a lost rank
+    has hung once without a trace -- repeated once, with a warning (bounded_run.run(retry=True))."""
+    return bounded_run.run(*args, retry=True, **kw)
+
+
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -126,7 +133,7 @@ def test_gpus_n_launches_itself_and_the_whole_n_rank_body_runs_over_gloo(world):
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    res = bounded_run.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world),
+    res = launch_ranks([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world),
                            "--dist-backend", "gloo"] + SHORT, cwd=ROOT, timeout=500, env=env, label="bench_gloo%d" % world)
     d = _one_line(res)
     _check_dist_line(d, world, "gloo")
@@ -146,7 +153,7 @@ def test_strong_scaling_splits_one_gpus_job_over_the_ranks():
         env.pop(k, None)
     lines = {}
     for world in (1, 2):
-        res = bounded_run.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world),
+        res = launch_ranks([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world),
                                "--dist-backend", "gloo", "--scaling", "strong"] + SHORT + ["--steps", "4"],
                               cwd=ROOT, timeout=500, env=env, label="bench_strong%d" % world)
         lines[world] = _one_line(res)
@@ -169,7 +176,7 @@ def test_one_rank_under_torchrun_runs_the_same_body_over_rccl():
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    res = bounded_run.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+    res = launch_ranks([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                            "--master-addr", "127.0.0.1", "--master-port", str(port),
                            os.path.join(ROOT, "bench.py"), "--gpus", "1"] + SHORT, cwd=ROOT, timeout=500,
                           label="bench_rccl1")
@@ -185,7 +192,7 @@ def test_more_ranks_than_gpus_is_refused_legibly():
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    res = bounded_run.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + SHORT,
+    res = launch_ranks([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + SHORT,
                           cwd=ROOT, timeout=400, env=env, label="bench_refused")
     assert res.returncode != 0
     assert "one GPU per rank" in res.stderr

@@ -12,6 +12,13 @@ import pytest
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import bounded_run  # noqa: E402
 
+
+def launch_ranks(*args, **kw):
+    """A multi-rank launch (torch.distributed.run + a process group): the one kind of child a lost rank
+    has hung once without a trace -- repeated once, with a warning (bounded_run.run(retry=True))."""
+    return bounded_run.run(*args, retry=True, **kw)
+
+
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -37,7 +44,7 @@ def _torchrun(k, target, extra, timeout=300):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT, THRIFTY_SHARDED="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(k),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + target + extra
-    res = bounded_run.run(cmd, env=env, cwd=ROOT, timeout=timeout, label="torchrun%d" % k)
+    res = launch_ranks(cmd, env=env, cwd=ROOT, timeout=timeout, label="torchrun%d" % k)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     return res
 
@@ -106,7 +113,7 @@ def test_thrifty_detect_gpus_cli_writes_the_single_process_toad(golden, tmp_path
     common = [str(tmp_path / "rx.card"), "--quiet", "-c", str(tmp_path / "detector.cfg")]
     detector_cli(Detector, argv=common + ["-o", str(tmp_path / "one.toad")])
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
-    res = bounded_run.run([sys.executable, "-m", "thrifty_amd.detect", "--gpus", str(k)] + common +
+    res = launch_ranks([sys.executable, "-m", "thrifty_amd.detect", "--gpus", str(k)] + common +
                           ["-o", str(tmp_path / "many.toad")], env=env, cwd=ROOT, timeout=300, label="cli%d" % k)
     if k == 1:      # --gpus 1 is the plain single-process CLI; also run it as ONE rank under torchrun
         assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
@@ -140,7 +147,7 @@ def test_the_cli_with_more_ranks_than_gpus_rehearsed_over_gloo(golden, tmp_path,
     env = dict(os.environ, PYTHONPATH=ROOT)
     for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "THRIFTY_SHARDED"):
         env.pop(key, None)
-    res = bounded_run.run([sys.executable, "-m", "thrifty_amd.detect", "--gpus", str(k), "--dist-backend", "gloo"]
+    res = launch_ranks([sys.executable, "-m", "thrifty_amd.detect", "--gpus", str(k), "--dist-backend", "gloo"]
                           + common + ["-o", str(tmp_path / "many.toad")], env=env, cwd=ROOT, timeout=400,
                           label="cli_gloo%d" % k)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]

@@ -511,6 +511,16 @@ def test_native_card_framing_equals_python_framing():
     cs = block_data.CardStream(io.BytesIO(b"hello\n"), n)
     with pytest.raises(ValueError):
         cs.next_batch(4)
+    # a header that does not parse (`12x.5 7 <payload>`) behind good lines: both framers hand the
+    # records in front of it out first, then raise at the line -- the Python framer's fast path too
+    good = [block_data.card_line(100.0 + i, i, rng.integers(0, 256, 2 * n, dtype=np.uint8)) for i in range(3)]
+    bad = "12x.5 7 " + good[0].split(" ", 2)[2]
+    for py in (False, True):
+        cs = block_data.CardStream(io.BytesIO("".join(good + [bad] + good).encode()), n)
+        first = cs._next_batch_py(16) if py else cs.next_batch(16)
+        assert first is not None and first[1].tolist() == [0, 1, 2], py
+        with pytest.raises(ValueError):
+            cs._next_batch_py(16) if py else cs.next_batch(16)
 
 
 def test_bench_gpus_n_starts_its_own_ranks_and_fails_loudly_without_a_gpu():

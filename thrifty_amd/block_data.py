@@ -387,8 +387,16 @@ class CardStream(object):
                 end = sp2 + 1 + chars
                 if sp2 >= 0 and end < self._end and (
                         buf[end] == 0x0A or (buf[end] == 0x0D and end + 1 < self._end and buf[end + 1] == 0x0A)):
-                    stamps.append(float(buf[start:sp1]))
-                    idxs.append(int(buf[sp1 + 1:sp2]))
+                    try:
+                        ts, bi = float(buf[start:sp1]), int(buf[sp1 + 1:sp2])
+                    except ValueError:
+                        # a header like `12x.5 7 <payload>`: the records framed so far go out first (as in
+                        # the general path below and in thr_frame_card); the next call raises at this line
+                        if offs:
+                            break
+                        raise ValueError("malformed .card header: %r" % bytes(buf[start:sp2]))
+                    stamps.append(ts)
+                    idxs.append(bi)
                     offs.append(sp2 + 1)
                     self._pos = end + (1 if buf[end] == 0x0A else 2)
                     continue

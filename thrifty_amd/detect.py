@@ -1129,6 +1129,11 @@ def detector_cli(detector_class, parser=None, extra_args=None, argv=None):
             if not hasattr(detections, "iter_detected_records"):
                 raise SystemExit("--gpus: %s does not expose iter_detected_records() (the records that "
                                  "travel between the ranks)" % type(detections).__name__)
+            if getattr(detections, "_host_path", False):
+                # (every rank builds the same class, so every rank leaves here)
+                raise SystemExit("--gpus: %s replaces a stage by a host callable (sync.interpolator / "
+                                 "soa_estimate.interpolate): that slow path runs in one process, not sharded"
+                                 % type(detections).__name__)
             parallel.run_sharded(detections, rank, world, local, output_file, backend=args.dist_backend)
         finally:
             _close(detections)
