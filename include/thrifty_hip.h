@@ -12,7 +12,7 @@
  * stream), so a host may drive 8 GPUs from 8 processes or threads.
  *
  * No exceptions cross this boundary and no torch / C++ types appear in it: the
- * entry points are function-try-blocks (csrc/api.hip: thr::on_exception) -- host
+ * entry points are function-try-blocks (csrc/handle.hip: thr::on_exception) -- host
  * memory exhaustion or a thread the OS refuses come back as THR_ERR_DEVICE with a
  * message, a half-built handle or input window is torn down first.
  */

@@ -1,4 +1,4 @@
-"""The overlap-save plan of the long-block correlate stage (thr_plan_sections, csrc/api.hip:
+"""The overlap-save plan of the long-block correlate stage (thr_plan_sections, csrc/handle.hip:
 plan_sections), checked on the CPU against the oracle's `despread` / `corr_peak`
 (reference soa_estimator.py:97-102, 137-143): sectioning must reproduce the reference's kept
 lags, its windowed first-max, the peak's neighbours and the stddev sums -- exactly the claims

@@ -1,5 +1,5 @@
 """The overlap-save plan of a 16384-sample block with a short template (thr_plan_sections at
-block_len 16384, csrc/api.hip: plan_sections_4k): up to four sections of 4096 samples cover the
+block_len 16384, csrc/handle.hip: plan_sections_4k): up to four sections of 4096 samples cover the
 unique window, which is what csrc/detect16k_sec.hip builds on.  Checked on the CPU against the
 oracle's `despread` / `corr_peak` (reference soa_estimator.py:97-102, 137-143, 159-170): the
 sections' windowed first-max, its power and the peak's two neighbours must be the block's.  No GPU

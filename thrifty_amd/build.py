@@ -12,9 +12,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libthriftyhip.so")
-SOURCES = ["api.hip", "detect16k.hip", "detect16k_geom0.hip", "detect16k_geom1.hip", "detect16k_geom2.hip", "detect16k_carrier.hip", "detect16k_preshift.hip", "detect16k_sec.hip", "detect_seg.hip", "detect_long.hip", "detect_small.hip", "generic.hip", "card_ingest.hip", "identify.hip", "run_file.hip"]
-HEADERS = ["correlate16k.hpp", "correlate16k_geom.hpp", "detect_common.hpp", "fft_regs.hpp", "kernel_util.hpp", "lmdif8.hpp", "passes_w8.hpp", os.path.join("..", "..", "include", "thrifty_hip.h")]
-HOST_ONLY = ("api.hip", "run_file.hip")     # no kernels: not part of csrc_hash()
+SOURCES = ["handle.hip", "window.hip", "pipeline.hip", "entry.hip", "text.hip", "detect16k.hip", "detect16k_geom0.hip", "detect16k_geom1.hip", "detect16k_geom2.hip", "detect16k_carrier.hip", "detect16k_preshift.hip", "detect16k_sec.hip", "detect_seg.hip", "detect_long.hip", "detect_small.hip", "generic.hip", "card_ingest.hip", "identify.hip", "run_file.hip"]
+HEADERS = ["host_internal.hpp", "correlate16k.hpp", "correlate16k_geom.hpp", "detect_common.hpp", "fft_regs.hpp", "kernel_util.hpp", "lmdif8.hpp", "passes_w8.hpp", os.path.join("..", "..", "include", "thrifty_hip.h")]
+HOST_ONLY = ("handle.hip", "window.hip", "pipeline.hip", "entry.hip", "text.hip", "run_file.hip",
+             "host_internal.hpp")     # no kernels: not part of csrc_hash()
 # per-file code-generation flags (measured on MI355X, see csrc/detect16k_carrier.hip)
 PER_FILE_FLAGS = {"detect16k_carrier.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
                   # the work cursor's atomicAdd stays ONE lane's atomic whose result is waited for where it is

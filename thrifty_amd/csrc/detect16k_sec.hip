@@ -39,7 +39,7 @@
 // OWNS (cfg.seg_lo / seg_hi, section coordinates) to seg_stats[block][section] and k_finish keeps
 // the first section holding the block's largest power (np.argmax: lowest lag) -- the machinery of
 // the long blocks' sections (detect_seg.hip).  No stddev term, no stage dumps:
-// every other launch of a 16384-sample block keeps k_correlate (api.hip chooses).
+// every other launch of a 16384-sample block keeps k_correlate (handle.hip chooses).
 //
 // SEVERAL TEMPLATES (BASELINE configs[4]; one SoaEstimator per template, soa_estimator.py:78-102):
 // the section is transformed ONCE and its spectrum multiplied with each template's in turn --
@@ -730,7 +730,7 @@ size_t park_bytes_4k(int grid) { return Q_MULTI_FORM == 2 ? size_t(grid) * QN * 
 
 // seg_stats: [block of the batch][template][section]; tspec4k: per template conj(FFT(template zero-padded
 // to 4096)) / 4096 in the short-block kernels' lane-coalesced order; ctab_pair: C[32][32] as
-// [j][c] = (C[2 j][c], C[2 j + 1][c]) (api.hip, build_constants); park: park_bytes_4k(grid) of scratch
+// [j][c] = (C[2 j][c], C[2 j + 1][c]) (handle.hip, build_constants); park: park_bytes_4k(grid) of scratch
 hipError_t launch_correlate_4k(int fmt, const void* samples, const DevCfg& cfg, const float2* tables,
                                const float2* twn, const float4* tspec4k, const ShiftParams* shifts,
                                const int* work_list, const int* work_count, CorrStats* seg_stats,

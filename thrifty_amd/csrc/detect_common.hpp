@@ -41,7 +41,7 @@ struct DevCfg {
     // short template (detect16k_sec.hip): [seg_start[g], seg_start[g] + 4096).  In SECTION
     // coordinates (lag - seg_start[g]): it owns the window lags [seg_lo[g], seg_hi[g]) and, for the
     // stddev term, sums the lags [seg_sum_lo[g], seg_sum_hi[g]); the owned ranges tile the block's
-    // [corr_lo, corr_hi) resp. [0, corr_len) exactly once (plan_sections, api.hip).
+    // [corr_lo, corr_hi) resp. [0, corr_len) exactly once (plan_sections, handle.hip).
     int no_row_geom;   // THR_PATH_GENERIC_ROWS: the correlate launches take the generic kernel (cross-checks)
     int n_seg;
     int seg_start[kMaxSections];

@@ -10,7 +10,7 @@
 // 65536-sample block; each is one work item of the same kernel a 16384-sample block runs, and what
 // leaves the CU per section is one 32-byte CorrStats -- against the 0.75 MiB of parked rows per
 // block of the decimated form (detect_long.hip), which stays for stage dumps and for templates too
-// long to section (api.hip: plan_sections).  k_finish (detect16k_carrier.hip) keeps, per block and
+// long to section (handle.hip: plan_sections).  k_finish (detect16k_carrier.hip) keeps, per block and
 // template, the first section holding the maximum (soa_estimator.py:137-143: np.argmax takes the
 // lowest lag, and the owned lag ranges ascend with the section index).
 #include <hip/hip_runtime.h>

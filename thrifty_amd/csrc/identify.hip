@@ -19,7 +19,7 @@
 
 namespace thr {
 int fail_msg(int code, const char* fmt, ...);
-int on_exception(const char* who) noexcept;  // api.hip
+int on_exception(const char* who) noexcept;  // handle.hip
 }
 
 namespace {
