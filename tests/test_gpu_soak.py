@@ -95,8 +95,8 @@ def test_an_eighth_of_the_baseline_workload_equals_the_oracle():
 
 def test_four_templates_fresh_blocks_equal_the_oracle_per_template():
     """BASELINE configs[4] in-suite at soak size: 4096 fresh blocks whose bursts use the four
-    templates in turn, through the several-template k_correlate (window rows at compile time,
-    late-table pass B) in 16384-slot launch shape; every template column against ITS oracle --
+    templates in turn, through the sectioned correlate stage (k_correlate_4k with several templates:
+    one forward transform per section, a product + inverse per template); every template column against ITS oracle --
     indices and verdicts exact, floats inside this file's tolerances."""
     nb, T = 4096, 4
     rng = np.random.default_rng(20260929)
@@ -112,6 +112,7 @@ def test_four_templates_fresh_blocks_equal_the_oracle_per_template():
     has = np.concatenate(has)[order]
     which = np.repeat(np.arange(T), nb // T)[order]          # the template each block's burst uses
     eng = F.Engine(N, H, tpls, (0, 15, 0), (7, 110), (0, 15, 0), max_batch=nb)
+    assert eng.sections() == (4, 4096) and eng.path_info()["correlate_kernel"] == "k_correlate_4k"
     rec = eng.detect(blocks, np.arange(nb))
     assert rec.shape == (nb, T) and np.array_equal(rec["template_id"], np.tile(np.arange(T), (nb, 1)))
     for t in range(T):

@@ -4,7 +4,10 @@ variant: default (BASELINE configs[1]) | preshift | fullwin (configs[1] with the
 carrier window '0--1': the full-spectrum carrier kernel) | c3 (configs[2]: 65536-sample blocks, the
 sectioned correlate stage) | c3u (the same through the unsectioned kernels) | n32k (32768-sample
 blocks, same template: three sections) | c1 (BASELINE configs[0]'s geometry: the example detector.cfg --
-history 4920, the 4914-sample extracted template of tests/golden/c1.npz -- on 16384-sample blocks)"""
+history 4920, the 4914-sample extracted template of tests/golden/c1.npz -- on 16384-sample blocks) |
+t4 (BASELINE configs[4]: configs[1] with FOUR Gold templates per block through the sectioned correlate
+stage; the bursts carry template 0, every template's record column is checked against ITS oracle --
+for the other three that is the first-max of a noise-like cross-correlation, sample index exact)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import multiprocessing as mp
@@ -39,7 +42,7 @@ def geometry(variant):
 
 def work(args):
     os.environ["OMP_NUM_THREADS"] = "1"
-    lo, blocks, tpl, variant = args
+    lo, blocks, tpl, variant, col = args
     from oracle import thrifty_np as onp
     N, cwin, _, _ = geometry(variant)
     if variant == "preshift":
@@ -55,7 +58,7 @@ def work(args):
         out.append((r.carrier.bin, r.carrier.detected, r.carrier.offset,
                     c.sample if c else -1, bool(c.detected) if c else False,
                     c.energy if c else 0.0, c.offset if c else 0.0))
-    return lo, out
+    return lo, col, out
 
 
 def main():
@@ -74,27 +77,33 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(777)
     data = bench.synth_on_device(torch, dev, gen, total, N, synth_tpl, window, 0.9)
-    eng = F.Engine(N, h, tpl, (0, 15, 0), cwin, (0, 15, 0), max_batch=8192,
+    tpls = [tpl]
+    if variant == "t4":
+        tpls = [synth.gold_template(bits, 2 + i, sps).astype(np.float64) for i in range(4)]
+    n_tpl = len(tpls)
+    eng = F.Engine(N, h, tpl if n_tpl == 1 else np.stack(tpls), (0, 15, 0), cwin, (0, 15, 0), max_batch=8192,
                    preshift_num=21 if variant == "preshift" else 0,
                    path="unsectioned" if variant == "c3u" else "auto")
-    rec = torch.zeros((total, 64), dtype=torch.uint8, device=dev)
+    rec = torch.zeros((total * n_tpl, 64), dtype=torch.uint8, device=dev)
+    if variant == "t4":
+        print("engine path:", eng.path_info()["text"], flush=True)
     torch.cuda.synchronize()
     for s in range(0, total, 8192):
         nb = min(8192, total - s)
-        eng.detect_device(data[s:s + nb].data_ptr(), F.THR_IN_U8, nb, rec[s:].data_ptr())
+        eng.detect_device(data[s:s + nb].data_ptr(), F.THR_IN_U8, nb, rec[s * n_tpl:].data_ptr())
     eng.sync()
-    rec = rec.cpu().numpy().view(F.RECORD_DTYPE).reshape(-1)
+    rec = rec.cpu().numpy().view(F.RECORD_DTYPE).reshape(total, n_tpl)
     host = data.cpu().numpy()
     chunk = 256 if N == 16384 else 64
-    jobs = [(s, host[s:s + chunk], tpl, variant) for s in range(0, total, chunk)]
+    jobs = [(s, host[s:s + chunk], tpls[t], variant, t) for t in range(n_tpl) for s in range(0, total, chunk)]
     t0 = time.perf_counter()
     mism = dict(bin=0, carrier=0, sample=0, det=0, energy=0, offset=0, car_off=0)
     worst = dict(energy=0.0, offset=0.0, car_off=0.0)
     dc = dict(blocks=0, energy=0.0, car_off=0.0)
     with mp.Pool(procs) as pool:
-        for lo, out in pool.imap_unordered(work, jobs):
+        for lo, col, out in pool.imap_unordered(work, jobs):
             for i, (cbin, cdet, coff, samp, det, en, off) in enumerate(out):
-                r = rec[lo + i]
+                r = rec[lo + i, col]
                 if r["carrier_bin"] != cbin:
                     mism["bin"] += 1
                     from oracle import thrifty_np as onp
@@ -105,7 +114,17 @@ def main():
                 mism["carrier"] += bool(r["flags"] & F.FLAG_CARRIER) != cdet
                 if not cdet:
                     continue
-                mism["sample"] += r["corr_sample"] != samp
+                if r["corr_sample"] != samp:
+                    mism["sample"] += 1
+                    # what the reference's own correlation holds at the two lags: equal to the last float32
+                    # digit means a tie np.argmax breaks by position and this engine by its rounding
+                    from oracle import thrifty_np as onp
+                    orc = onp.OracleDetector(N, h, tpls[col], (0, 15, 0), cwin, (0, 15, 0))
+                    _, data = orc.detect_u8(lo + i, host[lo + i], want_data=True)
+                    cm = np.abs(data[0][1])
+                    a, b = float(cm[r["corr_sample"]]), float(cm[samp])
+                    print("sample mismatch at block %d template %d: gpu lag %d |corr|=%.9g, oracle lag %d |corr|=%.9g "
+                          "(rel diff %.3g); detected=%s" % (lo + i, col, r["corr_sample"], a, samp, b, abs(a - b) / b, det))
                 mism["det"] += bool(r["flags"] & F.FLAG_CORR) != det
                 e = abs(r["corr_energy"] - en) / abs(en)
                 o = abs(r["corr_offset"] - off) if det else 0.0
@@ -125,7 +144,7 @@ def main():
                 mism["car_off"] += co > 1e-3
     dt = time.perf_counter() - t0
     print("variant=%s blocks=%d procs=%d oracle %.0f blocks/s (%.1f s)  mismatches=%s  worst=%s" % (
-        variant, total, procs, total / dt, dt, {k: int(v) for k, v in mism.items()},
+        variant, total, procs, total * n_tpl / dt, dt, {k: int(v) for k, v in mism.items()},
         {k: float("%.3g" % v) for k, v in worst.items()}) +
         ("" if not dc["blocks"] else "  DC-spike 'carriers' (bin 0, floats not counted): %s" % {
             k: float("%.3g" % v) for k, v in dc.items()}))
