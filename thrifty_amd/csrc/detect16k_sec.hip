@@ -273,8 +273,50 @@ __device__ __forceinline__ void q_passA_ld(cpx* lds, cpx* z, const f4* __restric
     });
 }
 
-// Pass B beside a live spectrum: inv_passB<true, true> of passes_w8.hpp (table twiddles in two halves)
-// with the second half requested behind the butterfly instead of behind the first half's use
+// Pass B (radix 32 over k2, in place; thread (row, n3)) with its table twiddles W_4096^(row q) =
+// W_16384^(4 row q) from the PAIR table behind the shared one (handle.hip, build_constants):
+// gtwp[(4 row * 16 + j) * 32 + n3] = (W[32 (2 j) + n3], W[32 (2 j + 1) + n3]) -- sixteen 16-byte loads
+// per thread and pass instead of thirty-two 8-byte ones (8-byte accesses run at 0.54-0.70 x the
+// 16-byte rate, MI355X_MICROARCH.md: one template -1.9 %, four templates -3.7 %, three interleaved
+// rounds each).  HALVES: the spectrum stays live beside this pass (several templates): the twiddles
+// come in two halves, the second requested behind the butterfly.
+#ifndef THR_Q_PAIRED_B
+#define THR_Q_PAIRED_B 1   // dev A/B: 0 = the shared table, 8-byte loads
+#endif
+template <bool HALVES>
+__device__ __forceinline__ void q_passB(cpx* lds, const f4* __restrict__ gtwp) {
+    const int t = opaque_tid();
+    const int k1 = t >> 5, n3 = t & 31;
+    cpx* base = lds + k1 * ROW + n3;
+    cpx v[R2];
+#pragma unroll
+    for (int k2 = 0; k2 < R2; ++k2) v[k2] = lds_b64(base + k2 * CHUNK);
+    const char* tw = reinterpret_cast<const char*>(gtwp) + unsigned(k1 * (16 / QR) * 16 * 32 + n3) * 16u;
+    f4 w[R2 / 2];
+    constexpr int FIRST = HALVES ? R2 / 4 : R2 / 2;
+    static_for<FIRST>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        w[j] = *reinterpret_cast<const f4*>(tw + j * 512);
+    });
+    dft_reg<R2, +1>(v);
+    if constexpr (HALVES) {
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<R2 / 4>([&](auto J) {
+            constexpr int j = R2 / 4 + decltype(J)::value;
+            w[j] = *reinterpret_cast<const f4*>(tw + j * 512);
+        });
+    }
+    static_for<R2 / 2>([&](auto J) {
+        constexpr int j = decltype(J)::value, n2 = 2 * j;
+        cpx y0, y1;
+        cmulc2(v[brev(n2, R2)], cpx{w[j].x, w[j].y}, v[brev(n2 + 1, R2)], cpx{w[j].z, w[j].w}, y0, y1);
+        base[n2 * CHUNK] = y0;
+        base[(n2 + 1) * CHUNK] = y1;
+    });
+}
+
+// (dev A/B, THR_Q_PAIRED_B = 0) the same beside a live spectrum on the shared table: inv_passB<true, true>
+// of passes_w8.hpp with the second half requested behind the butterfly
 __device__ __forceinline__ void q_passB_ld(cpx* lds, const cpx* __restrict__ gtw, int tw_row) {
     const int t = opaque_tid();
     const int k1 = t >> 5, n3 = t & 31;
@@ -564,7 +606,9 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(2))) void k_
             q_passA(lds, z, cw);
         __builtin_amdgcn_sched_barrier(0);
         THR_STAMP(7);
-        if constexpr (MULTI == 1)
+        if constexpr (THR_Q_PAIRED_B)
+            q_passB<MULTI == 1>(lds, reinterpret_cast<const f4*>(gtw + 16 * 1024));   // (the pair table follows the shared one)
+        else if constexpr (MULTI == 1)
             q_passB_ld(lds, gtw, (opaque_tid() >> 5) * (16 / QR));
         else
             inv_passB<true>(lds, gtw, (opaque_tid() >> 5) * (16 / QR));
@@ -659,7 +703,6 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(2))) void k_
         // |corr[pk - 1 .. pk + 1]|^2 for the log-parabola.  pk is uniform in the workgroup, so WHICH of
         // its 32 powers a thread would contribute, q = n1 * 8 + j of lag n = n1 * 1024 + 8 t + j, is
         // uniform too: one scalar jump picks the register, the one thread that holds the lag stores it
-#ifndef THR_Q_NO_NEIGH
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const int n = pk - 1 + d;
@@ -679,7 +722,6 @@ __global__ __launch_bounds__(QT) __attribute__((amdgpu_waves_per_eu(2))) void k_
             }
             if (((n & 1023) >> 3) == t) cs->m2[d] = val;
         }
-#endif
         if (t == 0) {
             cs->pm2 = __uint_as_float(unsigned(best >> 32));
             cs->pk = pk;

@@ -33,7 +33,7 @@ struct DevCfg {
                                     // size for packed blocks, 2 (N - H) for raw-stream framing
     int car_prune;     // pruned FFT#1 (16384 path): 0 off, 1 window+margin inside bins [0,128),
                        // 2 any window of <= 122 bins (samples pre-shifted by win_lo - 3)
-    const void* gtw;   // [16][1024] W_16384^(k1 q) for k_correlate's passes 1 and B (kernels compiled for the LDS-table form ignore it)
+    const void* gtw;   // [16][1024] W_16384^(k1 q) for k_correlate's passes 1 and B, followed by the same values in the pairs pass B reads (handle.hip; kernels compiled for the LDS-table form ignore it)
     int variant;       // 0 reference Detector, 1 PreshiftDetector, 2 fastdet-compatible (power-domain verdicts)
     int interp;        // PreshiftDetector: carrier interpolator (THR_INTERP_*: 0 parabolic, 1 none, 2 gaussian, 3 cosine)
     // Overlap-save sections of the correlate stage (0 = none): block_len > 16384 (detect_seg.hip):

@@ -191,9 +191,18 @@ int build_constants(thr_handle* h) {
     //     short-block kernels as one L2-resident table in global memory
     h->dev.gtw = nullptr;
     if (h->small || h->fast || h->seg || h->sec4k) {
-        std::vector<float2> g(16 * 1024);
+        std::vector<float2> g(2 * 16 * 1024);
         for (int k1 = 0; k1 < 16; ++k1)
             for (int q = 0; q < 1024; ++q) g[k1 * 1024 + q] = unit_root((long long)k1 * q, 16384);
+        // the same table again in the PAIRS a thread of pass B reads (thread n3 of row k1 needs
+        // W^(k1 (32 n2 + n3)) for n2 = 0 .. 31): [(k1 * 16 + j) * 32 + n3] = (n2 = 2 j, n2 = 2 j + 1) --
+        // sixteen 16-byte loads instead of thirty-two 8-byte ones (passes_w8.hpp: inv_passB)
+        for (int k1 = 0; k1 < 16; ++k1)
+            for (int j = 0; j < 16; ++j)
+                for (int n3 = 0; n3 < 32; ++n3)
+                    for (int e = 0; e < 2; ++e)
+                        g[16 * 1024 + ((k1 * 16 + j) * 32 + n3) * 2 + e] =
+                            unit_root((long long)k1 * (32 * (2 * j + e) + n3), 16384);
         HIP_TRY(hipMalloc(&h->d_gtw, g.size() * sizeof(float2)));
         HIP_TRY(hipMemcpy(h->d_gtw, g.data(), g.size() * sizeof(float2), hipMemcpyHostToDevice));
         h->dev.gtw = h->d_gtw;

@@ -336,7 +336,12 @@ __device__ __forceinline__ void inv_passB(cpx* lds, const cpx* __restrict__ gtw 
     cpx v[R2];
 #pragma unroll
     for (int k2 = 0; k2 < R2; ++k2) v[k2] = lds_b64(base + k2 * CHUNK);
+    // GTW: twiddles W_N^(k1 (32 n2 + n3)) from the L2-resident table; one template: out of its PAIR half
+    // (behind the 16 x 1024 entries: [(row * 16 + j) * 32 + n3] = (n2 = 2 j, n2 = 2 j + 1), handle.hip) --
+    // sixteen 16-byte loads per thread instead of thirty-two 8-byte ones
     if constexpr (GTW && GTW_LATE) {
+        // (8-byte loads from the plain table: these kernels sit at 256 VGPRs, and the pair form's
+        // addressing spills there)
         const cpx* tw = gtw + (tw_row >= 0 ? tw_row : k1) * 1024 + n3;
         cpx w[R2 / 2];
 #pragma unroll
@@ -360,17 +365,18 @@ __device__ __forceinline__ void inv_passB(cpx* lds, const cpx* __restrict__ gtw 
         return;
     }
     if constexpr (GTW) {
-        // twiddles W_N^(k1 (32 n2 + n3)) straight from the L2-resident table: issued before the
-        // butterfly, consumed after it
-        const cpx* tw = gtw + (tw_row >= 0 ? tw_row : k1) * 1024 + n3;
-        cpx w[R2];
-#pragma unroll
-        for (int n2 = 0; n2 < R2; ++n2) w[n2] = tw[n2 * 32];
+        // issued before the butterfly, consumed after it
+        const char* tw = reinterpret_cast<const char*>(gtw + 16 * 1024) +
+                         unsigned(((tw_row >= 0 ? tw_row : k1) * 16) * 32 + n3) * 16u;
+        f4 w[R2 / 2];
+        static_for<R2 / 2>([&](auto J) {
+            w[decltype(J)::value] = *reinterpret_cast<const f4*>(tw + decltype(J)::value * 512);
+        });
         dft_reg<R2, +1>(v);
         static_for<R2 / 2>([&](auto K) {
-            constexpr int n2 = 2 * decltype(K)::value;
+            constexpr int j = decltype(K)::value, n2 = 2 * j;
             cpx y0, y1;
-            cmulc2(v[brev(n2, R2)], w[n2], v[brev(n2 + 1, R2)], w[n2 + 1], y0, y1);
+            cmulc2(v[brev(n2, R2)], cpx{w[j].x, w[j].y}, v[brev(n2 + 1, R2)], cpx{w[j].z, w[j].w}, y0, y1);
             base[n2 * CHUNK] = y0;
             base[(n2 + 1) * CHUNK] = y1;
         });
