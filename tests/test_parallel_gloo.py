@@ -87,6 +87,20 @@ def _selftest_worker(rank, world, port, break_gather, ret):
                 real(tensor, gather_list, dst=dst, group=group)
                 gather_list[1].zero_()           # rank 0 receives something else than was sent
             dist.gather = garbled
+        if break_gather == "device":
+            # neither collective of the run's backend moves the record buffer; a second group does
+            real_g, real_ag = dist.gather, dist.all_gather
+
+            def no_gather(tensor, gather_list=None, dst=0, group=None):
+                if group is None:
+                    raise RuntimeError("no gather on the device backend")
+                return real_g(tensor, gather_list, dst=dst, group=group)
+
+            def no_records(tensor_list, tensor, group=None):
+                if group is None and tensor.dim() == 2:
+                    raise RuntimeError("all_gather refuses the record buffer")
+                return real_ag(tensor_list, tensor, group=group)
+            dist.gather, dist.all_gather = no_gather, no_records
         method = parallel.gather_selftest(world, rank, torch.device("cpu"))
         # ... and the run's own gather then takes the method the rehearsal settled on
         counts = [4, 0, 9][:world]
@@ -98,11 +112,13 @@ def _selftest_worker(rank, world, port, break_gather, ret):
 
 
 @pytest.mark.parametrize("world,break_gather,want", [(2, None, "gather"), (3, None, "gather"),
-                                                     (3, "raises", "all_gather"), (3, "garbles", "all_gather")])
+                                                     (3, "raises", "all_gather"), (3, "garbles", "all_gather"),
+                                                     (3, "device", "host")])
 def test_gather_selftest_settles_the_method_collectively(world, break_gather, want):
     """The pre-flight rehearsal of the record gather (uneven counts, one empty rank): a backend
     whose `gather` raises, or delivers other bytes to rank 0 only, moves EVERY rank to the all_gather
-    form -- and the run's gather then uses it and still arrives complete and in rank order."""
+    form -- and the run's gather then uses it and still arrives complete and in rank order; if that
+    fails too the records travel over a gloo group on the host (64 bytes per detection)."""
     import torch.multiprocessing as mp
     assert parallel.selftest_counts(1) == [3] and parallel.selftest_counts(8)[-1] == 0
     assert len(set(parallel.selftest_counts(8)[:-1])) > 1          # uneven

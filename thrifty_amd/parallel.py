@@ -65,7 +65,8 @@ def populate_threads(world):
     return max(1, min(3, cpu_budget() // max(1, int(world)) - 3))
 
 
-_gather_method = "gather"      # or "all_gather": chosen by gather_selftest() on the real backend
+_gather_method = "gather"      # or "all_gather" / "host": chosen by gather_selftest() on the real backend
+_host_group = None             # method "host": a gloo group beside the device backend's (created collectively)
 
 
 def gather_records(local, world, rank, device=None, group=None, force=False, method=None):
@@ -78,7 +79,9 @@ def gather_records(local, world, rank, device=None, group=None, force=False, met
     method "gather" (default): counts by all_gather, then ONE padded `dist.gather` to rank 0;
     "all_gather": the padded buffers go to every rank and the others drop them -- the same bytes
     over the most exercised collective, what gather_selftest() falls back to if the backend's
-    gather does not work."""
+    gather does not work; "host": the same exchange with CPU tensors over a gloo group beside the
+    device backend's -- 64 bytes per detection do not need the fabric -- the last resort if neither
+    device collective delivers the records."""
     import torch
     import torch.distributed as dist
 
@@ -86,6 +89,10 @@ def gather_records(local, world, rank, device=None, group=None, force=False, met
         return local
     method = method or _gather_method
     dev = local.device if device is None else device
+    if method == "host":
+        got = gather_records(local.cpu(), world, rank, torch.device("cpu"), group=_host_group, force=force,
+                             method="gather")
+        return got.to(dev)
     n = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n, group=group)
@@ -157,10 +164,17 @@ def gather_selftest(world, rank, device, group=None):
         print("pre-flight: gather over %s failed on %d rank(s)%s; falling back to all_gather"
               % (dist.get_backend(group), failed, " (rank %d: %s)" % (rank, why) if why else ""), file=sys.stderr)
         failed2, why2 = one_round("all_gather")
-        if failed2:
-            raise SystemExit("pre-flight: neither gather nor all_gather over %s delivers the ranks' records "
-                             "(rank %d: %s)" % (dist.get_backend(group), rank, why2 or why))
         _gather_method = "all_gather"
+        if failed2:
+            print("pre-flight: all_gather over %s failed too%s; the records travel over a gloo group on the host"
+                  % (dist.get_backend(group), " (rank %d: %s)" % (rank, why2) if why2 else ""), file=sys.stderr)
+            global _host_group
+            _host_group = dist.new_group(backend="gloo")      # (collective: every rank is here)
+            failed3, why3 = one_round("host")
+            if failed3:
+                raise SystemExit("pre-flight: neither gather nor all_gather over %s nor a gloo group delivers the "
+                                 "ranks' records (rank %d: %s)" % (dist.get_backend(group), rank, why3 or why2 or why))
+            _gather_method = "host"
     else:
         _gather_method = "gather"
     return _gather_method
