@@ -156,7 +156,7 @@ def test_rank_env_is_the_same_on_every_launch_route(monkeypatch):
     src = open(os.path.join(root, "bench.py")).read()
     main = src[src.index("def main():"):]
     assert main.index("parallel.rank_env()") < main.index("import torch")
-    cli = open(os.path.join(root, "thrifty_amd", "detect.py")).read()
+    cli = open(os.path.join(root, "thrifty_amd", "detect_cli.py")).read()
     body = cli[cli.index("def detector_cli("):]
     assert body.index("parallel.rank_env()") < body.index("parallel.sharded_env(")
 

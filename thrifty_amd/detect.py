@@ -10,23 +10,20 @@ and re-hydrates records in input order.  There is no CPU fallback.
 """
 from __future__ import annotations
 
-import argparse
 import logging
-import sys
 import time
 from collections import deque, namedtuple
 from types import SimpleNamespace
 
 import numpy as np
 
-from thrifty_amd import _native, toads_data, util
+from thrifty_amd import _native, toads_data
+from thrifty_amd.stages import SoaStage, SyncStage, unique_window      # noqa: F401  (unique_window: part of this module's API)
 try:
     from thrifty_amd import _fastresults
 except ImportError as _exc:      # pragma: no cover -- a tree that was never built
     raise ImportError("thrifty_amd._fastresults is not built: run `python -m thrifty_amd.build` (%s)" % _exc)
-from thrifty_amd.block_data import CardStream, RawStream, block_reader, card_reader
-from thrifty_amd.setting_parsers import normalize_freq_range
-from thrifty_amd.settings import load_args
+from thrifty_amd.block_data import CardStream, RawStream
 
 DetectorSettings = namedtuple("DetectorSettings", [
     "block_len", "history_len", "carrier_len", "carrier_thresh", "carrier_window",
@@ -40,15 +37,6 @@ _UNKNOWN_FILL_S = 0.05   # a source that does not say whether it is live: longes
 _YIELD_DATA_BATCH = 64    # blocks per batch with yield_data (each drags two N-point dumps along)
 
 
-def unique_window(block_len, history_len, template_len):
-    """Half-open range of correlation lags owned by one block (reference
-    soa_estimator.py:20-39)."""
-    assert history_len >= template_len - 1
-    corr_len = block_len - template_len + 1
-    pad = history_len - template_len + 1
-    return pad // 2, corr_len - (pad - pad // 2)
-
-
 def _offset_mode(offset_type):
     """thr_format_toad's carrier_offset_f32 argument for a Detector's `_offset_type`."""
     return 0 if offset_type is float else 2 if offset_type is int else 1
@@ -60,130 +48,6 @@ class _Deferred(object):
 
     def __init__(self, exc):
         self.exc = exc
-
-
-class _SyncStage(object):
-    """`Detector.sync`: what the reference's `DefaultSynchronizer` offers an analysis script
-    (carrier_sync.py:30-118) -- the attributes `thresh_coeffs`, `window`, `weights` and the call
-    `sync(signal) -> (shifted_fft or None, CarrierSyncInfo)` -- evaluated by the engine for ONE
-    block (carrier stage, Dirichlet fit, frequency shift, FFT#2; `thr_debug_stage` returns the
-    shifted spectrum in natural order).  `detector` and `shifter` are stages of fused kernels and
-    cannot be replaced (the reference's own subclasses that do so are separate detectors here:
-    `PreshiftDetector`, `FastDetector`).  `interpolator` CAN be assigned, as the reference's
-    InterpolationDetector does (experimental/detect_carrier_interpol.py:17-40): any callable
-    `(fft_mag, peak_idx) -> offset` -- or None for no sub-bin estimate, carrier_sync.py:66-68 --
-    then runs on the HOST between two engine passes (carrier stage + |FFT#1| out, offsets back in:
-    thr_detect_offsets), a slow path for analysis scripts."""
-
-    _DEVICE_FIT = object()      # `interpolator` not assigned: the engine's own Dirichlet fit (k_fit)
-
-    def __init__(self, det, settings):
-        self._det, self.weights = det, None
-        self.thresh_coeffs, self.window = settings.carrier_thresh, settings.carrier_window
-        # _last: (the shifted_fft handed out, record, corr) of the latest block
-        self._last, self._interpolator = None, self._DEVICE_FIT
-
-    @property
-    def interpolator(self):
-        return self._device_interpolator if self._interpolator is self._DEVICE_FIT else self._interpolator
-
-    @interpolator.setter
-    def interpolator(self, fn):
-        if fn is not None and not callable(fn):
-            raise TypeError("sync.interpolator takes a callable (fft_mag, peak_idx) -> offset, or None")
-        self._interpolator = fn
-        self._det._use_host_interpolator()
-
-    def sync(self, signal):
-        det = self._det
-        if self._interpolator is not self._DEVICE_FIT:
-            # (the stage dump is the engine's OWN pipeline, Dirichlet fit included: it cannot show
-            # the spectrum shifted by somebody else's offset)
-            raise NotImplementedError("sync(block) evaluates the engine's own stages; with a replaced "
-                                      "interpolator use Detector.detect(timestamp, block_idx, block)")
-        arr = det._stack([signal])
-        rec = det._run(arr, np.zeros(1, dtype=np.int64))[0, 0]
-        _, result = det._result(0.0, 0, rec)
-        if result.corr_info is None:
-            self._last = None
-            return None, result.carrier_info
-        xhat, corr = det._engine.debug_stage(arr)
-        shifted_fft = xhat[0]
-        self._last = (shifted_fft, rec, corr[0][:det.soa_estimate.corr_len])
-        return shifted_fft, result.carrier_info
-
-    __call__ = sync
-
-    def detect(self, fft_mag):
-        raise NotImplementedError(
-            "the carrier detector runs inside the engine's carrier kernel, on a block's samples: "
-            "call sync(block) -- or Detector.detect(timestamp, block_idx, block) -- instead")
-
-    detector = detect
-
-    def _device_interpolator(self, fft_mag, peak_idx):
-        raise NotImplementedError("the Dirichlet fit runs inside the engine (k_fit): call sync(block) -- or "
-                                  "assign sync.interpolator a host callable (slow path)")
-
-    def shifter(self, signal, shift):
-        raise NotImplementedError("the frequency shift is fused into the correlate kernel: call sync(block)")
-
-
-class _SoaStage(object):
-    """`Detector.soa_estimate`: the attributes of the reference's `SoaEstimator`
-    (soa_estimator.py:63-92: `template`, `template_energy`, `corr_len`, `window`,
-    `thresh_coeffs`) and the call `soa_estimate(fft) -> (detected, CorrDetectionInfo, corr)` for
-    the spectrum `Detector.sync(block)` has just returned -- the pair of calls that makes up the
-    body of the reference's `Detector.detect` (detect.py:60-78).  Any other spectrum would have to be
-    correlated from host memory, which the engine has no entry point for."""
-
-    _DEVICE = object()          # `interpolate` not assigned: the engine's log-parabola (k_finish)
-
-    def __init__(self, det, settings, template, corr_len):
-        self._det = det
-        self._interpolate = self._DEVICE
-        self.last_fft = None        # the shifted spectrum of the block a replaced `interpolate` is looking at
-        self.template = template
-        self.template_energy = float(np.sum(np.abs(template) ** 2))
-        self.corr_len = corr_len
-        self.thresh_coeffs = settings.corr_thresh
-        self.window = unique_window(settings.block_len, settings.history_len, template.shape[-1])
-
-    @property
-    def interpolate(self):
-        """The correlation-peak interpolator (reference soa_estimator.py:74: `self.interpolate =
-        gaussian_interpolation`).  Assignable like the reference's (experimental/
-        detect_xcorr_interpol.py:62): any callable `(corr_mag, peak_idx) -> offset`, evaluated on the
-        HOST for the detected blocks of a batch -- a slow path for analysis scripts."""
-        return self._device_interpolate if self._interpolate is self._DEVICE else self._interpolate
-
-    @interpolate.setter
-    def interpolate(self, fn):
-        if not callable(fn):
-            raise TypeError("soa_estimate.interpolate takes a callable (corr_mag, peak_idx) -> offset")
-        self._det._use_host_soa_interpolator()
-        self._interpolate = fn
-
-    def _device_interpolate(self, corr_mag, peak_idx):
-        raise NotImplementedError("the log-parabola runs inside the engine (k_finish): call "
-                                  "soa_estimate(shifted_fft) -- or assign soa_estimate.interpolate a host callable")
-
-    def soa_estimate(self, fft):
-        if self._interpolate is not self._DEVICE:
-            raise NotImplementedError("soa_estimate(fft) evaluates the engine's own stages; with a replaced "
-                                      "interpolator use Detector.detect(timestamp, block_idx, block)")
-        last = self._det.sync._last
-        if last is None or fft is not last[0]:
-            raise NotImplementedError(
-                "soa_estimate() takes the shifted spectrum that Detector.sync(block) returned for "
-                "the latest block; arbitrary spectra cannot be handed to the engine")
-        _, rec, corr = last
-        detected = bool(int(rec["flags"]) & _native.FLAG_CORR)
-        info = toads_data.CorrDetectionInfo(int(rec["corr_sample"]), float(rec["corr_offset"]) if detected else 0,
-                                            float(rec["corr_energy"]), float(rec["corr_noise"]))
-        return detected, info, corr
-
-    __call__ = soa_estimate
 
 
 class Detector(object):
@@ -302,8 +166,8 @@ class Detector(object):
         # twins of the reference's sub-objects (detect.py:46-58): the same attributes, and CALLABLE
         # like them -- evaluated by the engine, one block at a time (_SyncStage / _SoaStage below)
         self._host_interp = self._host_soa = False   # a stage replaced by a host callable: the slow path below
-        self.sync = _SyncStage(self, settings)
-        self.soa_estimate = _SoaStage(self, settings, template, corr_len)
+        self.sync = SyncStage(self, settings)
+        self.soa_estimate = SoaStage(self, settings, template, corr_len)
 
     # ------------------------------------------------------------------ core
     def _stack(self, blocks):
@@ -985,201 +849,19 @@ def _write_fd(fd, data):
         view = view[os.write(fd, view):]
 
 
-def _carrier_freq(carrier_info, block_len, sample_rate):
-    bin_freq = sample_rate / block_len
-    return (util.fft_bin(carrier_info.bin, block_len) + carrier_info.offset) * bin_freq
-
-
-class SummaryLineFormatter(object):
-    """One human-readable line per block (reference detect.py:103-158)."""
-
-    def __init__(self, sample_rate, block_len, add_dt=False):
-        self.sample_rate = sample_rate
-        self.block_len = block_len
-        self.add_dt = add_dt
-
-    _CARRIER = ("blk={blk}; carrier: {det} @ {freq:.3f} kHz / {idx:>3.0f}:{offset:+.2f}, "
-                "SNR = {ampl:>4.0f} / {noise:>2.0f} = {snr:>5.2f} dB")
-    _CORR = "; corr: {det} @ {idx:>4}{offset:+.3f}{dt}, SNR = {ampl:>4.0f}/{noise:>2.0f} = {snr:>5.2f} dB"
-
-    @staticmethod
-    def _stage(fmt, mark, info, **extra):
-        """One stage's half of the line: its verdict mark, its four-field info tuple and its SNR."""
-        return fmt.format(det=mark, idx=info[0], offset=info[1], ampl=info[2], noise=info[3],
-                          snr=util.snr(info[2], info[3]), **extra)
-
-    def __call__(self, detected, result):
-        has_carrier = result.corr_info is not None
-        parts = [self._stage(self._CARRIER, "yes" if has_carrier else "no ", result.carrier_info, blk=result.block,
-                             freq=_carrier_freq(result.carrier_info, self.block_len, self.sample_rate) / 1e3)]
-        if has_carrier:
-            parts.append(self._stage(self._CORR, "yes" if detected else "no ", result.corr_info, dt=""))
-        return "".join(parts)
-
-
-def _strip_output_args(argv):
-    """argv without -o/--output/-a/--append (ranks other than 0 must not open -- and with -o
-    truncate -- the output file that rank 0 writes)."""
-    out, skip = [], False
-    for a in argv:
-        if skip:
-            skip = False
-            continue
-        if a in ("-o", "--output", "-a", "--append"):
-            skip = True
-            continue
-        if a.startswith(("--output=", "--append=")) or (a[:2] in ("-o", "-a") and len(a) > 2 and a[1] != "-"):
-            continue
-        out.append(a)
-    return out
-
-
 def detector_cli(detector_class, parser=None, extra_args=None, argv=None):
-    """`thrifty detect` front end (reference detect.py:161-223): same arguments and
-    settings keys; `detector_class(settings, blocks, rxid=..., **kwargs)` must iterate
-    to `(detected, result)` pairs.
-
-    Addition: `--gpus N` shards a regular input file over N GPUs of this node by contiguous
-    block ranges, one process per GPU (re-launched under `torch.distributed.run`); the ranks'
-    detection records are gathered to rank 0 over RCCL and written as ONE `.toad` in input
-    order.  The per-block summary lines are a console aid of the
-    single-process loop and are not printed in that mode."""
-    from thrifty_amd import parallel
-    parallel.rank_env()     # (before the HIP runtime initialises: the same on every launch route)
-    argv = list(sys.argv[1:] if argv is None else argv)
-    gpus = parallel.peek_gpus(argv)
-    # a rank of a sharded run is a process that THIS CLI re-launched, or that torchrun started
-    # with as many ranks as --gpus asks for; RANK / WORLD_SIZE inherited from an unrelated
-    # launcher do not turn a plain `thrifty detect` into one (parallel.sharded_env)
-    rank, world, local = parallel.sharded_env(gpus)
-    if gpus > 1 and world is None:
-        if not any(a in ("-o", "--output", "-a", "--append") or a.startswith(("--output=", "--append="))
-                   or (a[:2] in ("-o", "-a") and len(a) > 2 and a[1] != "-") for a in argv):
-            raise SystemExit("--gpus %d needs an output file (-o / -a): the ranks' detections are "
-                             "gathered and written by rank 0, nothing is printed per block" % gpus)
-        sys.exit(parallel.relaunch_under_torchrun(gpus, argv))
-    if world is not None and rank != 0:
-        argv = _strip_output_args(argv)
-    if parser is None:
-        parser = argparse.ArgumentParser(description=__doc__,
-                                         formatter_class=argparse.RawDescriptionHelpFormatter)
-    parser.add_argument("input", type=argparse.FileType("rb"), default="-",
-                        help="input data ('-' streams from stdin)")
-    parser.add_argument("--raw", dest="raw", action="store_true", help="input data is raw binary data")
-    parser.add_argument("--quiet", dest="quiet", action="store_true",
-                        help="do not write anything to standard output")
-    parser.add_argument("--gpus", dest="gpus", type=int, default=1,
-                        help="shard a regular input file over this many GPUs of the node")
-    parser.add_argument("--dist-backend", dest="dist_backend", choices=["nccl", "gloo"], default="nccl",
-                        help="with --gpus N: nccl = RCCL, one GPU per rank (the real thing); gloo = a "
-                             "rehearsal of the N-rank run on ONE GPU (every rank computes on device 0, "
-                             "the records travel over gloo)")
-    parser.add_argument("--templates", dest="templates", nargs="+", metavar="NPY", default=None,
-                        help="correlate every block against several TX templates (.npy files of "
-                             "equal length, instead of the `template` setting); detections carry "
-                             "the template's position as txid, written after the rxid")
-    group = parser.add_mutually_exclusive_group()
-    group.add_argument("-o", "--output", dest="output", type=argparse.FileType("w"),
-                       help="Output file (.toad) ('-' for stdout)")
-    group.add_argument("-a", "--append", dest="append", type=argparse.FileType("a"),
-                       help="Output file to append to (.toad)")
-    keys = ["sample_rate", "block_size", "block_history", "carrier_window", "carrier_threshold",
-            "corr_threshold", "template", "rxid"]
-    config, args = load_args(parser, keys, argv=argv)
-    kwargs = {a: args[a] for a in extra_args} if extra_args is not None else {}
-
-    output_file = args.output if args.append is None else args.append
-    info_out = sys.stderr if output_file is sys.stdout else sys.stdout
-    window = normalize_freq_range(config.carrier_window, config.sample_rate / config.block_size)
-    if args.raw:
-        # byte stream -> overlapping blocks framed on the device (block_reader-compatible
-        # tuples if the detector class iterates it the classic way)
-        blocks = RawStream(args.input, config.block_size, config.block_history)
-    else:
-        # binary stream -> batches with on-device base64 decode (card_reader-compatible tuples
-        # if the detector class iterates it the classic way)
-        blocks = CardStream(args.input, config.block_size)
-    if args.templates:
-        tpls = [np.load(f) for f in args.templates]
-        if len({t.shape for t in tpls}) != 1 or tpls[0].ndim != 1:
-            raise SystemExit("--templates: the templates must be 1-D arrays of one length")
-        template = np.stack(tpls)
-        if detector_class is Detector:
-            detector_class = MultiTemplateDetector
-    else:
-        template = np.load(config.template)
-    settings = DetectorSettings(block_len=config.block_size, history_len=config.block_history,
-                                carrier_len=template.shape[-1], carrier_thresh=config.carrier_threshold,
-                                carrier_window=window, template=template,
-                                corr_thresh=config.corr_threshold)
-    if world is not None:
-        # one rank of a sharded run (also world == 1 under torchrun: same code path, same collectives)
-        if args.gpus != world:
-            raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-        blocks.shard(rank, world)
-        if "populate_threads" not in kwargs and detector_class in (Detector, MultiTemplateDetector):
-            kwargs["populate_threads"] = parallel.populate_threads(world)   # the ranks share the host's CPUs
-            kwargs["low_cpu"] = parallel.cpu_budget() // max(1, world) < 4  # (fewer than 4 CPUs per rank)
-        if args.dist_backend == "gloo":
-            local = 0               # rehearsal: every rank computes on device 0
-        # torch, the process group and the gather rehearsal first: the engine's threads start with it
-        parallel.init_rank(rank, world, local, backend=args.dist_backend)
-        detections = detector_class(settings, blocks, rxid=config.rxid, device_id=local, **kwargs)
-        try:
-            if not hasattr(detections, "iter_detected_records"):
-                raise SystemExit("--gpus: %s does not expose iter_detected_records() (the records that "
-                                 "travel between the ranks)" % type(detections).__name__)
-            if getattr(detections, "_host_path", False):
-                # (every rank builds the same class, so every rank leaves here)
-                raise SystemExit("--gpus: %s replaces a stage by a host callable (sync.interpolator / "
-                                 "soa_estimate.interpolate): that slow path runs in one process, not sharded"
-                                 % type(detections).__name__)
-            parallel.run_sharded(detections, rank, world, local, output_file, backend=args.dist_backend)
-        finally:
-            _close(detections)
-        return
-    detections = detector_class(settings, blocks, rxid=config.rxid, **kwargs)
-    try:
-        _cli_loop(detections, args, config, output_file, info_out)
-    finally:
-        # the engine goes NOW (threads joined, pages unlocked, device memory back), not whenever the
-        # interpreter's shutdown gets to an object whose stages refer back to it
-        _close(detections)
+    """`thrifty detect` front end (reference detect.py:161-223): same arguments and settings keys;
+    `detector_class(settings, blocks, rxid=..., **kwargs)` must iterate to `(detected, result)` pairs.
+    The implementation is thrifty_amd/detect_cli.py (which also holds `SummaryLineFormatter`)."""
+    from thrifty_amd import detect_cli
+    return detect_cli.detector_cli(detector_class, parser, extra_args, argv)
 
 
-def _close(detections):
-    close = getattr(detections, "close", None)
-    if callable(close):
-        close()
-
-
-def _cli_loop(detections, args, config, output_file, info_out):
-    """The reference's loop (detect.py:214-223) over whatever detector class the caller passed."""
-    if args.quiet and hasattr(detections, "only_detections"):
-        detections.only_detections = True   # nothing is printed for the other blocks anyway
-    if (args.quiet and output_file is not None and hasattr(detections, "write_toad")
-            and not getattr(detections, "_host_path", False)):
-        # nothing per block is needed: a mapped input runs entirely inside the library
-        # (thr_run_card / thr_run_stream), anything else a batch of text at a time
-        detections.write_toad(output_file)
-        return
-    if (args.quiet and output_file is not None and hasattr(detections, "iter_toad_text")
-            and not getattr(detections, "_host_path", False)):
-        for text in detections.iter_toad_text():
-            output_file.write(text.decode("ascii"))
-        output_file.flush()
-        return
-    summary = SummaryLineFormatter(config.sample_rate, config.block_size, add_dt=True)
-    for item in detections:
-        # (one (detected, result) pair per block; a multi-template detector: a list of them)
-        for detected, result in (item if isinstance(item, list) else [item]):
-            if detected and output_file is not None:
-                print(result.serialize(), file=output_file)
-            if not args.quiet:
-                line = summary(detected, result)
-                print(line if result.txid is None else "tx=%d; %s" % (result.txid, line), file=info_out)
-    if output_file is not None:
-        output_file.flush()
+def __getattr__(name):
+    if name == "SummaryLineFormatter":      # (reference detect.py:103-158; lives with the CLI)
+        from thrifty_amd import detect_cli
+        return detect_cli.SummaryLineFormatter
+    raise AttributeError("module %r has no attribute %r" % (__name__, name))
 
 
 def _main():
