@@ -865,7 +865,10 @@ def __getattr__(name):
 
 
 def _main():
-    detector_cli(Detector)
+    # (`python -m thrifty_amd.detect` runs this file as __main__: hand the front end the class of the
+    # IMPORTED module, the one it compares detector classes with)
+    from thrifty_amd import detect, detect_cli
+    detect_cli.detector_cli(detect.Detector)
 
 
 if __name__ == "__main__":
