@@ -77,12 +77,20 @@ def _dump(fn):
     return ast.dump(_Normalise().visit(copy.deepcopy(fn)), annotate_fields=False)
 
 
+# product files whose reference counterpart has another name (code that was split out of a mirror)
+ALSO = {"detect_cli.py": ["detect.py"], "stages.py": ["carrier_sync.py", "soa_estimator.py", "detect.py"],
+        "fastdet.py": ["detect.py"], "parallel.py": ["detect.py"], "synth.py": ["gold.py", "template_generate.py"]}
+
+
 def _reference_files():
     index = {}
     for dirpath, _, files in os.walk(REF):
         for f in files:
             if f.endswith(".py"):
                 index.setdefault(f, []).append(os.path.join(dirpath, f))
+    for ours, theirs in ALSO.items():
+        for name in theirs:
+            index.setdefault(ours, []).extend(index.get(name, []))
     return index
 
 

@@ -24,28 +24,25 @@ _PREFERRED = {
 
 
 def _msequence(nbits, taps):
-    """Maximal-length sequence of a Fibonacci LFSR seeded with all ones."""
-    length = (1 << nbits) - 1
-    out = np.ones(length, dtype=np.uint8)
-    for i in range(nbits, length):
-        bit = out[i - nbits]
-        for t in taps:
-            bit ^= out[i - nbits + t]
-        out[i] = bit
-    return out.astype(bool)
+    """Maximal-length sequence of a Fibonacci LFSR seeded with all ones: the register is an integer
+    whose bit j is chip i + j; the chip entering at the top is the parity of the tapped bits (bit 0 and
+    the feedback exponents)."""
+    mask = sum(1 << t for t in (0,) + tuple(taps))
+    register, chips = (1 << nbits) - 1, []
+    for _ in range((1 << nbits) - 1):
+        chips.append(register & 1)
+        register = (register >> 1) | ((bin(register & mask).count("1") & 1) << (nbits - 1))
+    return np.array(chips, dtype=bool)
 
 
 def gold_code(nbits, index):
-    """index-th Gold code (boolean chips) of length 2**nbits - 1."""
-    if nbits not in _PREFERRED:
+    """index-th Gold code (boolean chips) of length 2**nbits - 1: the two m-sequences of the preferred
+    pair themselves (0, 1), then the first combined with the second rotated by index - 2 chips."""
+    pair = _PREFERRED.get(nbits)
+    if pair is None:
         raise ValueError("Preferred pairs for %d bits unknown." % nbits)
-    a = _msequence(nbits, _PREFERRED[nbits][0])
-    b = _msequence(nbits, _PREFERRED[nbits][1])
-    if index == 0:
-        return a
-    if index == 1:
-        return b
-    return np.logical_xor(a, np.roll(b, 2 - index))
+    first, second = (_msequence(nbits, taps) for taps in pair)
+    return {0: first, 1: second}.get(index, first ^ np.roll(second, 2 - index))
 
 
 def gold_template(nbits, index, sps=1.0):
