@@ -190,8 +190,9 @@ int thr_create_fastdet(const thr_settings* settings, thr_handle** out);
  *                         detect_long.hip, instead of sections of 16384 points, detect_seg.hip --
  *                         AUTO falls back to it by itself for templates longer than 9361 samples at
  *                         65536) and block_len 16384 (k_correlate instead of up to four sections of
- *                         4096 points, detect16k_sec.hip, which AUTO takes for ONE template of at
- *                         most about 1000 samples with no stddev threshold term).  thr_debug_stage
+ *                         4096 points, detect16k_sec.hip, which AUTO takes for templates -- one or
+ *                         several, ABI 9 -- of at most about 1000 samples with no stddev threshold
+ *                         term; thr_get_path_info says which a handle got and why).  thr_debug_stage
  *                         dumps always come from the unsectioned kernels.
  *   THR_PATH_GENERIC_ROWS AUTO, except that the correlate kernel of block_len 16384 (and of the
  *                         sections of longer blocks) is the generic one, with the unique-window test

@@ -187,7 +187,7 @@ int build_constants(thr_handle* h) {
             tab[1536 + k1 * 32 + mp] = unit_root((long long)k1 * mp, h->lng ? 16384 : n);
     HIP_TRY(hipMalloc(&h->d_tables, tab.size() * sizeof(float2)));
     HIP_TRY(hipMemcpy(h->d_tables, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice));
-    // --- pass-1 / pass-B twiddles W_16384^(k1 q) of k_correlate (one template) and of the
+    // --- pass-1 / pass-B twiddles W_16384^(k1 q) of k_correlate and of the
     //     short-block kernels as one L2-resident table in global memory
     h->dev.gtw = nullptr;
     if (h->small || h->fast || h->seg || h->sec4k) {
@@ -655,7 +655,7 @@ static int create_body(thr_handle*& h, const thr_settings* s, int preshift_num, 
         const bool unsectioned = path == THR_PATH_UNSECTIONED || path == THR_PATH_UNSECTIONED_GENERIC_ROWS;
         h->seg = h->lng && !unsectioned && plan_sections(d, s->template_len);
         if (!h->seg) d.n_seg = 0;
-        // block_len 16384, one short template, no stddev term: the correlate stage as 4096-sample
+        // block_len 16384, short template(s), no stddev term: the correlate stage as 4096-sample
         // sections (detect16k_sec.hip); stage dumps and every other launch keep k_correlate
         h->sec4k = h->fast && !preshift_num && d.variant == 0 && !d.cor_want_std &&
                    !unsectioned && plan_sections_4k(d, s->template_len);
