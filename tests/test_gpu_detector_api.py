@@ -60,6 +60,34 @@ def test_iterating_detector_reproduces_reference_toad(golden, name, batch):
     assert_toad_close(lines, g["toad"])
 
 
+@pytest.mark.parametrize("name", ["c2", "c1", "small"])
+def test_batch_built_results_serialize_like_the_library_and_like_python(golden, name):
+    """The results of the iteration are built a batch at a time in C (thrifty_amd._fastresults) and
+    serialize() of an untouched detected one is thr_format_toad's line: it must be the text the library
+    loop writes (iter_toad_lines) AND the text the reference's Python formatting gives for the same
+    attribute values (a result re-built through the reference's constructor formats in Python)."""
+    from thrifty_amd import toads_data
+    g = golden(name)
+    st = settings_of(g)
+    items = [(1000.0 + 0.25 * i, int(g["block_idx"][i]), g["blocks"][i]) for i in range(len(g["blocks"]))]
+    with Detector(st, iter(items), rxid=int(g["rxid"]), batch_size=9) as det:
+        got = list(det)
+    with Detector(st, iter(items), rxid=int(g["rxid"]), batch_size=9) as det:
+        want = [ln for batch in det.iter_toad_lines() for ln in batch]
+    fast = [res.serialize() for detected, res in got if detected]
+    assert fast == want and len(fast) == int(np.sum(g["det"]))
+    for detected, res in got:
+        assert isinstance(res, toads_data.DetectionResult)
+        if not detected:
+            continue
+        assert res._serialize_fast() is not None
+        plain = toads_data.DetectionResult(res.timestamp, res.block, res.soa, res.carrier_info, res.corr_info,
+                                           res.rxid, res.txid)
+        assert plain._serialize_fast() is None and plain.serialize() == res.serialize()
+        assert type(res.carrier_info.energy) is np.float32 and type(res.corr_info.energy) is float
+        assert res.soa == det.new_len * res.block + res.corr_info.sample + res.corr_info.offset
+
+
 def test_single_block_detect_and_yield_data(golden):
     g = golden("c2")
     st = settings_of(g)
