@@ -291,19 +291,21 @@ __device__ __forceinline__ void q_passB(cpx* lds, const f4* __restrict__ gtwp) {
     cpx v[R2];
 #pragma unroll
     for (int k2 = 0; k2 < R2; ++k2) v[k2] = lds_b64(base + k2 * CHUNK);
-    const char* tw = reinterpret_cast<const char*>(gtwp) + unsigned(k1 * (16 / QR) * 16 * 32 + n3) * 16u;
+    // (uniform base + 32-bit lane offset: the saddr form of global_load, no 64-bit address held per lane)
+    const char* tw = reinterpret_cast<const char*>(gtwp);
+    const unsigned off = unsigned(k1 * (16 / QR) * 16 * 32 + n3) * 16u;
     f4 w[R2 / 2];
     constexpr int FIRST = HALVES ? R2 / 4 : R2 / 2;
     static_for<FIRST>([&](auto J) {
         constexpr int j = decltype(J)::value;
-        w[j] = *reinterpret_cast<const f4*>(tw + j * 512);
+        w[j] = *reinterpret_cast<const f4*>(tw + (off + unsigned(j * 512)));
     });
     dft_reg<R2, +1>(v);
     if constexpr (HALVES) {
         __builtin_amdgcn_sched_barrier(0);
         static_for<R2 / 4>([&](auto J) {
             constexpr int j = R2 / 4 + decltype(J)::value;
-            w[j] = *reinterpret_cast<const f4*>(tw + j * 512);
+            w[j] = *reinterpret_cast<const f4*>(tw + (off + unsigned(j * 512)));
         });
     }
     static_for<R2 / 2>([&](auto J) {

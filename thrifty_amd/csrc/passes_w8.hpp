@@ -340,37 +340,41 @@ __device__ __forceinline__ void inv_passB(cpx* lds, const cpx* __restrict__ gtw 
     // (behind the 16 x 1024 entries: [(row * 16 + j) * 32 + n3] = (n2 = 2 j, n2 = 2 j + 1), handle.hip) --
     // sixteen 16-byte loads per thread instead of thirty-two 8-byte ones
     if constexpr (GTW && GTW_LATE) {
-        // (8-byte loads from the plain table: these kernels sit at 256 VGPRs, and the pair form's
-        // addressing spills there)
-        const cpx* tw = gtw + (tw_row >= 0 ? tw_row : k1) * 1024 + n3;
-        cpx w[R2 / 2];
-#pragma unroll
-        for (int n2 = 0; n2 < R2 / 2; ++n2) w[n2] = tw[n2 * 32];
+        // (uniform base + 32-bit lane offset: with a 64-bit address held per lane across the butterfly
+        // these kernels, which sit at 256 VGPRs, spill)
+        const char* tw = reinterpret_cast<const char*>(gtw + 16 * 1024);
+        const unsigned off = unsigned(((tw_row >= 0 ? tw_row : k1) * 16) * 32 + n3) * 16u;
+        f4 w[R2 / 4];
+        static_for<R2 / 4>([&](auto J) {
+            w[decltype(J)::value] = *reinterpret_cast<const f4*>(tw + (off + unsigned(decltype(J)::value * 512)));
+        });
         dft_reg<R2, +1>(v);
         static_for<2>([&](auto H) {
             constexpr int h = decltype(H)::value;
             static_for<R2 / 4>([&](auto K) {
-                constexpr int n2 = h * (R2 / 2) + 2 * decltype(K)::value;
+                constexpr int jj = decltype(K)::value, n2 = h * (R2 / 2) + 2 * jj;
                 cpx y0, y1;
-                cmulc2(v[brev(n2, R2)], w[n2 - h * (R2 / 2)], v[brev(n2 + 1, R2)], w[n2 + 1 - h * (R2 / 2)], y0, y1);
+                cmulc2(v[brev(n2, R2)], cpx{w[jj].x, w[jj].y}, v[brev(n2 + 1, R2)], cpx{w[jj].z, w[jj].w}, y0, y1);
                 base[n2 * CHUNK] = y0;
                 base[(n2 + 1) * CHUNK] = y1;
             });
             if constexpr (h == 0) {
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int n2 = 0; n2 < R2 / 2; ++n2) w[n2] = tw[(n2 + R2 / 2) * 32];
+                static_for<R2 / 4>([&](auto J) {
+                    w[decltype(J)::value] =
+                        *reinterpret_cast<const f4*>(tw + (off + unsigned((R2 / 4 + decltype(J)::value) * 512)));
+                });
             }
         });
         return;
     }
     if constexpr (GTW) {
         // issued before the butterfly, consumed after it
-        const char* tw = reinterpret_cast<const char*>(gtw + 16 * 1024) +
-                         unsigned(((tw_row >= 0 ? tw_row : k1) * 16) * 32 + n3) * 16u;
+        const char* tw = reinterpret_cast<const char*>(gtw + 16 * 1024);
+        const unsigned off = unsigned(((tw_row >= 0 ? tw_row : k1) * 16) * 32 + n3) * 16u;
         f4 w[R2 / 2];
         static_for<R2 / 2>([&](auto J) {
-            w[decltype(J)::value] = *reinterpret_cast<const f4*>(tw + decltype(J)::value * 512);
+            w[decltype(J)::value] = *reinterpret_cast<const f4*>(tw + (off + unsigned(decltype(J)::value * 512)));
         });
         dft_reg<R2, +1>(v);
         static_for<R2 / 2>([&](auto K) {
